@@ -1,0 +1,319 @@
+"""Cell / facet classification against a level-set (oracle; test infrastructure only).
+
+numpy restatement of `src/phifem/mesh_scripts.py` (a2-a8 of SURVEY.md section 8):
+  detection vector      mesh_scripts.py:95-134
+  cell tags             mesh_scripts.py:284-390
+  facet tags            mesh_scripts.py:393-558   (set algebra restated as per-facet predicates)
+  integration entities  mesh_scripts.py:137-192
+  tag transfer/submesh  mesh_scripts.py:217-281, 636-645
+  overwrite             mesh_scripts.py:561-568
+  orchestration         mesh_scripts.py:571-653
+
+Deviations that cannot be avoided without dolfinx/FFCx [3P] (all confined to cases where a
+sum of mixed-sign samples is within one ulp of the sum of their magnitudes):
+  * the common |detJ| factor of the `dx` detection sums and the per-facet measure factor of
+    the `ds` detection sums are dropped;
+  * a cell's boundary facets are accumulated in ascending LOCAL facet order.
+"""
+import warnings
+
+import numpy as np
+
+from . import points as P
+from .topology import Topology
+
+debug_mode = False  # mesh_scripts.py:22-25 (MODE=debug); tests flip it explicitly
+
+
+class MeshTags:
+    """Shape of dolfinx.mesh.MeshTags as used at mesh_scripts.py:386-388,425-427,562-567."""
+
+    def __init__(self, dim, indices, values):
+        self.dim = int(dim)
+        self.indices = np.asarray(indices, dtype=np.int32)
+        self.values = np.asarray(values, dtype=np.int32)
+        if self.indices.size and np.any(np.diff(self.indices) <= 0):
+            # [3P] dolfinx MeshTags rejects unsorted / duplicated entities
+            raise ValueError("MeshTags entities must be sorted and unique")
+
+    def find(self, v):
+        return self.indices[self.values == v]
+
+
+class NodalP1:
+    """phi given by its values at the mesh vertices (a `dolfinx.fem.Function` in P1)."""
+
+    def __init__(self, values):
+        self.values = np.asarray(values, dtype=np.float64)
+
+
+def _seq_dot(N, vals):
+    """sum_i N[q,i]*vals[...,i] accumulated left to right (no pairwise summation)."""
+    acc = N[:, 0] * vals[..., 0:1]
+    for i in range(1, N.shape[1]):
+        acc = acc + N[:, i] * vals[..., i:i + 1]
+    return acc
+
+
+def _eval_on(levelset, Nmat, vert_ids, x):
+    """phi at points given by shape-function rows `Nmat` over vertices `vert_ids` (n, k)."""
+    if isinstance(levelset, NodalP1):
+        return _seq_dot(Nmat, levelset.values[vert_ids])  # (n, npts)
+    gdim = x.shape[1]
+    xq = np.stack([_seq_dot(Nmat, x[vert_ids, d]) for d in range(gdim)], axis=0)
+    n, npts = xq.shape[1], xq.shape[2]
+    with np.errstate(all="ignore"):
+        vals = levelset(xq.reshape(gdim, n * npts))
+    return np.asarray(vals, dtype=np.float64).reshape(n, npts)
+
+
+def _ratio(phi_q):
+    """mesh_scripts.py:112-134 with sequential sums."""
+    num = phi_q[:, 0].copy()
+    den = np.abs(phi_q[:, 0])
+    for q in range(1, phi_q.shape[1]):
+        num = num + phi_q[:, q]
+        den = den + np.abs(phi_q[:, q])
+    d = np.full_like(num, 0.5)
+    ok = den > 0.0
+    with np.errstate(all="ignore"):
+        d[ok] = num[ok] / den[ok]
+    return d, den
+
+
+def cell_detection_vector(topo, x, levelset, degree, warn=True):
+    pts = P.cell_detection_points(topo.cell_type, degree)
+    Nmat = P.shape_functions(topo.cell_type, pts)
+    d, den = _ratio(_eval_on(levelset, Nmat, topo.cells, x))
+    if warn and np.any(np.isclose(den, 0.0)):
+        warnings.warn("The detection function is zero everywhere on a cell. We mark it as "
+                      "'cut' but this can be incorrect and should be carefully checked.",
+                      RuntimeWarning)
+    return d
+
+
+def boundary_cell_cut_flags(topo, x, levelset, degree):
+    """`ds` detection (mesh_scripts.py:434-452): per cell, True when the level-set changes
+    sign over the union of the cell's background-boundary facets.  Cells without boundary
+    facets have a zero denominator -> 0.5 -> True, exactly as in the reference."""
+    fpts = P.facet_detection_points(topo.cell_type, degree)
+    Nf = P.shape_functions(P.FACET_TYPE[topo.cell_type], fpts)
+    is_bnd = np.zeros(topo.nf, dtype=bool)
+    is_bnd[topo.boundary_facets] = True
+    num = np.zeros(topo.nc)
+    den = np.zeros(topo.nc)
+    fv = P.FACET_VERTS[topo.cell_type]
+    for lf in range(topo.nfpc):
+        sel = np.flatnonzero(is_bnd[topo.c2f[:, lf]])
+        if sel.size == 0:
+            continue
+        phi_q = _eval_on(levelset, Nf, topo.cells[sel][:, fv[lf]], x)
+        for q in range(phi_q.shape[1]):
+            num[sel] = num[sel] + phi_q[:, q]
+            den[sel] = den[sel] + np.abs(phi_q[:, q])
+    d = np.full(topo.nc, 0.5)
+    ok = den > 0.0
+    with np.errstate(all="ignore"):
+        d[ok] = num[ok] / den[ok]
+    return np.logical_and(d > -1.0, d < 1.0)
+
+
+def tag_cells_values(topo, x, levelset, degree, single_layer_cut=False, warn=True):
+    """int8 tag per cell (1 inside, 2 cut, 3 outside; 0 = unclassified)."""
+    d = cell_detection_vector(topo, x, levelset, degree, warn=warn)
+    tags = np.zeros(topo.nc, dtype=np.int8)
+    tags[np.logical_and(d > -1.0, d < 1.0)] = 2
+    tags[d == 1.0] = 3
+    tags[d == -1.0] = 1
+    if single_layer_cut:
+        # mesh_scripts.py:349-358: a cut cell none of whose vertex-neighbours is inside
+        # becomes outside.  "shares a vertex with an inside cell" == "owns a vertex that
+        # an inside cell owns".
+        touched = np.zeros(topo.nv, dtype=bool)
+        touched[topo.cells[tags == 1].reshape(-1)] = True
+        cut = np.flatnonzero(tags == 2)
+        keep = touched[topo.cells[cut]].any(axis=1)
+        tags[cut[~keep]] = 3
+    return tags
+
+
+def tag_facets_values(topo, cell_tags, bnd_cell_cut):
+    """Per-facet predicates equivalent to the set algebra of mesh_scripts.py:454-496.
+    Returns (tag int8[nf], membership_count int8[nf]); count != 1 means the reference's
+    sets overlap (or miss) on that facet and dolfinx's MeshTags would reject the input."""
+    f2c = topo.f2c
+    c0 = f2c[:, 0]
+    c1 = f2c[:, 1]
+    has1 = c1 >= 0
+    t0 = cell_tags[c0]
+    t1 = np.where(has1, cell_tags[np.where(has1, c1, 0)], 0)
+    I = (t0 == 1) | (t1 == 1)
+    C = (t0 == 2) | (t1 == 2)
+    E = (t0 == 3) | (t1 == 3)
+    B = ~has1
+    no_ext = not np.any(cell_tags == 3)
+    cellcut = bnd_cell_cut[c0]
+    CB = B & cellcut                              # :454-456
+    UB = B & ~cellcut & ~E & ~I                   # :457-461
+    IB = I & C                                    # :464-466
+    BF = B.copy() if no_ext else ((E & C) | UB)   # :469-474
+    DI = E & I                                    # :476-478
+    cut = (C & ~(BF | IB | DI | UB)) | CB         # :480-484
+    inte = I & ~(IB | BF | DI)                    # :487-489
+    ext = E & ~(IB | BF | DI)                     # :492-494
+    BF = BF & ~cut                                # :496
+    count = (ext.astype(np.int8) + inte + IB + cut + BF + DI).astype(np.int8)
+    tags = np.zeros(topo.nf, dtype=np.int8)
+    # later assignments win; with count == 1 everywhere the order is irrelevant
+    tags[ext] = 5
+    tags[inte] = 1
+    tags[IB] = 3
+    tags[cut] = 2
+    tags[BF] = 4
+    tags[DI] = 6
+    return tags, count
+
+
+def integration_entities(topo, integration_cells, integration_facets):
+    """mesh_scripts.py:137-192: flat int32 [cell, local facet, ...]."""
+    integration_facets = np.asarray(integration_facets, dtype=np.int64)
+    incell = np.zeros(topo.nc + 1, dtype=bool)
+    incell[np.asarray(integration_cells, dtype=np.int64)] = True
+    infacet = np.zeros(topo.nf, dtype=bool)
+    infacet[integration_facets] = True
+    # _reshape_map stores the links in reverse order (mesh_scripts.py:210-213)
+    links = topo.f2c[integration_facets]
+    rev = np.where(links[:, 1:2] >= 0, links[:, ::-1], links)
+    flat = rev.reshape(-1)
+    flat = flat[(flat >= 0) & incell[np.where(flat >= 0, flat, topo.nc)]]
+    _, first = np.unique(flat, return_index=True)
+    cells = flat[np.sort(first)]
+    mask = infacet[topo.c2f[cells]] if cells.size else np.zeros((0, topo.nfpc), bool)
+    rows, lfs = np.nonzero(mask)
+    out = np.empty(2 * rows.size, dtype=np.int32)
+    out[0::2] = cells[rows]
+    out[1::2] = lfs
+    return out
+
+
+class SubMesh:
+    def __init__(self, parent, x, cell_ids):
+        self.c_map = np.asarray(cell_ids, dtype=np.int64)
+        pc = parent.cells[self.c_map]
+        self.v_map = np.unique(pc)
+        self.n_map = self.v_map
+        renum = -np.ones(parent.nv, dtype=np.int64)
+        renum[self.v_map] = np.arange(self.v_map.size)
+        self.topology = Topology(parent.cell_type, renum[pc], num_vertices=self.v_map.size)
+        self.x = x[self.v_map]
+
+
+def transfer_facet_tags(parent, sub, facet_values):
+    """mesh_scripts.py:244-260: first occurrence of each submesh facet in its flattened
+    c->f table points at the parent's facet in the same (cell, local facet) slot."""
+    src = parent.c2f[sub.c_map].reshape(-1)
+    dst = sub.topology.c2f.reshape(-1)
+    _, first = np.unique(dst, return_index=True)
+    return facet_values[src[first]]
+
+
+def overwrite(dim, old, new):
+    """mesh_scripts.py:561-568: user tags win."""
+    idx = np.hstack([new.indices, old.indices])
+    val = np.hstack([new.values, old.values])
+    u, first = np.unique(idx, return_index=True)
+    return MeshTags(dim, u, val[first])
+
+
+class BoundaryMeasure:
+    """Stand-in for the `ufl.Measure("ds", subdomain_data=...)` of mesh_scripts.py:631-633,644."""
+
+    def __init__(self, entities=None):
+        self.entities = entities  # {100: int32[...], 101: int32[...]} or None (all exterior)
+
+    def __call__(self, tag):
+        return self.entities[tag]
+
+
+def compute_tags_measures(cell_type, x, cells, levelset, detection_degree, box_mode=False,
+                          single_layer_cut=False, overwrite_tags=None, warn=True):
+    """mesh_scripts.py:571-653 on plain arrays.  Returns
+    (cells_tags, facets_tags, submesh|None, boundaries_measure, submesh_maps|None, topology)."""
+    overwrite_tags = overwrite_tags or {}
+    x = np.asarray(x, dtype=np.float64)
+    topo = cells if isinstance(cells, Topology) else Topology(cell_type, cells, x.shape[0])
+    tdim = P.TDIM[cell_type]
+    cv = tag_cells_values(topo, x, levelset, detection_degree, single_layer_cut, warn=warn)
+    if debug_mode:
+        if not np.any(cv == 1):
+            raise ValueError("No interior cells (1)!")
+    bcut = boundary_cell_cut_flags(topo, x, levelset, detection_degree)
+    fvals, count = tag_facets_values(topo, cv, bcut)
+    if np.any(count != 1):
+        raise ValueError("facet tag sets do not form a partition")
+    if debug_mode:
+        if not np.any(fvals == 1):
+            raise ValueError("No interior facets (1)!")
+        if not np.any(fvals == 4):
+            raise ValueError("No boundary facets (4)!")
+    tagged = np.flatnonzero(cv > 0)
+    cells_tags = MeshTags(tdim, tagged, cv[tagged])
+    facets_tags = MeshTags(tdim - 1, np.arange(topo.nf), fvals)
+
+    if "cells" in overwrite_tags:
+        ow = overwrite_tags["cells"]
+        if np.any(np.isin([1, 2, 3], ow.values)):
+            raise ValueError("Cannot overwrite cells tags with values 1, 2 or 3.")
+        cells_tags = overwrite(tdim, cells_tags, ow)
+    if "facets" in overwrite_tags:
+        ow = overwrite_tags["facets"]
+        if np.any(np.isin([1, 2, 3, 4, 5, 6, 100, 101], ow.values)):
+            raise ValueError(
+                "Cannot overwrite facets tags with values 1, 2, 3, 4, 5, 6, 100 or 101.")
+        facets_tags = overwrite(tdim - 1, facets_tags, ow)
+
+    if box_mode:
+        ents = {
+            100: integration_entities(
+                topo, np.union1d(cells_tags.find(2), cells_tags.find(1)), facets_tags.find(4)),
+            101: integration_entities(
+                topo, np.union1d(cells_tags.find(2), cells_tags.find(3)), facets_tags.find(3)),
+        }
+        return cells_tags, facets_tags, None, BoundaryMeasure(ents), None, topo
+
+    omega_h = np.unique(np.hstack([cells_tags.find(1), cells_tags.find(2)]))
+    sub = SubMesh(topo, x, omega_h)
+    cvals = np.zeros(topo.nc, dtype=np.int32)
+    cvals[cells_tags.indices] = cells_tags.values
+    fvals_full = np.zeros(topo.nf, dtype=np.int32)
+    fvals_full[facets_tags.indices] = facets_tags.values
+    sub_ct = MeshTags(tdim, np.arange(sub.c_map.size), cvals[sub.c_map])
+    sub_ft = MeshTags(tdim - 1, np.arange(sub.topology.nf),
+                      transfer_facet_tags(topo, sub, fvals_full))
+    return (sub_ct, sub_ft, sub, BoundaryMeasure(None),
+            [sub.c_map, sub.v_map, sub.n_map], topo)
+
+
+# --------------------------------------------------------------------------------------
+# one-sided facet integrals (tests/test_one_sided_integral.py:139-144)
+# --------------------------------------------------------------------------------------
+def outward_normals_2d(topo, x, cells, lfs):
+    fv = P.FACET_VERTS[topo.cell_type]
+    a = x[topo.cells[cells, fv[lfs, 0]]]
+    b = x[topo.cells[cells, fv[lfs, 1]]]
+    t = b - a
+    length = np.sqrt(t[:, 0] ** 2 + t[:, 1] ** 2)
+    n = np.stack([t[:, 1], -t[:, 0]], axis=1) / length[:, None]
+    centroid = x[topo.cells[cells]].mean(axis=1)
+    flip = np.einsum("ij,ij->i", n, 0.5 * (a + b) - centroid) < 0
+    n[flip] *= -1.0
+    return n, length
+
+
+def one_sided_integral_2d(topo, x, entities, integrand):
+    """sum over (cell, local facet) of |F| * integrand(n) with n outward from the cell."""
+    ents = np.asarray(entities).reshape(-1, 2)
+    if ents.size == 0:
+        return 0.0
+    n, length = outward_normals_2d(topo, x, ents[:, 0], ents[:, 1])
+    return float(np.sum(length * integrand(n)))

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Build the committed golden fixtures from the reference's own TEST DATA files.
+
+Run once in the build container (needs /root/reference and /opt/conda/bin/h5dump):
+
+    python tests/golden/make_fixtures.py
+
+Inputs (data files only, no reference source code is read or copied):
+  * /root/reference/tests/tests_data/{disk,square_tri,square_quad,coarse_square}.h5
+      the four test meshes of tests/test_compute_meshtags.py:28-104
+  * /root/reference/tests/tests_data/*_tags.csv
+      the 336 live golden tag files compared at tests/test_compute_meshtags.py:239-243
+      (two rows each: entity indices in dolfinx-0.9.0 local numbering; tag values)
+
+Outputs (small, committed):
+  * tests/golden/meshes.npz        coords (f64) + cells (i32, file order) of the 4 meshes
+  * tests/golden/tags_golden.npz   per golden CSV: values as int8 and indices as int32
+                                   (kept whole so that index-exact parity can be added
+                                   once dolfinx's renumbering is restated)
+  * tests/golden/one_sided_kat.json  the 9 known answers of
+                                   tests/test_one_sided_integral.py:32,63,88
+The known-answer values are plain numbers asserted by the reference's test; they are
+restated here as data.
+"""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+
+REF = "/root/reference/tests/tests_data"
+HERE = os.path.dirname(os.path.abspath(__file__))
+H5DUMP = "/opt/conda/bin/h5dump"
+
+
+def h5_dataset(path, name, dtype):
+    out = subprocess.run([H5DUMP, "-d", name, "-y", "-w", "0", path],
+                         check=True, capture_output=True, text=True).stdout
+    m = re.search(r"DATASPACE\s+SIMPLE\s*\{\s*\(\s*(\d+)\s*,\s*(\d+)\s*\)", out)
+    shape = (int(m.group(1)), int(m.group(2)))
+    body = out[out.index("DATA {") + 6:]
+    body = body[:body.index("}")]
+    vals = [v for v in re.split(r"[,\s]+", body.strip()) if v]
+    return np.array(vals, dtype=np.float64).astype(dtype).reshape(shape)
+
+
+def main():
+    meshes = {}
+    spec = {
+        "disk": ("/data0", "/data1", "triangle"),
+        "square_tri": ("/Mesh/mesh/geometry", "/Mesh/mesh/topology", "triangle"),
+        "square_quad": ("/Mesh/mesh/geometry", "/Mesh/mesh/topology", "quadrilateral"),
+        "coarse_square": ("/Mesh/mesh/geometry", "/Mesh/mesh/topology", "triangle"),
+    }
+    for name, (g, t, ctype) in spec.items():
+        p = os.path.join(REF, name + ".h5")
+        x = h5_dataset(p, g, np.float64)
+        c = h5_dataset(p, t, np.int32)
+        meshes[name + "_x"] = x
+        meshes[name + "_cells"] = c
+        meshes[name + "_type"] = np.array(ctype)
+        print(name, x.shape, c.shape, ctype)
+    np.savez_compressed(os.path.join(HERE, "meshes.npz"), **meshes)
+
+    datasets = ["circle_in_circle", "boundary_crossing_circle", "circle_in_square",
+                "square_in_square", "ellipse_in_square", "circle_near_boundary",
+                "nasty_levelset"]
+    gold = {}
+    n = 0
+    for d in datasets:
+        for deg in (1, 2, 3):
+            for disc in (False, True):
+                for box in (True, False):
+                    for sl in (False, True):
+                        mid = "_"
+                        if disc:
+                            mid += "discretize_"
+                        if not box:
+                            mid += "submesh_"
+                        if sl:
+                            mid += "single_layer_"
+                        for ent in ("cells", "facets"):
+                            key = f"{d}_{deg}{mid}{ent}_tags"
+                            a = np.loadtxt(os.path.join(REF, key + ".csv"), delimiter=" ")
+                            a = np.atleast_2d(a)
+                            gold[key + ":i"] = a[0].astype(np.int32)
+                            gold[key + ":v"] = a[1].astype(np.int8)
+                            n += 1
+    np.savez_compressed(os.path.join(HERE, "tags_golden.npz"), **gold)
+    print("golden tag files:", n)
+
+    kat = {
+        "line_in_square_quad": {"mesh": "square_quad", "values": [3.0, -3.0]},
+        "square_in_square_quad": {"mesh": "square_quad", "values": [3.2, 2.4]},
+        "square_in_square_tri": {"mesh": "square_tri", "values": [3.2, 2.4]},
+    }
+    with open(os.path.join(HERE, "one_sided_kat.json"), "w") as f:
+        json.dump(kat, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

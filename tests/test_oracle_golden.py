@@ -1,0 +1,98 @@
+"""The oracle against every golden the reference holds for the tagging path (CPU only).
+
+  * 336 tag CSVs of tests/test_compute_meshtags.py -> histograms (the CSV indices are in
+    dolfinx-local numbering, SURVEY 4.3, so only numbering-free facts can be compared);
+  * 9 known answers of tests/test_one_sided_integral.py:32,63,88 (the `discretize=False` leg;
+    for the robust data the `discretize=True` leg has the same goldens).
+"""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import tagging as T
+from oracle.topology import Topology
+
+from datasets import (FP_FRAGILE, FP_FRAGILE_DISCRETIZED, MESHTAG_DATA, ONE_SIDED_DATA,
+                      load_mesh)
+
+HERE = os.path.dirname(__file__)
+GOLD = np.load(os.path.join(HERE, "golden", "tags_golden.npz"))
+
+
+def hist(v, hi):
+    return np.bincount(np.asarray(v, dtype=np.int64), minlength=hi + 1)[1:hi + 1]
+
+
+def golden_key(name, deg, disc, box, sl, ent):
+    mid = "_"
+    if disc:
+        mid += "discretize_"
+    if not box:
+        mid += "submesh_"
+    if sl:
+        mid += "single_layer_"
+    return f"{name}_{deg}{mid}{ent}_tags"
+
+
+CASES = [(n, d, disc, box, sl) for n in MESHTAG_DATA for d in (1, 2, 3)
+         for disc in (False, True) for box in (True, False) for sl in (False, True)]
+
+
+@pytest.mark.parametrize("name,deg,disc,box,sl", CASES)
+def test_tag_histograms(name, deg, disc, box, sl):
+    fragile = name in (FP_FRAGILE_DISCRETIZED if disc else FP_FRAGILE)
+    mesh, f = MESHTAG_DATA[name]
+    ctype, x, cells = load_mesh(mesh)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ct, ft, sub, _, maps, topo = T.compute_tags_measures(
+            ctype, x, cells, f, deg, box_mode=box, single_layer_cut=sl)
+    gc_i = GOLD[golden_key(name, deg, disc, box, sl, "cells") + ":i"]
+    gc_v = GOLD[golden_key(name, deg, disc, box, sl, "cells") + ":v"]
+    gf_i = GOLD[golden_key(name, deg, disc, box, sl, "facets") + ":i"]
+    gf_v = GOLD[golden_key(name, deg, disc, box, sl, "facets") + ":v"]
+    ok = (np.array_equal(hist(ct.values, 3), hist(gc_v, 3))
+          and np.array_equal(hist(ft.values, 6), hist(gf_v, 6))
+          and ct.indices.size == gc_i.size and ft.indices.size == gf_i.size)
+    if fragile and not ok:
+        pytest.xfail("floating-point-degenerate level-set (SURVEY 4.3): decided by FFCx round-off")
+    assert np.array_equal(hist(ct.values, 3), hist(gc_v, 3))
+    assert np.array_equal(hist(ft.values, 6), hist(gf_v, 6))
+    # golden entity lists are dense 0..n-1, as ours
+    assert np.array_equal(ct.indices, gc_i)
+    assert np.array_equal(ft.indices, gf_i)
+
+
+@pytest.mark.parametrize("name", list(MESHTAG_DATA))
+@pytest.mark.parametrize("deg", [1, 2, 3])
+def test_facet_tags_partition(name, deg):
+    mesh, f = MESHTAG_DATA[name]
+    ctype, x, cells = load_mesh(mesh)
+    topo = Topology(ctype, cells, x.shape[0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cv = T.tag_cells_values(topo, x, f, deg)
+        bc = T.boundary_cell_cut_flags(topo, x, f, deg)
+    tags, count = T.tag_facets_values(topo, cv, bc)
+    assert np.all(count == 1) and np.all(tags > 0)
+
+
+KAT = json.load(open(os.path.join(HERE, "golden", "one_sided_kat.json")))
+
+
+@pytest.mark.parametrize("name", list(ONE_SIDED_DATA))
+@pytest.mark.parametrize("deg", [1, 2, 3])
+def test_one_sided_integrals(name, deg):
+    mesh, f, integrand = ONE_SIDED_DATA[name]
+    ctype, x, cells = load_mesh(mesh)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ct, ft, _, meas, _, topo = T.compute_tags_measures(ctype, x, cells, f, deg, box_mode=True)
+    v100 = T.one_sided_integral_2d(topo, x, meas(100), integrand)
+    v101 = T.one_sided_integral_2d(topo, x, meas(101), integrand)
+    # tests/test_one_sided_integral.py:167-168 (np.isclose, atol=1e-20, default rtol)
+    assert np.isclose(v100, KAT[name]["values"][0], atol=1.0e-20)
+    assert np.isclose(v101, KAT[name]["values"][1], atol=1.0e-20)
