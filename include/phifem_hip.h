@@ -1,0 +1,188 @@
+/* phifem_hip.h -- C ABI of the MI355X-native phi-FEM hot path (libphifem_hip.so).
+ *
+ * The reference (PhiFEM/phiFEM v0.7.0) has no FFI: its boundary is the Python call
+ *   compute_tags_measures(mesh, discrete_levelset, detection_degree, box_mode,
+ *                         single_layer_cut, overwrite_tags)      src/phifem/mesh_scripts.py:571-653
+ * followed, in every demo, by dolfinx `assemble_matrix` / `assemble_vector` and a PETSc/MUMPS
+ * solve (demo/weak-dirichlet/flower/main.py:137-139,153-154,162-182).  Each entry point below
+ * names the reference lines it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer it passes in;
+ *   - every function returns 0 on success or a negative phx_status; phx_last_error() gives
+ *     the message of the last failure on the calling thread;
+ *   - arguments called `loc` say where a buffer lives: PHX_HOST or PHX_DEVICE (a device
+ *     pointer of the mesh's GPU, e.g. a torch tensor's data_ptr);
+ *   - one mesh handle is bound to one GPU and one HIP stream; handles are not thread-safe,
+ *     different handles may be used concurrently;
+ *   - there is NO CPU fallback: without a usable GPU the device entry points fail with
+ *     PHX_ERR_HIP.  The few host-only helpers are marked [host].
+ *
+ * Numbering contract (also restated in oracle/topology.py and oracle/meshgen.py)
+ *   cells/vertices keep caller order; simplex local facet i is opposite local vertex i;
+ *   quadrilateral vertices are in tensor-product order, facets (0,1),(0,2),(1,3),(2,3);
+ *   u-DoF of vertex v is v, p-DoF is nv + v.
+ */
+#ifndef PHIFEM_HIP_H
+#define PHIFEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct phx_mesh phx_mesh;     /* mesh + topology + current tags, resident in HBM */
+typedef struct phx_system phx_system; /* assembled matrix + rhs + solver workspace       */
+
+enum phx_status {
+  PHX_OK = 0,
+  PHX_ERR_VALUE = -1,          /* -> ValueError            (mesh_scripts.py:242,262,609,614) */
+  PHX_ERR_NOT_IMPLEMENTED = -2,/* -> NotImplementedError   (mesh_scripts.py:326-329)         */
+  PHX_ERR_HIP = -3,            /* -> RuntimeError: HIP runtime failure / no GPU              */
+  PHX_ERR_PARTITION = -4,      /* -> ValueError: facet tag sets overlap (dolfinx MeshTags
+                                     rejects duplicated entities, mesh_scripts.py:554-556)    */
+  PHX_ERR_CAPACITY = -5,       /* row-slot capacity exceeded during assembly; retry larger   */
+  PHX_ERR_BREAKDOWN = -6       /* Krylov breakdown (rho or omega vanished)                   */
+};
+
+enum phx_loc { PHX_HOST = 0, PHX_DEVICE = 1 };
+
+enum phx_cell_type { PHX_TRIANGLE = 0, PHX_QUADRILATERAL = 1, PHX_TETRAHEDRON = 2 };
+
+/* How the level-set reaches the tagging kernels (mesh_scripts.py:571-574: a P_k Function or a
+ * UFL expression). */
+enum phx_phi_kind {
+  PHX_PHI_NODAL_P1 = 0, /* phi[nv]: values at the mesh vertices                               */
+  PHX_PHI_POINTS = 1,   /* phi_cells[nc*npts_cell] then phi_bfacets[nbf*npts_facet]: values the
+                           host evaluated at the physical detection points (expression mode)  */
+  PHX_PHI_QUADRIC = 2   /* 7 doubles {cx,cy,cz, sx,sy,sz, c0}: sum_a (s_a x_a - c_a)^2 + c0,
+                           evaluated on the device at the physical detection points           */
+};
+
+enum phx_array {          /* phx_mesh_get_array selectors */
+  PHX_ARR_COORDS = 0,     /* f64 [nv*gdim]                                */
+  PHX_ARR_CELLS = 1,      /* i32 [nc*nvpc]                                */
+  PHX_ARR_C2F = 2,        /* i32 [nc*nfpc]                                */
+  PHX_ARR_F2C = 3,        /* i32 [nf*2], ascending cell index, -1 padded  */
+  PHX_ARR_CELL_TAGS = 4,  /* i32 [nc]  values 1,2,3 (0 = unclassified)    */
+  PHX_ARR_FACET_TAGS = 5, /* i32 [nf]  values 1..6                        */
+  PHX_ARR_BFACETS = 6     /* i32 [nbf*2] (cell, local facet) of the background-boundary facets,
+                             ascending facet index                        */
+};
+
+/* ------------------------------------------------------------------ misc ------------- */
+int phx_version(void);                     /* [host] ABI version (1) */
+const char *phx_last_error(void);          /* [host] */
+int phx_device_count(int *n);              /* [host] 0 GPUs is not an error here */
+
+/* [host] Detection points on the reference cell / reference facet: restates
+ * _reference_{segment,triangle_boundary,square_boundary}_points (mesh_scripts.py:28-92) and
+ * extends them to the tetrahedron.  which = 0: cell points (tdim coords each), 1: facet points
+ * (tdim-1 coords each).  Count-then-fill: call with out == NULL to get *npts. */
+int phx_detection_points(int cell_type, int degree, int which, double *out, int64_t *npts);
+
+/* [host] Facet numbering and connectivities of an unstructured mesh: stands in for dolfinx
+ * create_connectivity (mesh_scripts.py:151-153,419-422) and locate_entities_boundary (:430).
+ * c2f[nc*nfpc], f2c[(max)nc*nfpc*2] are caller buffers; *nf receives the facet count. */
+int phx_topology_build_host(int cell_type, int64_t nv, int64_t nc, const int32_t *cells,
+                            int32_t *c2f, int32_t *f2c, int64_t *nf);
+
+/* ------------------------------------------------------------------ mesh ------------- */
+/* Unstructured mesh from caller arrays (host): replaces XDMFFile.read_mesh + connectivities
+ * (tests/test_compute_meshtags.py:136-137).  Quadrilaterals in tensor-product order. */
+int phx_mesh_create(int gdim, int cell_type, int64_t nv, const double *coords, int64_t nc,
+                    const int32_t *cells, int device, phx_mesh **out);
+
+/* Structured Kuhn/Freudenthal simplicial box generated ON THE DEVICE: replaces
+ * dolfinx.mesh.create_rectangle / create_box (demo/weak-dirichlet/flower/main.py:45-46).
+ * n[gdim] cubes per axis in this (sub-)box; vertex (i,j,k) sits at
+ *   lo[a] + (hi[a]-lo[a]) * (double)(offset[a]+i) / (double)n_global[a]
+ * so that a slab of a larger box (multi-GPU partition) reproduces the global coordinates bit
+ * for bit.  offset/n_global may be NULL (= 0 / n). */
+int phx_mesh_create_box(int gdim, const double *lo, const double *hi, const int64_t *n,
+                        const int64_t *offset, const int64_t *n_global, int device,
+                        phx_mesh **out);
+
+int phx_mesh_destroy(phx_mesh *m);
+/* counts[6] = {gdim, cell_type, nv, nc, nf, nbf} */
+int phx_mesh_counts(const phx_mesh *m, int64_t *counts);
+/* Copy a mesh array out (to host or to a device buffer of the same GPU). */
+int phx_mesh_get_array(phx_mesh *m, int which, void *out, int loc);
+/* The HIP stream all work of this mesh is enqueued on (as uintptr). */
+int phx_mesh_stream(phx_mesh *m, uint64_t *stream);
+int phx_mesh_synchronize(phx_mesh *m);
+
+/* ------------------------------------------------------------------ tagging ---------- */
+/* _tag_cells (mesh_scripts.py:284-390) incl. _compute_detection_vector (:95-134):
+ * tags 1 inside / 2 cut / 3 outside, optional single-layer demotion (:349-358).
+ * warn_zero_denominator (may be NULL) receives 1 when some cell's denominator is ~0 (the
+ * RuntimeWarning of :129-133). */
+int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int loc, int detection_degree,
+                  int single_layer_cut, int *warn_zero_denominator);
+
+/* _tag_facets (mesh_scripts.py:393-558), tags 1..6, from the cell tags currently held by the
+ * mesh; the `ds` detection of the background-boundary facets (:434-461) uses the same phi.
+ * Fails with PHX_ERR_PARTITION when the reference's sets do not partition the facets. */
+int phx_tag_facets(phx_mesh *m, int phi_kind, const double *phi, int loc, int detection_degree);
+
+/* User overwrite of tags (_overwrite_tags, mesh_scripts.py:561-568, value checks :606-615). */
+int phx_overwrite_tags(phx_mesh *m, int entity_is_facet, int64_t n, const int32_t *indices,
+                       const int32_t *values);
+/* Install externally computed dense tags (tests, multi-GPU ghost exchange). */
+int phx_set_tags(phx_mesh *m, int entity_is_facet, const int32_t *values, int loc);
+
+/* _compute_integration_entities (mesh_scripts.py:137-192) for the two one-sided measures of
+ * compute_tags_measures (:617-626): which = 100 -> facets tagged 4 seen from cells {1,2};
+ * which = 101 -> facets tagged 3 seen from cells {2,3}.  Flat [cell, local facet, ...] in the
+ * reference's order.  Count-then-fill on *n_pairs (out may be NULL). */
+int phx_integration_entities(phx_mesh *m, int which, int32_t *out, int64_t *n_pairs);
+
+/* Sub-mesh of the cells tagged 1 or 2 with transferred tags: dolfinx create_submesh +
+ * _transfer_tags (mesh_scripts.py:217-281,636-645).  c_map[ncs], v_map[nvs] are count-then-fill
+ * (pass NULL first, sizes come back in counts of *sub). */
+int phx_submesh_create(phx_mesh *m, phx_mesh **sub);
+int phx_submesh_maps(phx_mesh *sub, int32_t *c_map, int32_t *v_map);
+
+/* ------------------------------------------------------------------ assembly --------- */
+/* Weak-Dirichlet phi-FEM Poisson, mixed (u,p) in P1 x P1: bilinear form
+ * demo/weak-dirichlet/flower/main.py:112-135 + assemble_matrix :137-139, linear form :142-151 +
+ * assemble_vector :153-154, on the tags currently held by the mesh (dx((1,2)), dx(2), dS((2,3)),
+ * ds = ds(100) in box mode or all exterior facets on a sub-mesh).
+ * phi_h, f_h, u_D: nodal P1 arrays [nv].  Only the active DoFs (rows touched by an integral)
+ * are stored. */
+int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab_coef, const double *phi_h,
+                            const double *f_h, const double *u_D, int loc, phx_system **out);
+int phx_system_destroy(phx_system *s);
+/* info[8] = {n_active, n_active_u, nnz (structural, CSR), n_full (= 2*nv), sell_padded_nnz,
+ *            slot_capacity, sell_nnz (explicit zeros dropped), n_slices} */
+int phx_system_info(const phx_system *s, int64_t *info);
+/* CSR of the active system in ORIGINAL active numbering (sorted columns) + the map active row ->
+ * full DoF index; host buffers: rowptr[n_active+1], col[nnz], val[nnz], rhs[n_active],
+ * dof[n_active].  Any pointer may be NULL. */
+int phx_system_export(phx_system *s, int64_t *rowptr, int32_t *col, double *val, double *rhs,
+                      int64_t *dof);
+
+/* ------------------------------------------------------------------ solve ------------ */
+enum phx_method { PHX_BICGSTAB_JACOBI = 0 };
+/* Replaces KSP preonly + LU/MUMPS with null-pivot detection (main.py:162-182): solves the active
+ * system, returns x in FULL numbering [2*nv] with inactive DoFs = 0 (what ICNTL(24)=1 yields).
+ * stats[4] = {iterations, relative residual ||b-Ax||/||b||, seconds, spmv_count}. */
+int phx_solve(phx_system *s, int method, double rtol, int64_t max_iter, double *x, int loc,
+              double *stats);
+
+/* y = A x on the active system (solver ordering is internal; x, y are in active numbering).
+ * For tests and halo-exchange driven (multi-GPU) solvers. */
+int phx_spmv(phx_system *s, const double *x, double *y, int loc);
+/* Times `reps` launches of the SpMV kernel with HIP events on the mesh's stream.
+ * out[3] = {avg ms per launch, algorithmic bytes per launch (12 nnz + 20 n), padded bytes}. */
+int phx_spmv_bench(phx_system *s, int reps, double *out);
+
+/* Per-stage device seconds of the last calls, measured with HIP events on the mesh's stream:
+ * t[8] = {tag_cells, tag_facets, assemble, solve, spmv_avg, n/a, n/a, n/a}. */
+int phx_last_timings(const phx_mesh *m, double *t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHIFEM_HIP_H */

@@ -69,9 +69,9 @@ def _eval_on(levelset, Nmat, vert_ids, x):
 
 def _ratio(phi_q):
     """mesh_scripts.py:112-134 with sequential sums."""
-    num = phi_q[:, 0].copy()
-    den = np.abs(phi_q[:, 0])
-    for q in range(1, phi_q.shape[1]):
+    num = np.zeros(phi_q.shape[0])
+    den = np.zeros(phi_q.shape[0])
+    for q in range(phi_q.shape[1]):
         num = num + phi_q[:, q]
         den = den + np.abs(phi_q[:, q])
     d = np.full_like(num, 0.5)
@@ -108,9 +108,15 @@ def boundary_cell_cut_flags(topo, x, levelset, degree):
         if sel.size == 0:
             continue
         phi_q = _eval_on(levelset, Nf, topo.cells[sel][:, fv[lf]], x)
+        # one exterior-facet kernel call per facet: its element vector starts at zero and is
+        # then added to the cell's DG0 entry [3P: dolfinx assemble_vector]
+        pn = np.zeros(sel.size)
+        pd = np.zeros(sel.size)
         for q in range(phi_q.shape[1]):
-            num[sel] = num[sel] + phi_q[:, q]
-            den[sel] = den[sel] + np.abs(phi_q[:, q])
+            pn = pn + phi_q[:, q]
+            pd = pd + np.abs(phi_q[:, q])
+        num[sel] = num[sel] + pn
+        den[sel] = den[sel] + pd
     d = np.full(topo.nc, 0.5)
     ok = den > 0.0
     with np.errstate(all="ignore"):

@@ -1,0 +1,550 @@
+// Weak-Dirichlet phi-FEM Poisson assembly on the device (gfx950): element integration, scatter
+// into per-row slots with f64 atomics, compaction to CSR, conversion to SELL-64 for the solver.
+// Replaces the FFCx-generated tabulate_tensor kernels + dolfinx assemble_matrix/assemble_vector +
+// PETSc MatSetValuesLocal behind demo/weak-dirichlet/flower/main.py:112-139 (bilinear form) and
+// :142-154 (linear form) [3P].  P1 x P1 on affine simplices: every integrand is a polynomial, the
+// closed-form simplex integrals below equal any exact quadrature to round-off.
+//
+// Only ACTIVE DoFs get rows (u on vertices of cells tagged 1/2, p on vertices of cut cells): the
+// reference's matrix has empty rows elsewhere and relies on MUMPS null-pivot detection
+// (main.py:169-173); restricting to the active set is the same solution (hard part 2).
+#include <hipcub/hipcub.hpp>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "phx_common.h"
+
+int phx_collect_entities(phx_mesh *m);
+int phx_system_build_sell(phx_system *s);
+
+// ---------------------------------------------------------------------------------------------
+// active DoF numbering
+// ---------------------------------------------------------------------------------------------
+template <int NVPC>
+__global__ void k_mark_active(int64_t nc, const int32_t *__restrict__ cells,
+                              const int8_t *__restrict__ tags, uint8_t *__restrict__ fu,
+                              uint8_t *__restrict__ fp) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int t = tags[c] & PHX_TAG_MASK;
+  if (t != 1 && t != 2) return;
+  for (int i = 0; i < NVPC; ++i) {
+    const int32_t v = cells[c * NVPC + i];
+    fu[v] = 1;
+    if (t == 2) fp[v] = 1;
+  }
+}
+
+__global__ void k_finish_numbering(int64_t nv, const uint8_t *__restrict__ fu,
+                                   const uint8_t *__restrict__ fp,
+                                   const int32_t *__restrict__ su, const int32_t *__restrict__ sp,
+                                   int32_t nu, int32_t *__restrict__ du, int32_t *__restrict__ dp,
+                                   int64_t *__restrict__ full_of_active) {
+  const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  int32_t a = -1, b = -1;
+  if (fu[v]) { a = su[v]; full_of_active[a] = v; }
+  if (fp[v]) { b = nu + sp[v]; full_of_active[b] = nv + v; }
+  du[v] = a;
+  dp[v] = b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row slots: W (col,val) pairs per row, filled front to back.  A column claims the first free slot
+// with a CAS; values accumulate with hardware f64 atomics (global_atomic_add_f64).
+// ---------------------------------------------------------------------------------------------
+struct Slots {
+  int32_t *cols;
+  double *vals;
+  int W;
+  int *overflow;
+};
+
+__device__ __forceinline__ void slot_add(const Slots &s, int32_t row, int32_t col, double v) {
+  if (row < 0 || col < 0) return;  // inactive DoF (only reachable through user-overwritten tags)
+  int32_t *rc = s.cols + (int64_t)row * s.W;
+  double *rv = s.vals + (int64_t)row * s.W;
+  for (int k = 0; k < s.W; ++k) {
+    int32_t cur = __hip_atomic_load(&rc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == -1) {
+      cur = atomicCAS(&rc[k], -1, col);
+      if (cur == -1) cur = col;
+    }
+    if (cur == col) {
+      unsafeAtomicAdd(&rv[k], v);
+      return;
+    }
+  }
+  atomicOr(s.overflow, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// affine simplex geometry: gradients of the barycentric coordinates, volume, diameter
+// ---------------------------------------------------------------------------------------------
+template <int D>
+struct Geo {
+  double g[D + 1][D];
+  double vol, h;
+};
+
+template <int D>
+__device__ __forceinline__ void simplex_geometry(const double (*X)[D], Geo<D> &G) {
+  if constexpr (D == 2) {
+    const double a = X[1][0] - X[0][0], b = X[2][0] - X[0][0];
+    const double c = X[1][1] - X[0][1], d = X[2][1] - X[0][1];
+    const double det = a * d - b * c;
+    const double id = 1.0 / det;
+    G.g[1][0] = d * id;  G.g[1][1] = -b * id;
+    G.g[2][0] = -c * id; G.g[2][1] = a * id;
+    G.g[0][0] = -(G.g[1][0] + G.g[2][0]);
+    G.g[0][1] = -(G.g[1][1] + G.g[2][1]);
+    G.vol = 0.5 * fabs(det);
+  } else {
+    double e[3][3];  // e[k] = X[k+1]-X[0]
+    for (int k = 0; k < 3; ++k)
+      for (int d = 0; d < 3; ++d) e[k][d] = X[k + 1][d] - X[0][d];
+    // rows of J^-1 are cross products / det  (J columns = e[k])
+    double cr[3][3];
+    cr[0][0] = e[1][1] * e[2][2] - e[1][2] * e[2][1];
+    cr[0][1] = e[1][2] * e[2][0] - e[1][0] * e[2][2];
+    cr[0][2] = e[1][0] * e[2][1] - e[1][1] * e[2][0];
+    cr[1][0] = e[2][1] * e[0][2] - e[2][2] * e[0][1];
+    cr[1][1] = e[2][2] * e[0][0] - e[2][0] * e[0][2];
+    cr[1][2] = e[2][0] * e[0][1] - e[2][1] * e[0][0];
+    cr[2][0] = e[0][1] * e[1][2] - e[0][2] * e[1][1];
+    cr[2][1] = e[0][2] * e[1][0] - e[0][0] * e[1][2];
+    cr[2][2] = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+    const double det = e[0][0] * cr[0][0] + e[0][1] * cr[0][1] + e[0][2] * cr[0][2];
+    const double id = 1.0 / det;
+    for (int k = 0; k < 3; ++k)
+      for (int d = 0; d < 3; ++d) G.g[k + 1][d] = cr[k][d] * id;
+    for (int d = 0; d < 3; ++d) G.g[0][d] = -(G.g[1][d] + G.g[2][d] + G.g[3][d]);
+    G.vol = fabs(det) * (1.0 / 6.0);
+  }
+  // ufl.CellDiameter (main.py:108): largest vertex-vertex distance
+  double h2 = 0.0;
+  for (int i = 0; i <= D; ++i)
+    for (int j = i + 1; j <= D; ++j) {
+      double s = 0.0;
+      for (int d = 0; d < D; ++d) { const double t = X[i][d] - X[j][d]; s += t * t; }
+      h2 = fmax(h2, s);
+    }
+  G.h = sqrt(h2);
+}
+
+template <int D>
+__device__ __forceinline__ void load_cell(const int32_t *__restrict__ cells,
+                                          const double *__restrict__ x, int64_t c, int32_t *v,
+                                          double (*X)[D]) {
+  for (int i = 0; i <= D; ++i) {
+    v[i] = cells[c * (D + 1) + i];
+    for (int d = 0; d < D; ++d) X[i][d] = x[(int64_t)v[i] * D + d];
+  }
+}
+
+struct AsmArgs {
+  const int32_t *cells;
+  const double *x;
+  const int8_t *ctags;
+  const int8_t *ftags;
+  const int32_t *c2f;
+  const int32_t *f2c;
+  const int32_t *du;
+  const int32_t *dp;
+  const double *phi, *f, *ud;
+  double gamma, sigma;
+  double *rhs;
+  Slots slots;
+};
+
+// (1/|K|) int N_i N_j N_k N_l = D! alpha! / (D+4)!
+__device__ __forceinline__ double mult4(int i, int j, int k, int l) {
+  int cnt[4] = {0, 0, 0, 0};
+  cnt[i]++; cnt[j]++; cnt[k]++; cnt[l]++;
+  double r = 1.0;
+  for (int a = 0; a < 4; ++a) r *= (cnt[a] == 2 ? 2.0 : (cnt[a] == 3 ? 6.0 : (cnt[a] == 4 ? 24.0 : 1.0)));
+  return r;
+}
+
+// --- cells: main.py:113 (stiffness, dx((1,2))), :115-122 (penalisation, dx(2)), :143-149 (rhs) ---
+template <int D>
+__global__ void __launch_bounds__(256) k_assemble_cells(int64_t nc, AsmArgs A) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int t = A.ctags[c] & PHX_TAG_MASK;
+  if (t != 1 && t != 2) return;
+  constexpr int N = D + 1;
+  int32_t v[N];
+  double X[N][D];
+  load_cell<D>(A.cells, A.x, c, v, X);
+  Geo<D> G;
+  simplex_geometry<D>(X, G);
+  int32_t ru[N];
+  for (int i = 0; i < N; ++i) ru[i] = A.du[v[i]];
+  constexpr double c2 = D == 3 ? 1.0 / 20.0 : 1.0 / 12.0;    // (1+d_ij) c2  = int N_i N_j / |K|
+  constexpr double c3 = D == 3 ? 1.0 / 120.0 : 1.0 / 60.0;   // alpha! c3
+  constexpr double c4 = D == 3 ? 1.0 / 840.0 : 1.0 / 360.0;  // alpha! c4
+  double fl[N], sf = 0.0;
+  for (int i = 0; i < N; ++i) { fl[i] = A.f[v[i]]; sf += fl[i]; }
+  double pen_uu = 0.0;
+  if (t == 2) pen_uu = A.gamma * G.vol / (G.h * G.h);
+  for (int i = 0; i < N; ++i) {
+    for (int j = 0; j < N; ++j) {
+      double k = 0.0;
+      for (int d = 0; d < D; ++d) k += G.g[i][d] * G.g[j][d];
+      k *= G.vol;
+      if (t == 2) k += pen_uu * c2 * (i == j ? 2.0 : 1.0);
+      slot_add(A.slots, ru[i], ru[j], k);
+    }
+    // int f_h N_i = |K| c2 (sum_j f_j + f_i)
+    unsafeAtomicAdd(&A.rhs[ru[i]], G.vol * c2 * (sf + fl[i]));
+  }
+  if (t != 2) return;
+  int32_t rp[N];
+  double ph[N], ud[N], sp = 0.0, sud = 0.0;
+  for (int i = 0; i < N; ++i) {
+    rp[i] = A.dp[v[i]];
+    ph[i] = A.phi[v[i]];
+    ud[i] = A.ud[v[i]];
+    sp += ph[i];
+    sud += ud[i];
+  }
+  const double h1 = 1.0 / G.h;
+  const double w3 = -A.gamma * G.vol * h1 * h1 * h1 * c3;
+  const double w4 = A.gamma * G.vol * h1 * h1 * h1 * h1 * c4;
+  for (int i = 0; i < N; ++i) {
+    double bq = 0.0;
+    for (int j = 0; j < N; ++j) {
+      // int N_i N_j phi_h = |K| c3 (1+d_ij)(S + phi_i + phi_j)
+      const double m3 = (i == j ? 2.0 : 1.0) * (sp + ph[i] + ph[j]);
+      slot_add(A.slots, ru[i], rp[j], w3 * m3);
+      slot_add(A.slots, rp[i], ru[j], w3 * m3);
+      double m4 = 0.0;
+      for (int k = 0; k < N; ++k)
+        for (int l = 0; l < N; ++l) m4 += mult4(i, j, k, l) * ph[k] * ph[l];
+      slot_add(A.slots, rp[i], rp[j], w4 * m4);
+      bq += ud[j] * m3;
+    }
+    unsafeAtomicAdd(&A.rhs[ru[i]], pen_uu * c2 * (sud + ud[i]));   // main.py:147 (v part)
+    unsafeAtomicAdd(&A.rhs[rp[i]], w3 * bq);                       // main.py:147 (q part)
+  }
+  // main.py:123-128,150: div(grad(.)) of a P1 function is identically zero.
+}
+
+// --- one-sided boundary term, main.py:114:  -int_F (grad u . n) v  over (cell, local facet) ---
+// With n = -g_lf/|g_lf|, |F| = D |K| |g_lf| and int_F N_i = |F|/D (i on F) the entry is
+// |K| (g_j . g_lf) for every row i != lf and every column j.
+template <int D>
+__global__ void k_assemble_ds(int64_t nent, const int64_t *__restrict__ ent_packed,
+                              const int32_t *__restrict__ ent_pairs, AsmArgs A) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= nent) return;
+  int64_t c;
+  int lf;
+  if (ent_packed) { c = ent_packed[2 * e + 1] >> 8; lf = (int)(ent_packed[2 * e + 1] & 0xff); }
+  else { c = ent_pairs[2 * e]; lf = ent_pairs[2 * e + 1]; }
+  constexpr int N = D + 1;
+  int32_t v[N];
+  double X[N][D];
+  load_cell<D>(A.cells, A.x, c, v, X);
+  Geo<D> G;
+  simplex_geometry<D>(X, G);
+  for (int j = 0; j < N; ++j) {
+    double k = 0.0;
+    for (int d = 0; d < D; ++d) k += G.g[j][d] * G.g[lf][d];
+    k *= G.vol;
+    for (int i = 0; i < N; ++i)
+      if (i != lf) slot_add(A.slots, A.du[v[i]], A.du[v[j]], k);
+  }
+}
+
+// --- ghost penalty, main.py:129-134:  sigma avg(h) int_F [grad u . n][grad v . n] on dS((2,3)) ---
+template <int D>
+__global__ void k_assemble_facets(int64_t nf, AsmArgs A) {
+  const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  const int ft = A.ftags[f];
+  if (ft != 2 && ft != 3) return;
+  const int32_t cp = A.f2c[2 * f], cm = A.f2c[2 * f + 1];
+  if (cm < 0) return;  // dS integrates interior facets only
+  constexpr int N = D + 1;
+  int32_t dofs[2 * N];
+  double J[2 * N];
+  double hsum = 0.0, area = 0.0;
+  for (int side = 0; side < 2; ++side) {
+    const int64_t c = side == 0 ? cp : cm;
+    int32_t v[N];
+    double X[N][D];
+    load_cell<D>(A.cells, A.x, c, v, X);
+    Geo<D> G;
+    simplex_geometry<D>(X, G);
+    int lf = 0;
+    for (int k = 0; k < N; ++k)
+      if (A.c2f[c * N + k] == (int32_t)f) lf = k;
+    double gn = 0.0;
+    for (int d = 0; d < D; ++d) gn += G.g[lf][d] * G.g[lf][d];
+    gn = sqrt(gn);
+    if (side == 0) area = D * G.vol * gn;
+    hsum += G.h;
+    for (int j = 0; j < N; ++j) {
+      double s = 0.0;
+      for (int d = 0; d < D; ++d) s += G.g[j][d] * G.g[lf][d];
+      J[side * N + j] = -s / gn;  // grad N_j . n, n outward from this side's cell
+      dofs[side * N + j] = A.du[v[j]];
+    }
+  }
+  const double w = A.sigma * 0.5 * hsum * area;
+  for (int a = 0; a < 2 * N; ++a)
+    for (int b = 0; b < 2 * N; ++b) slot_add(A.slots, dofs[a], dofs[b], w * J[a] * J[b]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// compaction: one wave per row; lanes hold the slots, sorted by column with a bitonic network
+// ---------------------------------------------------------------------------------------------
+__global__ void k_row_counts(int64_t n, int W, const int32_t *__restrict__ cols,
+                             int64_t *__restrict__ counts) {
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const bool used = lane < W && cols[row * W + lane] != -1;
+  const unsigned long long b = __ballot(used);
+  if (lane == 0) counts[row] = __popcll(b);
+}
+
+__global__ void k_row_fill(int64_t n, int W, const int32_t *__restrict__ cols,
+                           const double *__restrict__ vals, const int64_t *__restrict__ rowptr,
+                           int32_t *__restrict__ ocol, double *__restrict__ oval,
+                           double *__restrict__ diag) {
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int32_t c = 0x7fffffff;
+  double v = 0.0;
+  if (lane < W) {
+    const int32_t cc = cols[row * W + lane];
+    if (cc != -1) { c = cc; v = vals[row * W + lane]; }
+  }
+  if (c == (int32_t)row) diag[row] = v;
+  for (int k = 2; k <= 64; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int32_t oc = __shfl_xor(c, j);
+      const double ov = __shfl_xor(v, j);
+      const bool up = ((lane & k) == 0);
+      const bool lower = ((lane & j) == 0);
+      const bool take = (lower == up) ? (oc < c) : (oc > c);
+      if (take) { c = oc; v = ov; }
+    }
+  const int64_t base = rowptr[row];
+  const int64_t cnt = rowptr[row + 1] - base;
+  if (lane < cnt) { ocol[base + lane] = c; oval[base + lane] = v; }
+}
+
+template <typename T>
+static int exclusive_sum(phx_mesh *m, const T *in, T *out, int64_t n) {
+  size_t bytes = 0;
+  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, m->stream));
+  void *tmp = nullptr;
+  PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(tmp));
+  return PHX_OK;
+}
+
+struct U8ToI32 {
+  __host__ __device__ int32_t operator()(const uint8_t &a) const { return (int32_t)a; }
+};
+
+static int scan_flags(phx_mesh *m, const uint8_t *flags, int32_t *out, int64_t n, int32_t *total) {
+  hipcub::TransformInputIterator<int32_t, U8ToI32, const uint8_t *> it(flags, U8ToI32());
+  size_t bytes = 0;
+  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, (int)n, m->stream));
+  void *tmp = nullptr;
+  PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, out, (int)n, m->stream));
+  int32_t last = 0;
+  uint8_t lastf = 0;
+  PHX_HIP(hipMemcpyAsync(&last, out + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
+  PHX_HIP(hipMemcpyAsync(&lastf, flags + (n - 1), 1, hipMemcpyDeviceToHost, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(tmp));
+  *total = last + (int32_t)lastf;
+  return PHX_OK;
+}
+
+extern "C" int phx_system_destroy(phx_system *s) {
+  if (!s) return PHX_OK;
+  (void)hipSetDevice(s->mesh->device);
+  (void)hipStreamSynchronize(s->mesh->stream);
+  void *ptrs[] = {s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active, s->rowptr, s->col,
+                  s->val, s->rhs, s->diag, s->slice_ptr, s->sell_col, s->sell_val,
+                  s->sell_val_raw, s->perm, s->iperm, s->work, s->scal};
+  for (void *p : ptrs) (void)hipFree(p);
+  if (s->scal_h) (void)hipHostFree(s->scal_h);
+  delete s;
+  return PHX_OK;
+}
+
+static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef,
+                                  const double *dphi, const double *df, const double *dud, int W,
+                                  phx_system **out) {
+  phx_system *s = new phx_system();
+  s->mesh = m;
+  s->nfull = 2 * m->nv;
+  s->slot_cap = W;
+  const int D = m->gdim;
+  const dim3 block(256);
+  // ---- active numbering
+  uint8_t *fu = nullptr, *fp = nullptr;
+  int32_t *su = nullptr, *sp = nullptr;
+  PHX_HIP(hipMalloc(&fu, (size_t)m->nv));
+  PHX_HIP(hipMalloc(&fp, (size_t)m->nv));
+  PHX_HIP(hipMalloc(&su, sizeof(int32_t) * (size_t)m->nv));
+  PHX_HIP(hipMalloc(&sp, sizeof(int32_t) * (size_t)m->nv));
+  PHX_HIP(hipMemsetAsync(fu, 0, (size_t)m->nv, m->stream));
+  PHX_HIP(hipMemsetAsync(fp, 0, (size_t)m->nv, m->stream));
+  const dim3 gcells((unsigned)phx_div_up(m->nc, 256));
+  if (D == 2) k_mark_active<3><<<gcells, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, fu, fp);
+  else k_mark_active<4><<<gcells, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, fu, fp);
+  int32_t nu = 0, np = 0;
+  PHX_CHECK(scan_flags(m, fu, su, m->nv, &nu));
+  PHX_CHECK(scan_flags(m, fp, sp, m->nv, &np));
+  s->nu = nu;
+  s->n = (int64_t)nu + np;
+  PHX_REQUIRE(s->n > 0, PHX_ERR_VALUE, "no active DoF: no cell is tagged 1 or 2");
+  PHX_HIP(hipMalloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)m->nv));
+  PHX_HIP(hipMalloc(&s->dof_of_vertex_p, sizeof(int32_t) * (size_t)m->nv));
+  PHX_HIP(hipMalloc(&s->full_of_active, sizeof(int64_t) * (size_t)s->n));
+  k_finish_numbering<<<dim3((unsigned)phx_div_up(m->nv, 256)), block, 0, m->stream>>>(
+      m->nv, fu, fp, su, sp, nu, s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active);
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(fu)); PHX_HIP(hipFree(fp)); PHX_HIP(hipFree(su)); PHX_HIP(hipFree(sp));
+  // ---- slots
+  Slots sl;
+  sl.W = W;
+  PHX_HIP(hipMalloc(&sl.cols, sizeof(int32_t) * (size_t)s->n * W));
+  PHX_HIP(hipMalloc(&sl.vals, sizeof(double) * (size_t)s->n * W));
+  PHX_HIP(hipMalloc(&sl.overflow, sizeof(int)));
+  PHX_HIP(hipMemsetAsync(sl.cols, 0xff, sizeof(int32_t) * (size_t)s->n * W, m->stream));
+  PHX_HIP(hipMemsetAsync(sl.vals, 0, sizeof(double) * (size_t)s->n * W, m->stream));
+  PHX_HIP(hipMemsetAsync(sl.overflow, 0, sizeof(int), m->stream));
+  PHX_HIP(hipMalloc(&s->rhs, sizeof(double) * (size_t)s->n));
+  PHX_HIP(hipMemsetAsync(s->rhs, 0, sizeof(double) * (size_t)s->n, m->stream));
+  AsmArgs A;
+  A.cells = m->cells; A.x = m->x; A.ctags = m->cell_tags; A.ftags = m->facet_tags;
+  A.c2f = m->c2f; A.f2c = m->f2c; A.du = s->dof_of_vertex_u; A.dp = s->dof_of_vertex_p;
+  A.phi = dphi; A.f = df; A.ud = dud; A.gamma = pen_coef; A.sigma = stab_coef;
+  A.rhs = s->rhs; A.slots = sl;
+  // ---- element kernels
+  if (D == 2) k_assemble_cells<2><<<gcells, block, 0, m->stream>>>(m->nc, A);
+  else k_assemble_cells<3><<<gcells, block, 0, m->stream>>>(m->nc, A);
+  PHX_HIP(hipGetLastError());
+  if (m->is_submesh) {
+    // main.py:74: ds = every exterior facet of the sub-mesh
+    if (m->nbf > 0) {
+      const dim3 g((unsigned)phx_div_up(m->nbf, 256));
+      if (D == 2) k_assemble_ds<2><<<g, block, 0, m->stream>>>(m->nbf, nullptr, m->bfacets, A);
+      else k_assemble_ds<3><<<g, block, 0, m->stream>>>(m->nbf, nullptr, m->bfacets, A);
+    }
+  } else {
+    PHX_CHECK(phx_collect_entities(m));  // main.py:65: ds = ds_bdy(100)
+    if (m->ent_count[0] > 0) {
+      const dim3 g((unsigned)phx_div_up(m->ent_count[0], 256));
+      if (D == 2) k_assemble_ds<2><<<g, block, 0, m->stream>>>(m->ent_count[0], m->ent_buf[0], nullptr, A);
+      else k_assemble_ds<3><<<g, block, 0, m->stream>>>(m->ent_count[0], m->ent_buf[0], nullptr, A);
+    }
+  }
+  PHX_HIP(hipGetLastError());
+  {
+    const dim3 g((unsigned)phx_div_up(m->nf, 256));
+    if (D == 2) k_assemble_facets<2><<<g, block, 0, m->stream>>>(m->nf, A);
+    else k_assemble_facets<3><<<g, block, 0, m->stream>>>(m->nf, A);
+  }
+  PHX_HIP(hipGetLastError());
+  int overflow = 0;
+  PHX_HIP(hipMemcpyAsync(&overflow, sl.overflow, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  if (overflow) {
+    PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
+    phx_system_destroy(s);
+    phx_set_error("row-slot capacity %d exceeded", W);
+    return PHX_ERR_CAPACITY;
+  }
+  // ---- compaction to CSR (sorted columns)
+  int64_t *counts = nullptr;
+  PHX_HIP(hipMalloc(&counts, sizeof(int64_t) * (size_t)(s->n + 1)));
+  PHX_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(s->n + 1), m->stream));
+  PHX_HIP(hipMalloc(&s->rowptr, sizeof(int64_t) * (size_t)(s->n + 1)));
+  const dim3 growave((unsigned)phx_div_up(s->n * 64, 256));
+  k_row_counts<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, counts);
+  PHX_CHECK(exclusive_sum<int64_t>(m, counts, s->rowptr, s->n + 1));
+  int64_t nnz = 0;
+  PHX_HIP(hipMemcpy(&nnz, s->rowptr + s->n, sizeof(int64_t), hipMemcpyDeviceToHost));
+  s->nnz = nnz;
+  PHX_HIP(hipMalloc(&s->col, sizeof(int32_t) * (size_t)nnz));
+  PHX_HIP(hipMalloc(&s->val, sizeof(double) * (size_t)nnz));
+  PHX_HIP(hipMalloc(&s->diag, sizeof(double) * (size_t)s->n));
+  PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
+  k_row_fill<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, s->rowptr, s->col, s->val, s->diag);
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(counts));
+  PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
+  PHX_CHECK(phx_system_build_sell(s));
+  *out = s;
+  return PHX_OK;
+}
+
+static int to_device(phx_mesh *m, const double *p, int loc, int64_t n, const double **dev,
+                     double **owned) {
+  *owned = nullptr;
+  PHX_REQUIRE(p != nullptr, PHX_ERR_VALUE, "NULL nodal array");
+  if (loc == PHX_DEVICE) { *dev = p; return PHX_OK; }
+  PHX_HIP(hipMalloc(owned, sizeof(double) * (size_t)n));
+  PHX_HIP(hipMemcpyAsync(*owned, p, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, m->stream));
+  *dev = *owned;
+  return PHX_OK;
+}
+
+extern "C" int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab_coef,
+                                       const double *phi_h, const double *f_h, const double *u_D,
+                                       int loc, phx_system **out) {
+  PHX_HIP(hipSetDevice(m->device));
+  PHX_REQUIRE(m->cell_type == PHX_TRIANGLE || m->cell_type == PHX_TETRAHEDRON,
+              PHX_ERR_NOT_IMPLEMENTED, "assembly supports simplices (triangle, tetrahedron) only");
+  PHX_REQUIRE(m->have_cell_tags && m->have_facet_tags, PHX_ERR_VALUE,
+              "cell and facet tags must be computed before assembly");
+  const double *dphi, *df, *dud;
+  double *o1, *o2, *o3;
+  PHX_CHECK(to_device(m, phi_h, loc, m->nv, &dphi, &o1));
+  PHX_CHECK(to_device(m, f_h, loc, m->nv, &df, &o2));
+  PHX_CHECK(to_device(m, u_D, loc, m->nv, &dud, &o3));
+  PHX_CHECK(phx_begin_timing(m));
+  int W = m->gdim == 3 ? 64 : 32;
+  int rc = assemble_with_capacity(m, pen_coef, stab_coef, dphi, df, dud, W, out);
+  if (rc == PHX_ERR_CAPACITY && W < 64) rc = assemble_with_capacity(m, pen_coef, stab_coef, dphi, df, dud, 64, out);
+  if (rc == PHX_OK) rc = phx_end_timing(m, 2);
+  if (o1) (void)hipFree(o1);
+  if (o2) (void)hipFree(o2);
+  if (o3) (void)hipFree(o3);
+  return rc;
+}
+
+extern "C" int phx_system_info(const phx_system *s, int64_t *info) {
+  info[0] = s->n; info[1] = s->nu; info[2] = s->nnz; info[3] = s->nfull;
+  info[4] = s->sell_nnz; info[5] = s->slot_cap; info[6] = s->sell_true_nnz; info[7] = s->nslices;
+  return PHX_OK;
+}
+
+extern "C" int phx_system_export(phx_system *s, int64_t *rowptr, int32_t *col, double *val,
+                                 double *rhs, int64_t *dof) {
+  PHX_HIP(hipSetDevice(s->mesh->device));
+  if (rowptr) PHX_HIP(hipMemcpy(rowptr, s->rowptr, sizeof(int64_t) * (size_t)(s->n + 1), hipMemcpyDeviceToHost));
+  if (col) PHX_HIP(hipMemcpy(col, s->col, sizeof(int32_t) * (size_t)s->nnz, hipMemcpyDeviceToHost));
+  if (val) PHX_HIP(hipMemcpy(val, s->val, sizeof(double) * (size_t)s->nnz, hipMemcpyDeviceToHost));
+  if (rhs) PHX_HIP(hipMemcpy(rhs, s->rhs, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost));
+  if (dof) PHX_HIP(hipMemcpy(dof, s->full_of_active, sizeof(int64_t) * (size_t)s->n, hipMemcpyDeviceToHost));
+  return PHX_OK;
+}

@@ -1,0 +1,109 @@
+// Internal declarations shared by the translation units of libphifem_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/phifem_hip.h"
+
+#define PHX_MAX_PTS 40   // detection points per cell (tet degree 4 has 34)
+#define PHX_MAX_VPC 4
+
+void phx_set_error(const char *fmt, ...);
+
+#define PHX_HIP(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      phx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_));   \
+      return PHX_ERR_HIP;                                                                   \
+    }                                                                                       \
+  } while (0)
+
+#define PHX_CHECK(expr)        \
+  do {                         \
+    int rc_ = (expr);          \
+    if (rc_ != PHX_OK) return rc_; \
+  } while (0)
+
+#define PHX_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) {                   \
+      phx_set_error(__VA_ARGS__);    \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+static inline int64_t phx_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Bits 0-6 of a cell-tag byte: 1 inside, 2 cut, 3 outside (or a user tag <= 127).  Bit 7: the
+// `ds` detection says the level-set changes sign over the cell's background-boundary facets.
+#define PHX_TAG_MASK 0x7f
+#define PHX_BCUT_BIT 0x80
+
+struct phx_cell_info {
+  int tdim, nvpc, nfpc, nvpf;
+  int fv[4][3];  // local facet -> local vertices
+};
+int phx_get_cell_info(int cell_type, phx_cell_info *ci);
+
+struct phx_mesh {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int gdim = 0, cell_type = 0;
+  phx_cell_info ci{};
+  int64_t nv = 0, nc = 0, nf = 0, nbf = 0;
+  double *x = nullptr;        // [nv*gdim]
+  int32_t *cells = nullptr;   // [nc*nvpc]
+  int32_t *c2f = nullptr;     // [nc*nfpc]
+  int32_t *f2c = nullptr;     // [nf*2]
+  int32_t *bfacets = nullptr; // [nbf*2] (cell, local facet), ascending facet id
+  int32_t *bfacet_ids = nullptr; // [nbf] facet ids, ascending
+  int8_t *cell_tags = nullptr;   // [nc]
+  int8_t *facet_tags = nullptr;  // [nf]
+  bool have_cell_tags = false, have_facet_tags = false;
+  int64_t tag_hist[4] = {0, 0, 0, 0};
+  int64_t ftag_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // integration entities of the current tags (device, unordered): (key, cell, lf) triples
+  int64_t *ent_buf[2] = {nullptr, nullptr};
+  int64_t ent_count[2] = {0, 0};
+  bool have_entities = false;
+  // sub-mesh provenance
+  bool is_submesh = false;
+  int32_t *c_map_h = nullptr, *v_map_h = nullptr;
+  double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+struct phx_system {
+  phx_mesh *mesh = nullptr;
+  int64_t n = 0, nu = 0, nnz = 0, nfull = 0;
+  int slot_cap = 0;
+  // original active numbering
+  int32_t *dof_of_vertex_u = nullptr;  // [nv]  active index or -1
+  int32_t *dof_of_vertex_p = nullptr;  // [nv]
+  int64_t *full_of_active = nullptr;   // [n]
+  int64_t *rowptr = nullptr;           // [n+1]
+  int32_t *col = nullptr;              // [nnz]
+  double *val = nullptr;               // [nnz]
+  double *rhs = nullptr;               // [n]
+  double *diag = nullptr;              // [n]
+  // SELL-64 in solver ordering (rows permuted by window-sorted length)
+  int64_t nslices = 0, sell_nnz = 0, sell_true_nnz = 0;
+  int64_t *slice_ptr = nullptr;  // [nslices+1] offsets in units of entries
+  int32_t *sell_col = nullptr;   // [sell_nnz] solver-order column ids
+  double *sell_val = nullptr;    // [sell_nnz] values of A*D^-1 (right Jacobi scaling)
+  double *sell_val_raw = nullptr;// [sell_nnz] values of A
+  int32_t *perm = nullptr;       // [n] solver position -> original active row
+  int32_t *iperm = nullptr;      // [n] original active row -> solver position
+  // solver workspace
+  double *work = nullptr;        // 8 vectors of n
+  double *scal = nullptr;        // device scalars
+  double *scal_h = nullptr;      // pinned
+};
+
+// helpers implemented in phx_mesh.hip
+int phx_mesh_alloc_common(phx_mesh *m);
+int phx_begin_timing(phx_mesh *m);
+int phx_end_timing(phx_mesh *m, int slot);

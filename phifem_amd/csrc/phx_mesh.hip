@@ -1,0 +1,607 @@
+// Mesh handle: host topology builder for unstructured meshes, device generator for structured
+// Kuhn boxes, detection-point tables.  Replaces the dolfinx mesh/topology services the reference
+// calls at src/phifem/mesh_scripts.py:151-153,308-315,419-422,430 and
+// demo/weak-dirichlet/flower/main.py:45-46.  gfx950 only.
+#include <hipcub/hipcub.hpp>
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "phx_common.h"
+
+static thread_local char g_err[1024] = "";
+
+void phx_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int phx_version(void) { return 1; }
+extern "C" const char *phx_last_error(void) { return g_err; }
+extern "C" int phx_device_count(int *n) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+  *n = c;
+  return PHX_OK;
+}
+
+int phx_get_cell_info(int cell_type, phx_cell_info *ci) {
+  memset(ci, 0, sizeof(*ci));
+  if (cell_type == PHX_TRIANGLE) {
+    ci->tdim = 2; ci->nvpc = 3; ci->nfpc = 3; ci->nvpf = 2;
+    const int fv[3][2] = {{1, 2}, {0, 2}, {0, 1}};
+    for (int f = 0; f < 3; ++f) for (int k = 0; k < 2; ++k) ci->fv[f][k] = fv[f][k];
+  } else if (cell_type == PHX_QUADRILATERAL) {
+    ci->tdim = 2; ci->nvpc = 4; ci->nfpc = 4; ci->nvpf = 2;
+    const int fv[4][2] = {{0, 1}, {0, 2}, {1, 3}, {2, 3}};
+    for (int f = 0; f < 4; ++f) for (int k = 0; k < 2; ++k) ci->fv[f][k] = fv[f][k];
+  } else if (cell_type == PHX_TETRAHEDRON) {
+    ci->tdim = 3; ci->nvpc = 4; ci->nfpc = 4; ci->nvpf = 3;
+    const int fv[4][3] = {{1, 2, 3}, {0, 2, 3}, {0, 1, 3}, {0, 1, 2}};
+    for (int f = 0; f < 4; ++f) for (int k = 0; k < 3; ++k) ci->fv[f][k] = fv[f][k];
+  } else {
+    // mesh_scripts.py:326-329
+    phx_set_error("Mesh tags computation does not support other cell types than 'triangle', "
+                  "'quadrilateral' or 'tetrahedron'");
+    return PHX_ERR_NOT_IMPLEMENTED;
+  }
+  return PHX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Detection points (a1): mesh_scripts.py:28-92, extended to the tetrahedron.  The arithmetic
+// is spelled out so that it is bit-identical to oracle/points.py (numpy.linspace semantics).
+// ------------------------------------------------------------------------------------------
+static void lattice_1d(int N, std::vector<double> &t) {
+  t.resize(N + 1);
+  const double step = 1.0 / (double)N;
+  for (int i = 0; i <= N; ++i) t[i] = (double)i * step;
+  t[N] = 1.0;
+}
+
+static void cell_points(int cell_type, int N, std::vector<double> &p) {
+  p.clear();
+  std::vector<double> t;
+  if (N > 0) lattice_1d(N, t);
+  if (cell_type == PHX_TRIANGLE) {
+    if (N <= 0) { p = {1.0 / 3.0, 1.0 / 3.0}; return; }
+    for (int i = 0; i <= N; ++i) { p.push_back(t[i]); p.push_back(0.0); }
+    for (int i = 1; i <= N; ++i) { p.push_back(1.0 - t[i]); p.push_back(t[i]); }
+    for (int i = 1; i < N; ++i) { p.push_back(0.0); p.push_back(1.0 - t[i]); }
+  } else if (cell_type == PHX_QUADRILATERAL) {
+    if (N <= 0) { p = {0.5, 0.5}; return; }
+    for (int i = 0; i <= N; ++i) { p.push_back(t[i]); p.push_back(0.0); }
+    for (int i = 1; i <= N; ++i) { p.push_back(1.0); p.push_back(t[i]); }
+    for (int i = 1; i <= N; ++i) { p.push_back(1.0 - t[i]); p.push_back(1.0); }
+    for (int i = 1; i < N; ++i) { p.push_back(0.0); p.push_back(1.0 - t[i]); }
+  } else {  // tetrahedron: boundary lattice points
+    if (N <= 0) { p = {0.25, 0.25, 0.25}; return; }
+    for (int k = 0; k <= N; ++k)
+      for (int j = 0; j <= N - k; ++j)
+        for (int i = 0; i <= N - k - j; ++i) {
+          const int l = N - i - j - k;
+          if (i == 0 || j == 0 || k == 0 || l == 0) {
+            p.push_back(t[i]); p.push_back(t[j]); p.push_back(t[k]);
+          }
+        }
+  }
+}
+
+static void facet_points(int cell_type, int N, std::vector<double> &p) {
+  p.clear();
+  std::vector<double> t;
+  if (N > 0) lattice_1d(N, t);
+  if (cell_type == PHX_TETRAHEDRON) {  // closed triangle lattice
+    if (N <= 0) { p = {1.0 / 3.0, 1.0 / 3.0}; return; }
+    for (int j = 0; j <= N; ++j)
+      for (int i = 0; i <= N - j; ++i) { p.push_back(t[i]); p.push_back(t[j]); }
+  } else {  // segment, mesh_scripts.py:28-40
+    if (N <= 0) { p = {0.5}; return; }
+    for (int i = 0; i <= N; ++i) p.push_back(t[i]);
+  }
+}
+
+// First-order shape functions, same operation order as oracle/points.py:shape_functions.
+// which = 0: the cell's, 1: the facet's.
+int phx_shape_table(int cell_type, int degree, int which, std::vector<double> &tab, int *npts,
+                    int *nfun) {
+  phx_cell_info ci;
+  PHX_CHECK(phx_get_cell_info(cell_type, &ci));
+  std::vector<double> p;
+  int dim;
+  int kind;  // 1 interval, 2 triangle, 3 tetrahedron, 4 quadrilateral
+  if (which == 0) {
+    cell_points(cell_type, degree, p);
+    dim = ci.tdim;
+    kind = cell_type == PHX_TRIANGLE ? 2 : (cell_type == PHX_QUADRILATERAL ? 4 : 3);
+  } else {
+    facet_points(cell_type, degree, p);
+    dim = ci.tdim - 1;
+    kind = cell_type == PHX_TETRAHEDRON ? 2 : 1;
+  }
+  const int n = (int)(p.size() / dim);
+  const int nf = kind == 1 ? 2 : (kind == 2 ? 3 : 4);
+  tab.assign((size_t)n * nf, 0.0);
+  for (int q = 0; q < n; ++q) {
+    const double *c = &p[(size_t)q * dim];
+    double *N = &tab[(size_t)q * nf];
+    if (kind == 1) { N[0] = 1.0 - c[0]; N[1] = c[0]; }
+    else if (kind == 2) { N[0] = (1.0 - c[0]) - c[1]; N[1] = c[0]; N[2] = c[1]; }
+    else if (kind == 3) { N[0] = ((1.0 - c[0]) - c[1]) - c[2]; N[1] = c[0]; N[2] = c[1]; N[3] = c[2]; }
+    else {
+      N[0] = (1.0 - c[0]) * (1.0 - c[1]); N[1] = c[0] * (1.0 - c[1]);
+      N[2] = (1.0 - c[0]) * c[1]; N[3] = c[0] * c[1];
+    }
+  }
+  *npts = n;
+  *nfun = nf;
+  PHX_REQUIRE(n <= PHX_MAX_PTS, PHX_ERR_NOT_IMPLEMENTED, "detection degree %d too large", degree);
+  return PHX_OK;
+}
+
+extern "C" int phx_detection_points(int cell_type, int degree, int which, double *out,
+                                    int64_t *npts) {
+  phx_cell_info ci;
+  PHX_CHECK(phx_get_cell_info(cell_type, &ci));
+  std::vector<double> p;
+  if (which == 0) cell_points(cell_type, degree, p);
+  else facet_points(cell_type, degree, p);
+  const int dim = which == 0 ? ci.tdim : ci.tdim - 1;
+  *npts = (int64_t)(p.size() / dim);
+  if (out) memcpy(out, p.data(), p.size() * sizeof(double));
+  return PHX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host topology builder (unstructured meshes)
+// ------------------------------------------------------------------------------------------
+namespace {
+struct FacetRec {
+  int32_t v[3];
+  int32_t cell;
+  int32_t lf;
+};
+}  // namespace
+
+extern "C" int phx_topology_build_host(int cell_type, int64_t nv, int64_t nc,
+                                       const int32_t *cells, int32_t *c2f, int32_t *f2c,
+                                       int64_t *nf_out) {
+  phx_cell_info ci;
+  PHX_CHECK(phx_get_cell_info(cell_type, &ci));
+  PHX_REQUIRE(nc > 0 && nv > 0, PHX_ERR_VALUE, "empty mesh");
+  std::vector<FacetRec> recs((size_t)nc * ci.nfpc);
+  for (int64_t c = 0; c < nc; ++c)
+    for (int lf = 0; lf < ci.nfpc; ++lf) {
+      FacetRec &r = recs[(size_t)c * ci.nfpc + lf];
+      r.v[2] = -1;
+      for (int k = 0; k < ci.nvpf; ++k) {
+        const int32_t v = cells[c * ci.nvpc + ci.fv[lf][k]];
+        PHX_REQUIRE(v >= 0 && v < nv, PHX_ERR_VALUE, "cell %lld has vertex %d out of range",
+                    (long long)c, v);
+        r.v[k] = v;
+      }
+      std::sort(r.v, r.v + ci.nvpf);
+      r.cell = (int32_t)c;
+      r.lf = lf;
+    }
+  std::sort(recs.begin(), recs.end(), [](const FacetRec &a, const FacetRec &b) {
+    if (a.v[0] != b.v[0]) return a.v[0] < b.v[0];
+    if (a.v[1] != b.v[1]) return a.v[1] < b.v[1];
+    if (a.v[2] != b.v[2]) return a.v[2] < b.v[2];
+    return a.cell < b.cell;
+  });
+  int64_t nf = 0;
+  size_t i = 0;
+  while (i < recs.size()) {
+    size_t j = i + 1;
+    while (j < recs.size() && recs[j].v[0] == recs[i].v[0] && recs[j].v[1] == recs[i].v[1] &&
+           recs[j].v[2] == recs[i].v[2])
+      ++j;
+    PHX_REQUIRE(j - i <= 2, PHX_ERR_VALUE, "facet shared by %zu cells (non-manifold mesh)", j - i);
+    f2c[2 * nf] = recs[i].cell;
+    f2c[2 * nf + 1] = (j - i == 2) ? recs[i + 1].cell : -1;
+    for (size_t k = i; k < j; ++k) c2f[(size_t)recs[k].cell * ci.nfpc + recs[k].lf] = (int32_t)nf;
+    ++nf;
+    i = j;
+  }
+  *nf_out = nf;
+  return PHX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Common allocation / timing helpers
+// ------------------------------------------------------------------------------------------
+int phx_begin_timing(phx_mesh *m) {
+  PHX_HIP(hipEventRecord(m->ev0, m->stream));
+  return PHX_OK;
+}
+int phx_end_timing(phx_mesh *m, int slot) {
+  PHX_HIP(hipEventRecord(m->ev1, m->stream));
+  PHX_HIP(hipEventSynchronize(m->ev1));
+  float ms = 0.f;
+  PHX_HIP(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+  m->timings[slot] = (double)ms * 1e-3;
+  return PHX_OK;
+}
+
+static int mesh_init_device(phx_mesh *m, int device) {
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  PHX_REQUIRE(e == hipSuccess && ndev > 0, PHX_ERR_HIP,
+              "no usable HIP device (libphifem_hip has no CPU fallback): %s",
+              e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  PHX_REQUIRE(device >= 0 && device < ndev, PHX_ERR_VALUE, "device %d out of range (%d)", device,
+              ndev);
+  m->device = device;
+  PHX_HIP(hipSetDevice(device));
+  PHX_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+  PHX_HIP(hipEventCreate(&m->ev0));
+  PHX_HIP(hipEventCreate(&m->ev1));
+  return PHX_OK;
+}
+
+int phx_mesh_alloc_common(phx_mesh *m) {
+  PHX_HIP(hipMalloc(&m->cell_tags, (size_t)m->nc));
+  PHX_HIP(hipMalloc(&m->facet_tags, (size_t)m->nf));
+  PHX_HIP(hipMemsetAsync(m->cell_tags, 0, (size_t)m->nc, m->stream));
+  PHX_HIP(hipMemsetAsync(m->facet_tags, 0, (size_t)m->nf, m->stream));
+  return PHX_OK;
+}
+
+// boundary facets: compaction of {f : f2c[f][1] < 0} in ascending order
+struct IsBoundary {
+  const int32_t *f2c;
+  __host__ __device__ bool operator()(const int32_t &f) const { return f2c[2 * (int64_t)f + 1] < 0; }
+};
+
+__global__ void k_bfacet_pairs(int64_t nbf, const int32_t *__restrict__ bf,
+                               const int32_t *__restrict__ f2c, const int32_t *__restrict__ c2f,
+                               int nfpc, int32_t *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nbf) return;
+  const int32_t f = bf[i];
+  const int32_t c = f2c[2 * (int64_t)f];
+  int lf = 0;
+  for (int k = 0; k < nfpc; ++k)
+    if (c2f[(int64_t)c * nfpc + k] == f) lf = k;
+  out[2 * i] = c;
+  out[2 * i + 1] = lf;
+}
+
+static int build_boundary_list(phx_mesh *m) {
+  int32_t *sel = nullptr;
+  int64_t *dcount = nullptr;
+  PHX_HIP(hipMalloc(&sel, sizeof(int32_t) * (size_t)m->nf));
+  PHX_HIP(hipMalloc(&dcount, sizeof(int64_t)));
+  hipcub::CountingInputIterator<int32_t> it(0);
+  IsBoundary pred{m->f2c};
+  size_t tmp_bytes = 0;
+  PHX_HIP(hipcub::DeviceSelect::If(nullptr, tmp_bytes, it, sel, dcount, (int)m->nf, pred, m->stream));
+  void *tmp = nullptr;
+  PHX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  PHX_HIP(hipcub::DeviceSelect::If(tmp, tmp_bytes, it, sel, dcount, (int)m->nf, pred, m->stream));
+  int64_t nbf = 0;
+  PHX_HIP(hipMemcpyAsync(&nbf, dcount, sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  m->nbf = nbf;
+  PHX_HIP(hipMalloc(&m->bfacets, sizeof(int32_t) * 2 * (size_t)(nbf > 0 ? nbf : 1)));
+  if (nbf > 0)
+    k_bfacet_pairs<<<dim3((unsigned)phx_div_up(nbf, 256)), dim3(256), 0, m->stream>>>(
+        nbf, sel, m->f2c, m->c2f, m->ci.nfpc, m->bfacets);
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(tmp));
+  PHX_HIP(hipMalloc(&m->bfacet_ids, sizeof(int32_t) * (size_t)(nbf > 0 ? nbf : 1)));
+  if (nbf > 0)
+    PHX_HIP(hipMemcpy(m->bfacet_ids, sel, sizeof(int32_t) * (size_t)nbf, hipMemcpyDeviceToDevice));
+  PHX_HIP(hipFree(sel));
+  PHX_HIP(hipFree(dcount));
+  return PHX_OK;
+}
+
+extern "C" int phx_mesh_create(int gdim, int cell_type, int64_t nv, const double *coords,
+                               int64_t nc, const int32_t *cells, int device, phx_mesh **out) {
+  phx_cell_info ci;
+  PHX_CHECK(phx_get_cell_info(cell_type, &ci));
+  PHX_REQUIRE(gdim == ci.tdim, PHX_ERR_VALUE, "gdim %d does not match the cell type", gdim);
+  PHX_REQUIRE(nc * (int64_t)ci.nfpc < INT32_MAX, PHX_ERR_VALUE, "mesh too large for 32-bit local ids");
+  std::vector<int32_t> c2f((size_t)nc * ci.nfpc), f2c((size_t)nc * ci.nfpc * 2);
+  int64_t nf = 0;
+  PHX_CHECK(phx_topology_build_host(cell_type, nv, nc, cells, c2f.data(), f2c.data(), &nf));
+  phx_mesh *m = new phx_mesh();
+  int rc = mesh_init_device(m, device);
+  if (rc != PHX_OK) { delete m; return rc; }
+  m->gdim = gdim; m->cell_type = cell_type; m->ci = ci;
+  m->nv = nv; m->nc = nc; m->nf = nf;
+  PHX_HIP(hipMalloc(&m->x, sizeof(double) * (size_t)nv * gdim));
+  PHX_HIP(hipMalloc(&m->cells, sizeof(int32_t) * (size_t)nc * ci.nvpc));
+  PHX_HIP(hipMalloc(&m->c2f, sizeof(int32_t) * (size_t)nc * ci.nfpc));
+  PHX_HIP(hipMalloc(&m->f2c, sizeof(int32_t) * (size_t)nf * 2));
+  PHX_HIP(hipMemcpy(m->x, coords, sizeof(double) * (size_t)nv * gdim, hipMemcpyHostToDevice));
+  PHX_HIP(hipMemcpy(m->cells, cells, sizeof(int32_t) * (size_t)nc * ci.nvpc, hipMemcpyHostToDevice));
+  PHX_HIP(hipMemcpy(m->c2f, c2f.data(), sizeof(int32_t) * (size_t)nc * ci.nfpc, hipMemcpyHostToDevice));
+  PHX_HIP(hipMemcpy(m->f2c, f2c.data(), sizeof(int32_t) * (size_t)nf * 2, hipMemcpyHostToDevice));
+  PHX_CHECK(build_boundary_list(m));
+  PHX_CHECK(phx_mesh_alloc_common(m));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  *out = m;
+  return PHX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Device generator for Kuhn boxes.  Every connectivity is a closed form of (cube, permutation):
+//   simplex t of cube o walks  o, o+e_p0, o+e_p0+e_p1(, o+e_p0+e_p1+e_p2)  for the t-th
+//   lexicographic axis permutation p.  Facet classes ("types"):
+//     A(a,s)   : facets lying in a hyperplane x_a = const, 2-D: type a; 3-D: type 2a+s
+//     B        : facets through the cube's main diagonal, 2-D: type 2; 3-D: 6+c (pair first,
+//                single axis c last) and 9+a (single axis a first, pair last)
+//   facet id = base[type] + linear index of its anchor cube inside the type's extent.
+// ------------------------------------------------------------------------------------------
+struct BoxDesc {
+  int d;
+  int64_t n[3];       // cubes
+  int64_t ntypes;
+  int64_t base[13];   // facet id offsets per type (base[ntypes] = nf)
+  int64_t ext[12][3]; // extent per type
+  double lo[3], hi[3];
+  int64_t off[3], nglob[3];
+};
+
+__constant__ int c_perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+__constant__ int c_perm2[2][2] = {{0, 1}, {1, 0}};
+
+__device__ __forceinline__ int perm_index3(int p0, int p1, int p2) { return p0 * 2 + (p1 > p2 ? 1 : 0); }
+
+__device__ __forceinline__ int64_t anchor_index(const BoxDesc &b, int type, const int64_t o[3]) {
+  return o[0] + b.ext[type][0] * (o[1] + b.ext[type][1] * o[2]);
+}
+
+__global__ void k_box_coords(BoxDesc b, int64_t nv, double *__restrict__ x) {
+  const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  int64_t idx[3];
+  const int64_t n0 = b.n[0] + 1, n1 = b.n[1] + 1;
+  idx[0] = v % n0;
+  idx[1] = (v / n0) % n1;
+  idx[2] = b.d == 3 ? v / (n0 * n1) : 0;
+  for (int a = 0; a < b.d; ++a) {
+    const double t = (double)(b.off[a] + idx[a]) / (double)b.nglob[a];
+    x[v * b.d + a] = b.lo[a] + (b.hi[a] - b.lo[a]) * t;
+  }
+}
+
+__global__ void k_box_cells(BoxDesc b, int64_t nc, int32_t *__restrict__ cells,
+                            int32_t *__restrict__ c2f) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int d = b.d;
+  const int nper = d == 3 ? 6 : 2;
+  const int t = (int)(c % nper);
+  const int64_t cube = c / nper;
+  int64_t o[3];
+  o[0] = cube % b.n[0];
+  o[1] = (cube / b.n[0]) % b.n[1];
+  o[2] = d == 3 ? cube / (b.n[0] * b.n[1]) : 0;
+  const int64_t stride[3] = {1, b.n[0] + 1, (b.n[0] + 1) * (b.n[1] + 1)};
+  int p[3] = {0, 0, 0};
+  for (int s = 0; s < d; ++s) p[s] = d == 3 ? c_perm3[t][s] : c_perm2[t][s];
+  int64_t v = o[0] * stride[0] + o[1] * stride[1] + o[2] * stride[2];
+  cells[c * (d + 1)] = (int32_t)v;
+  for (int s = 0; s < d; ++s) {
+    v += stride[p[s]];
+    cells[c * (d + 1) + s + 1] = (int32_t)v;
+  }
+  // local facet m is opposite path vertex m
+  for (int m = 0; m <= d; ++m) {
+    int type;
+    int64_t an[3] = {o[0], o[1], o[2]};
+    if (d == 3) {
+      if (m == 0) { type = p[0] * 2 + (p[1] > p[2] ? 1 : 0); an[p[0]] += 1; }
+      else if (m == 3) { type = p[2] * 2 + (p[0] > p[1] ? 1 : 0); }
+      else if (m == 1) { type = 6 + p[2]; }
+      else { type = 9 + p[0]; }
+    } else {
+      if (m == 0) { type = p[0]; an[p[0]] += 1; }
+      else if (m == 2) { type = p[1]; }
+      else { type = 2; }
+    }
+    c2f[c * (d + 1) + m] = (int32_t)(b.base[type] + anchor_index(b, type, an));
+  }
+}
+
+__global__ void k_box_f2c(BoxDesc b, int64_t nf, int32_t *__restrict__ f2c) {
+  const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  const int d = b.d;
+  int type = 0;
+  while (type + 1 < b.ntypes && f >= b.base[type + 1]) ++type;
+  int64_t r = f - b.base[type];
+  int64_t o[3];
+  o[0] = r % b.ext[type][0];
+  o[1] = (r / b.ext[type][0]) % b.ext[type][1];
+  o[2] = d == 3 ? r / (b.ext[type][0] * b.ext[type][1]) : 0;
+  const int nper = d == 3 ? 6 : 2;
+  int64_t c0 = -1, c1 = -1;
+  auto cube_of = [&](const int64_t q[3]) { return q[0] + b.n[0] * (q[1] + b.n[1] * q[2]); };
+  if (d == 3) {
+    if (type < 6) {
+      const int a = type / 2, s = type % 2;
+      const int r0 = a == 0 ? 1 : 0, r1 = a == 2 ? 1 : 2;  // remaining axes, ascending
+      const int s0 = s ? r1 : r0, s1 = s ? r0 : r1;
+      if (o[a] > 0) {
+        int64_t q[3] = {o[0], o[1], o[2]};
+        q[a] -= 1;
+        c0 = cube_of(q) * nper + perm_index3(a, s0, s1);  // local facet 0
+      }
+      if (o[a] < b.n[a]) {
+        const int64_t cc = cube_of(o) * nper + perm_index3(s0, s1, a);  // local facet 3
+        if (c0 < 0) c0 = cc; else c1 = cc;
+      }
+    } else if (type < 9) {
+      const int c = type - 6;
+      const int r0 = c == 0 ? 1 : 0, r1 = c == 2 ? 1 : 2;
+      c0 = cube_of(o) * nper + perm_index3(r0, r1, c);
+      c1 = cube_of(o) * nper + perm_index3(r1, r0, c);
+    } else {
+      const int a = type - 9;
+      const int r0 = a == 0 ? 1 : 0, r1 = a == 2 ? 1 : 2;
+      c0 = cube_of(o) * nper + perm_index3(a, r0, r1);
+      c1 = cube_of(o) * nper + perm_index3(a, r1, r0);
+    }
+  } else {
+    if (type < 2) {
+      const int a = type, bx = 1 - a;
+      if (o[a] > 0) {
+        int64_t q[3] = {o[0], o[1], 0};
+        q[a] -= 1;
+        c0 = cube_of(q) * nper + a;  // perm (a,b), local facet 0
+      }
+      if (o[a] < b.n[a]) {
+        const int64_t cc = cube_of(o) * nper + bx;  // perm (b,a), local facet 2
+        if (c0 < 0) c0 = cc; else c1 = cc;
+      }
+    } else {
+      c0 = cube_of(o) * nper;
+      c1 = c0 + 1;
+    }
+  }
+  f2c[2 * f] = (int32_t)c0;
+  f2c[2 * f + 1] = (int32_t)c1;
+}
+
+extern "C" int phx_mesh_create_box(int gdim, const double *lo, const double *hi, const int64_t *n,
+                                   const int64_t *offset, const int64_t *n_global, int device,
+                                   phx_mesh **out) {
+  PHX_REQUIRE(gdim == 2 || gdim == 3, PHX_ERR_VALUE, "gdim must be 2 or 3");
+  BoxDesc b;
+  memset(&b, 0, sizeof(b));
+  b.d = gdim;
+  b.n[2] = 1;
+  for (int a = 0; a < gdim; ++a) {
+    PHX_REQUIRE(n[a] > 0, PHX_ERR_VALUE, "n[%d] must be positive", a);
+    b.n[a] = n[a];
+    b.lo[a] = lo[a];
+    b.hi[a] = hi[a];
+    b.off[a] = offset ? offset[a] : 0;
+    b.nglob[a] = n_global ? n_global[a] : n[a];
+  }
+  const int ntypes = gdim == 3 ? 12 : 3;
+  b.ntypes = ntypes;
+  for (int t = 0; t < ntypes; ++t) {
+    for (int a = 0; a < 3; ++a) b.ext[t][a] = a < gdim ? b.n[a] : 1;
+    if (gdim == 3 && t < 6) b.ext[t][t / 2] += 1;
+    if (gdim == 2 && t < 2) b.ext[t][t] += 1;
+  }
+  b.base[0] = 0;
+  for (int t = 0; t < ntypes; ++t) b.base[t + 1] = b.base[t] + b.ext[t][0] * b.ext[t][1] * b.ext[t][2];
+  const int64_t nf = b.base[ntypes];
+  int64_t nv = 1, ncube = 1;
+  for (int a = 0; a < gdim; ++a) { nv *= (b.n[a] + 1); ncube *= b.n[a]; }
+  const int64_t nc = ncube * (gdim == 3 ? 6 : 2);
+  PHX_REQUIRE(nf < INT32_MAX && nc < INT32_MAX, PHX_ERR_VALUE,
+              "box too large for 32-bit local ids (nc=%lld nf=%lld): partition it", (long long)nc,
+              (long long)nf);
+  phx_mesh *m = new phx_mesh();
+  int rc = mesh_init_device(m, device);
+  if (rc != PHX_OK) { delete m; return rc; }
+  m->gdim = gdim;
+  m->cell_type = gdim == 3 ? PHX_TETRAHEDRON : PHX_TRIANGLE;
+  PHX_CHECK(phx_get_cell_info(m->cell_type, &m->ci));
+  m->nv = nv; m->nc = nc; m->nf = nf;
+  PHX_HIP(hipMalloc(&m->x, sizeof(double) * (size_t)nv * gdim));
+  PHX_HIP(hipMalloc(&m->cells, sizeof(int32_t) * (size_t)nc * (gdim + 1)));
+  PHX_HIP(hipMalloc(&m->c2f, sizeof(int32_t) * (size_t)nc * (gdim + 1)));
+  PHX_HIP(hipMalloc(&m->f2c, sizeof(int32_t) * (size_t)nf * 2));
+  const int T = 256;
+  k_box_coords<<<dim3((unsigned)phx_div_up(nv, T)), dim3(T), 0, m->stream>>>(b, nv, m->x);
+  k_box_cells<<<dim3((unsigned)phx_div_up(nc, T)), dim3(T), 0, m->stream>>>(b, nc, m->cells, m->c2f);
+  k_box_f2c<<<dim3((unsigned)phx_div_up(nf, T)), dim3(T), 0, m->stream>>>(b, nf, m->f2c);
+  PHX_HIP(hipGetLastError());
+  PHX_CHECK(build_boundary_list(m));
+  PHX_CHECK(phx_mesh_alloc_common(m));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  *out = m;
+  return PHX_OK;
+}
+
+extern "C" int phx_mesh_destroy(phx_mesh *m) {
+  if (!m) return PHX_OK;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  void *ptrs[] = {m->x, m->cells, m->c2f, m->f2c, m->bfacets, m->bfacet_ids, m->cell_tags,
+                  m->facet_tags, m->ent_buf[0], m->ent_buf[1]};
+  for (void *p : ptrs) (void)hipFree(p);
+  free(m->c_map_h); free(m->v_map_h);
+  if (m->ev0) (void)hipEventDestroy(m->ev0);
+  if (m->ev1) (void)hipEventDestroy(m->ev1);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+  return PHX_OK;
+}
+
+extern "C" int phx_mesh_counts(const phx_mesh *m, int64_t *counts) {
+  counts[0] = m->gdim; counts[1] = m->cell_type; counts[2] = m->nv;
+  counts[3] = m->nc; counts[4] = m->nf; counts[5] = m->nbf;
+  return PHX_OK;
+}
+
+extern "C" int phx_mesh_stream(phx_mesh *m, uint64_t *stream) {
+  *stream = (uint64_t)(uintptr_t)m->stream;
+  return PHX_OK;
+}
+
+extern "C" int phx_mesh_synchronize(phx_mesh *m) {
+  PHX_HIP(hipSetDevice(m->device));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  return PHX_OK;
+}
+
+__global__ void k_widen_tags(int64_t n, const int8_t *__restrict__ in, int32_t *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)(in[i] & PHX_TAG_MASK);
+}
+
+extern "C" int phx_mesh_get_array(phx_mesh *m, int which, void *out, int loc) {
+  PHX_HIP(hipSetDevice(m->device));
+  const hipMemcpyKind kind = loc == PHX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  const void *src = nullptr;
+  size_t bytes = 0;
+  switch (which) {
+    case PHX_ARR_COORDS: src = m->x; bytes = sizeof(double) * m->nv * m->gdim; break;
+    case PHX_ARR_CELLS: src = m->cells; bytes = sizeof(int32_t) * m->nc * m->ci.nvpc; break;
+    case PHX_ARR_C2F: src = m->c2f; bytes = sizeof(int32_t) * m->nc * m->ci.nfpc; break;
+    case PHX_ARR_F2C: src = m->f2c; bytes = sizeof(int32_t) * m->nf * 2; break;
+    case PHX_ARR_BFACETS: src = m->bfacets; bytes = sizeof(int32_t) * m->nbf * 2; break;
+    case PHX_ARR_CELL_TAGS:
+    case PHX_ARR_FACET_TAGS: {
+      const bool fac = which == PHX_ARR_FACET_TAGS;
+      PHX_REQUIRE(fac ? m->have_facet_tags : m->have_cell_tags, PHX_ERR_VALUE, "tags not computed yet");
+      const int64_t n = fac ? m->nf : m->nc;
+      int32_t *dst = (int32_t *)out;
+      int32_t *tmp = nullptr;
+      if (loc != PHX_DEVICE) { PHX_HIP(hipMalloc(&tmp, sizeof(int32_t) * (size_t)n)); dst = tmp; }
+      k_widen_tags<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, m->stream>>>(
+          n, fac ? m->facet_tags : m->cell_tags, dst);
+      if (tmp) {
+        PHX_HIP(hipMemcpyAsync(out, tmp, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
+        PHX_HIP(hipStreamSynchronize(m->stream));
+        PHX_HIP(hipFree(tmp));
+      }
+      return PHX_OK;
+    }
+    default:
+      phx_set_error("unknown array selector %d", which);
+      return PHX_ERR_VALUE;
+  }
+  if (bytes) PHX_HIP(hipMemcpyAsync(out, src, bytes, kind, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  return PHX_OK;
+}
+
+extern "C" int phx_last_timings(const phx_mesh *m, double *t) {
+  for (int i = 0; i < 8; ++i) t[i] = m->timings[i];
+  return PHX_OK;
+}

@@ -1,0 +1,576 @@
+// Cell / facet classification against the level-set on the device (gfx950).
+// Replaces src/phifem/mesh_scripts.py:95-134 (_compute_detection_vector), :284-390 (_tag_cells),
+// :393-558 (_tag_facets), :137-192 (_compute_integration_entities), :561-568 (_overwrite_tags).
+//
+// All kernels are HBM-bound streaming passes (one thread per cell / facet, 16-byte connectivity
+// loads, one byte written per entity).  This file is compiled with -ffp-contract=off: the tags
+// hang on exact float compares (mesh_scripts.py:343-347), so every sum is evaluated in the order
+// the oracle spells out and without fused multiply-add.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "phx_common.h"
+
+int phx_shape_table(int cell_type, int degree, int which, std::vector<double> &tab, int *npts,
+                    int *nfun);
+
+struct DetTab {
+  int npts, nfun;
+  double N[PHX_MAX_PTS * 4];
+};
+struct Quadric {
+  double c[3], s[3], c0;
+};
+struct FacetVerts {
+  int nfpc, nvpf;
+  int fv[4][3];
+};
+
+template <int GDIM>
+__device__ __forceinline__ double quadric_eval(const Quadric &q, const double *xq) {
+  const double t0 = q.s[0] * xq[0] - q.c[0];
+  const double t1 = q.s[1] * xq[1] - q.c[1];
+  double r = t0 * t0 + t1 * t1;
+  if (GDIM == 3) {
+    const double t2 = q.s[2] * xq[2] - q.c[2];
+    r = r + t2 * t2;
+  }
+  return r + q.c0;
+}
+
+// phi at detection point q of an entity with NV vertices `v`
+template <int KIND, int GDIM>
+__device__ __forceinline__ double phi_at(const DetTab &tab, int q, int nvert, const int32_t *v,
+                                         const double *__restrict__ phi,
+                                         const double *__restrict__ x, const Quadric &quad,
+                                         int64_t point_base) {
+  const double *N = &tab.N[q * tab.nfun];
+  if (KIND == PHX_PHI_NODAL_P1) {
+    double a = N[0] * phi[v[0]];
+    for (int i = 1; i < nvert; ++i) a = a + N[i] * phi[v[i]];
+    return a;
+  } else if (KIND == PHX_PHI_POINTS) {
+    return phi[point_base + q];
+  } else {
+    double xq[3] = {0.0, 0.0, 0.0};
+    for (int d = 0; d < GDIM; ++d) {
+      double a = N[0] * x[(int64_t)v[0] * GDIM + d];
+      for (int i = 1; i < nvert; ++i) a = a + N[i] * x[(int64_t)v[i] * GDIM + d];
+      xq[d] = a;
+    }
+    return quadric_eval<GDIM>(quad, xq);
+  }
+}
+
+// --- a2 + a3: detection ratio and classification, one thread per cell -----------------------
+template <int KIND, int GDIM, int NVPC>
+__global__ void __launch_bounds__(256)
+k_tag_cells(int64_t nc, DetTab tab, const int32_t *__restrict__ cells,
+            const double *__restrict__ phi, const double *__restrict__ x, Quadric quad,
+            int8_t *__restrict__ tags, int *__restrict__ warn) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  int32_t v[NVPC];
+  if constexpr (NVPC == 4) {
+    const int4 cv = *reinterpret_cast<const int4 *>(cells + c * 4);
+    v[0] = cv.x; v[1] = cv.y; v[2] = cv.z; v[3] = cv.w;
+  } else {
+    for (int i = 0; i < NVPC; ++i) v[i] = cells[c * NVPC + i];
+  }
+  double num = 0.0, den = 0.0;
+  for (int q = 0; q < tab.npts; ++q) {
+    const double p = phi_at<KIND, GDIM>(tab, q, NVPC, v, phi, x, quad, c * (int64_t)tab.npts);
+    num = num + p;
+    den = den + fabs(p);
+  }
+  // mesh_scripts.py:124-128: 0.5 wherever the denominator is not > 0 (zero or NaN)
+  const double d = (den > 0.0) ? num / den : 0.5;
+  int8_t t = 0;
+  if (d > -1.0 && d < 1.0) t = 2;   // :343-345
+  if (d == 1.0) t = 3;              // :346
+  if (d == -1.0) t = 1;             // :347
+  tags[c] = t;
+  if (fabs(den) <= 1.0e-8) atomicOr(warn, 1);  // numpy.isclose(den, 0.0), :129
+}
+
+// --- single layer (mesh_scripts.py:349-358) -------------------------------------------------
+// "none of the cells sharing a vertex with this cut cell is inside" == "no vertex of this cut
+// cell belongs to an inside cell": mark, then test.  No vertex->cell adjacency is needed.
+template <int NVPC>
+__global__ void k_mark_inside_vertices(int64_t nc, const int32_t *__restrict__ cells,
+                                       const int8_t *__restrict__ tags,
+                                       uint8_t *__restrict__ touched) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nc || (tags[c] & PHX_TAG_MASK) != 1) return;
+  for (int i = 0; i < NVPC; ++i) touched[cells[c * NVPC + i]] = 1;
+}
+
+template <int NVPC>
+__global__ void k_demote_isolated_cut(int64_t nc, const int32_t *__restrict__ cells,
+                                      int8_t *__restrict__ tags,
+                                      const uint8_t *__restrict__ touched) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nc || (tags[c] & PHX_TAG_MASK) != 2) return;
+  bool keep = false;
+  for (int i = 0; i < NVPC; ++i) keep = keep || touched[cells[c * NVPC + i]];
+  if (!keep) tags[c] = 3;
+}
+
+__global__ void k_tag_hist(int64_t n, const int8_t *__restrict__ tags, int nbins,
+                           unsigned long long *__restrict__ hist) {
+  __shared__ unsigned int lh[8];
+  if (threadIdx.x < 8) lh[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = tags[i] & PHX_TAG_MASK;
+    if (t < nbins) atomicAdd(&lh[t], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < nbins && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+// --- `ds` detection of the background-boundary facets (mesh_scripts.py:434-452) --------------
+// One thread per boundary facet; the thread owning a cell's FIRST boundary facet judges the cell
+// on all of its boundary facets together (one partial sum per facet, added in local order).
+__device__ __forceinline__ int64_t lower_bound_i32(const int32_t *a, int64_t n, int32_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+template <int KIND, int GDIM>
+__global__ void k_boundary_cell_cut(int64_t nbf, DetTab tab, FacetVerts fvs, int nvpc,
+                                    const int32_t *__restrict__ bfacets,
+                                    const int32_t *__restrict__ bfacet_ids,
+                                    const int32_t *__restrict__ cells,
+                                    const int32_t *__restrict__ c2f,
+                                    const int32_t *__restrict__ f2c,
+                                    const double *__restrict__ phi,
+                                    const double *__restrict__ x, Quadric quad,
+                                    int8_t *__restrict__ tags) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nbf) return;
+  const int32_t c = bfacets[2 * i];
+  const int lf0 = bfacets[2 * i + 1];
+  for (int k = 0; k < lf0; ++k)
+    if (f2c[2 * (int64_t)c2f[(int64_t)c * fvs.nfpc + k] + 1] < 0) return;  // not the first
+  double num = 0.0, den = 0.0;
+  for (int k = lf0; k < fvs.nfpc; ++k) {
+    const int32_t f = c2f[(int64_t)c * fvs.nfpc + k];
+    if (f2c[2 * (int64_t)f + 1] >= 0) continue;
+    int32_t v[3];
+    for (int j = 0; j < fvs.nvpf; ++j) v[j] = cells[(int64_t)c * nvpc + fvs.fv[k][j]];
+    int64_t base = 0;
+    if (KIND == PHX_PHI_POINTS) base = lower_bound_i32(bfacet_ids, nbf, f) * (int64_t)tab.npts;
+    double pn = 0.0, pd = 0.0;
+    for (int q = 0; q < tab.npts; ++q) {
+      const double p = phi_at<KIND, GDIM>(tab, q, fvs.nvpf, v, phi, x, quad, base);
+      pn = pn + p;
+      pd = pd + fabs(p);
+    }
+    num = num + pn;
+    den = den + pd;
+  }
+  const double d = (den > 0.0) ? num / den : 0.5;
+  if (d > -1.0 && d < 1.0) tags[c] = (int8_t)(tags[c] | PHX_BCUT_BIT);
+}
+
+// --- a4: facet tags; per-facet predicates equivalent to the set algebra of :454-496 ----------
+__global__ void __launch_bounds__(256)
+k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restrict__ ctags,
+             int no_ext, int8_t *__restrict__ ftags, unsigned long long *__restrict__ bad) {
+  const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  const int2 cc = *reinterpret_cast<const int2 *>(f2c + 2 * f);
+  const int b0 = (int)(uint8_t)ctags[cc.x];
+  const int t0 = b0 & PHX_TAG_MASK;
+  const int t1 = cc.y >= 0 ? (ctags[cc.y] & PHX_TAG_MASK) : 0;
+  const bool I = (t0 == 1) || (t1 == 1);
+  const bool C = (t0 == 2) || (t1 == 2);
+  const bool E = (t0 == 3) || (t1 == 3);
+  const bool B = cc.y < 0;
+  const bool cellcut = (b0 & PHX_BCUT_BIT) != 0;
+  const bool CB = B && cellcut;                       // :454-456
+  const bool UB = B && !cellcut && !E && !I;          // :457-461
+  const bool IB = I && C;                             // :464-466
+  bool BF = no_ext ? B : ((E && C) || UB);            // :469-474
+  const bool DI = E && I;                             // :476-478
+  const bool cut = (C && !(BF || IB || DI || UB)) || CB;  // :480-484
+  const bool inte = I && !(IB || BF || DI);           // :487-489
+  const bool ext = E && !(IB || BF || DI);            // :492-494
+  BF = BF && !cut;                                    // :496
+  int8_t t = 0;
+  if (ext) t = 5;
+  if (inte) t = 1;
+  if (IB) t = 3;
+  if (cut) t = 2;
+  if (BF) t = 4;
+  if (DI) t = 6;
+  ftags[f] = t;
+  const int count = (int)ext + (int)inte + (int)IB + (int)cut + (int)BF + (int)DI;
+  if (count != 1) atomicAdd(bad, 1ull);
+}
+
+// --- a6: (facet, cell) incidences of a one-sided measure -------------------------------------
+// key = 2*facet + position of the cell in the reversed link list (mesh_scripts.py:210-213), so a
+// host-side sort by key reproduces the reference's first-seen order.
+__global__ void k_collect_entities(int64_t nf, int facet_tag, int cell_mask,
+                                   const int32_t *__restrict__ f2c,
+                                   const int32_t *__restrict__ c2f, int nfpc,
+                                   const int8_t *__restrict__ ctags,
+                                   const int8_t *__restrict__ ftags, int64_t cap,
+                                   int64_t *__restrict__ out,
+                                   unsigned long long *__restrict__ count) {
+  const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (f >= nf || ftags[f] != facet_tag) return;
+  const int32_t c0 = f2c[2 * f], c1 = f2c[2 * f + 1];
+  for (int pos = 0; pos < 2; ++pos) {
+    const int32_t c = c1 >= 0 ? (pos == 0 ? c1 : c0) : (pos == 0 ? c0 : -1);
+    if (c < 0) continue;
+    const int t = ctags[c] & PHX_TAG_MASK;
+    if (t > 30 || !((cell_mask >> t) & 1)) continue;
+    int lf = 0;
+    for (int k = 0; k < nfpc; ++k)
+      if (c2f[(int64_t)c * nfpc + k] == (int32_t)f) lf = k;
+    const unsigned long long slot = atomicAdd(count, 1ull);
+    if ((int64_t)slot < cap) {
+      out[2 * slot] = 2 * f + pos;
+      out[2 * slot + 1] = ((int64_t)c << 8) | lf;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+static int make_tab(const phx_mesh *m, int degree, int which, DetTab *tab) {
+  std::vector<double> t;
+  int npts = 0, nfun = 0;
+  PHX_CHECK(phx_shape_table(m->cell_type, degree, which, t, &npts, &nfun));
+  memset(tab, 0, sizeof(*tab));
+  tab->npts = npts;
+  tab->nfun = nfun;
+  for (size_t i = 0; i < t.size(); ++i) tab->N[i] = t[i];
+  return PHX_OK;
+}
+
+// Stage the level-set on the device; returns the device pointer (and an owned temp, if any).
+static int stage_phi(phx_mesh *m, int phi_kind, const double *phi, int loc, int64_t count,
+                     const double **dev, double **owned, Quadric *quad) {
+  *owned = nullptr;
+  *dev = nullptr;
+  memset(quad, 0, sizeof(*quad));
+  PHX_REQUIRE(phi != nullptr, PHX_ERR_VALUE, "phi is NULL");
+  if (phi_kind == PHX_PHI_QUADRIC) {
+    double h[7];
+    if (loc == PHX_DEVICE) PHX_HIP(hipMemcpy(h, phi, sizeof(h), hipMemcpyDeviceToHost));
+    else memcpy(h, phi, sizeof(h));
+    for (int a = 0; a < 3; ++a) { quad->c[a] = h[a]; quad->s[a] = h[3 + a]; }
+    quad->c0 = h[6];
+    return PHX_OK;
+  }
+  if (loc == PHX_DEVICE) { *dev = phi; return PHX_OK; }
+  PHX_HIP(hipMalloc(owned, sizeof(double) * (size_t)(count > 0 ? count : 1)));
+  PHX_HIP(hipMemcpyAsync(*owned, phi, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, m->stream));
+  *dev = *owned;
+  return PHX_OK;
+}
+
+static int64_t cell_points_count(const phx_mesh *m, int degree) {
+  DetTab t;
+  if (make_tab(m, degree, 0, &t) != PHX_OK) return 0;
+  return t.npts;
+}
+
+static int read_hist(phx_mesh *m, const int8_t *tags, int64_t n, int nbins, int64_t *out) {
+  unsigned long long *d = nullptr;
+  PHX_HIP(hipMalloc(&d, sizeof(unsigned long long) * 8));
+  PHX_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long) * 8, m->stream));
+  const int blocks = (int)std::min<int64_t>(phx_div_up(n, 256), 2048);
+  k_tag_hist<<<dim3(blocks), dim3(256), 0, m->stream>>>(n, tags, nbins, d);
+  unsigned long long h[8];
+  PHX_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(d));
+  for (int i = 0; i < nbins; ++i) out[i] = (int64_t)h[i];
+  return PHX_OK;
+}
+
+template <int KIND>
+static int launch_tag_cells(phx_mesh *m, const DetTab &tab, const double *dphi, const Quadric &q,
+                            int *dwarn) {
+  const dim3 grid((unsigned)phx_div_up(m->nc, 256)), block(256);
+  if (m->cell_type == PHX_TRIANGLE)
+    k_tag_cells<KIND, 2, 3><<<grid, block, 0, m->stream>>>(m->nc, tab, m->cells, dphi, m->x, q, m->cell_tags, dwarn);
+  else if (m->cell_type == PHX_QUADRILATERAL)
+    k_tag_cells<KIND, 2, 4><<<grid, block, 0, m->stream>>>(m->nc, tab, m->cells, dphi, m->x, q, m->cell_tags, dwarn);
+  else
+    k_tag_cells<KIND, 3, 4><<<grid, block, 0, m->stream>>>(m->nc, tab, m->cells, dphi, m->x, q, m->cell_tags, dwarn);
+  PHX_HIP(hipGetLastError());
+  return PHX_OK;
+}
+
+extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int loc,
+                             int detection_degree, int single_layer_cut,
+                             int *warn_zero_denominator) {
+  PHX_HIP(hipSetDevice(m->device));
+  PHX_REQUIRE(phi_kind >= 0 && phi_kind <= 2, PHX_ERR_VALUE, "unknown phi_kind %d", phi_kind);
+  DetTab tab;
+  PHX_CHECK(make_tab(m, detection_degree, 0, &tab));
+  const double *dphi = nullptr;
+  double *owned = nullptr;
+  Quadric quad;
+  const int64_t count = phi_kind == PHX_PHI_NODAL_P1 ? m->nv : m->nc * (int64_t)tab.npts;
+  PHX_CHECK(stage_phi(m, phi_kind, phi, loc, count, &dphi, &owned, &quad));
+  int *dwarn = nullptr;
+  PHX_HIP(hipMalloc(&dwarn, sizeof(int)));
+  PHX_HIP(hipMemsetAsync(dwarn, 0, sizeof(int), m->stream));
+  PHX_CHECK(phx_begin_timing(m));
+  if (phi_kind == PHX_PHI_NODAL_P1) PHX_CHECK(launch_tag_cells<PHX_PHI_NODAL_P1>(m, tab, dphi, quad, dwarn));
+  else if (phi_kind == PHX_PHI_POINTS) PHX_CHECK(launch_tag_cells<PHX_PHI_POINTS>(m, tab, dphi, quad, dwarn));
+  else PHX_CHECK(launch_tag_cells<PHX_PHI_QUADRIC>(m, tab, dphi, quad, dwarn));
+  if (single_layer_cut) {
+    uint8_t *touched = nullptr;
+    PHX_HIP(hipMalloc(&touched, (size_t)m->nv));
+    PHX_HIP(hipMemsetAsync(touched, 0, (size_t)m->nv, m->stream));
+    const dim3 grid((unsigned)phx_div_up(m->nc, 256)), block(256);
+    if (m->ci.nvpc == 3) {
+      k_mark_inside_vertices<3><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
+      k_demote_isolated_cut<3><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
+    } else {
+      k_mark_inside_vertices<4><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
+      k_demote_isolated_cut<4><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
+    }
+    PHX_HIP(hipGetLastError());
+    PHX_CHECK(phx_end_timing(m, 0));
+    PHX_HIP(hipFree(touched));
+  } else {
+    PHX_CHECK(phx_end_timing(m, 0));
+  }
+  int hwarn = 0;
+  PHX_HIP(hipMemcpy(&hwarn, dwarn, sizeof(int), hipMemcpyDeviceToHost));
+  PHX_HIP(hipFree(dwarn));
+  if (owned) PHX_HIP(hipFree(owned));
+  if (warn_zero_denominator) *warn_zero_denominator = hwarn;
+  PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist));
+  m->have_cell_tags = true;
+  m->have_facet_tags = false;
+  m->have_entities = false;
+  return PHX_OK;
+}
+
+template <int KIND>
+static int launch_bcut(phx_mesh *m, const DetTab &tab, const FacetVerts &fvs, const double *dphi,
+                       const Quadric &q) {
+  if (m->nbf == 0) return PHX_OK;
+  const dim3 grid((unsigned)phx_div_up(m->nbf, 256)), block(256);
+  if (m->gdim == 2)
+    k_boundary_cell_cut<KIND, 2><<<grid, block, 0, m->stream>>>(m->nbf, tab, fvs, m->ci.nvpc, m->bfacets, m->bfacet_ids, m->cells, m->c2f, m->f2c, dphi, m->x, q, m->cell_tags);
+  else
+    k_boundary_cell_cut<KIND, 3><<<grid, block, 0, m->stream>>>(m->nbf, tab, fvs, m->ci.nvpc, m->bfacets, m->bfacet_ids, m->cells, m->c2f, m->f2c, dphi, m->x, q, m->cell_tags);
+  PHX_HIP(hipGetLastError());
+  return PHX_OK;
+}
+
+__global__ void k_clear_bcut(int64_t n, int8_t *tags) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) tags[i] = (int8_t)(tags[i] & PHX_TAG_MASK);
+}
+
+static int run_facet_rule(phx_mesh *m) {
+  unsigned long long *dbad = nullptr;
+  PHX_HIP(hipMalloc(&dbad, sizeof(unsigned long long)));
+  PHX_HIP(hipMemsetAsync(dbad, 0, sizeof(unsigned long long), m->stream));
+  k_tag_facets<<<dim3((unsigned)phx_div_up(m->nf, 256)), dim3(256), 0, m->stream>>>(
+      m->nf, m->f2c, m->cell_tags, m->tag_hist[3] == 0 ? 1 : 0, m->facet_tags, dbad);
+  PHX_HIP(hipGetLastError());
+  PHX_CHECK(phx_end_timing(m, 1));
+  unsigned long long bad = 0;
+  PHX_HIP(hipMemcpy(&bad, dbad, sizeof(bad), hipMemcpyDeviceToHost));
+  PHX_HIP(hipFree(dbad));
+  PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist));
+  m->have_facet_tags = true;
+  m->have_entities = false;
+  PHX_REQUIRE(bad == 0, PHX_ERR_PARTITION,
+              "%llu facets belong to none or several of the reference's facet sets "
+              "(dolfinx MeshTags would reject duplicated entities)", bad);
+  return PHX_OK;
+}
+
+extern "C" int phx_tag_facets(phx_mesh *m, int phi_kind, const double *phi, int loc,
+                              int detection_degree) {
+  PHX_HIP(hipSetDevice(m->device));
+  PHX_REQUIRE(m->have_cell_tags, PHX_ERR_VALUE, "phx_tag_cells must run before phx_tag_facets");
+  PHX_REQUIRE(phi_kind >= 0 && phi_kind <= 2, PHX_ERR_VALUE, "unknown phi_kind %d", phi_kind);
+  DetTab tab;
+  PHX_CHECK(make_tab(m, detection_degree, 1, &tab));
+  FacetVerts fvs;
+  fvs.nfpc = m->ci.nfpc;
+  fvs.nvpf = m->ci.nvpf;
+  for (int f = 0; f < 4; ++f) for (int k = 0; k < 3; ++k) fvs.fv[f][k] = m->ci.fv[f][k];
+  const double *dphi = nullptr;
+  double *owned = nullptr;
+  Quadric quad;
+  int64_t count = m->nv;
+  const double *src = phi;
+  if (phi_kind == PHX_PHI_POINTS) {
+    // layout: phi_cells[nc*npts_cell] followed by phi_bfacets[nbf*npts_facet]
+    const int64_t skip = m->nc * cell_points_count(m, detection_degree);
+    src = phi + skip;
+    count = m->nbf * (int64_t)tab.npts;
+  }
+  PHX_CHECK(stage_phi(m, phi_kind, src, loc, count, &dphi, &owned, &quad));
+  PHX_CHECK(phx_begin_timing(m));
+  k_clear_bcut<<<dim3((unsigned)phx_div_up(m->nc, 256)), dim3(256), 0, m->stream>>>(m->nc, m->cell_tags);
+  if (phi_kind == PHX_PHI_NODAL_P1) PHX_CHECK(launch_bcut<PHX_PHI_NODAL_P1>(m, tab, fvs, dphi, quad));
+  else if (phi_kind == PHX_PHI_POINTS) PHX_CHECK(launch_bcut<PHX_PHI_POINTS>(m, tab, fvs, dphi, quad));
+  else PHX_CHECK(launch_bcut<PHX_PHI_QUADRIC>(m, tab, fvs, dphi, quad));
+  const int rc = run_facet_rule(m);
+  if (owned) PHX_HIP(hipFree(owned));
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void k_scatter_tags(int64_t n, const int32_t *__restrict__ idx,
+                               const int32_t *__restrict__ val, int8_t *__restrict__ tags,
+                               int keep_mask) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) tags[idx[i]] = (int8_t)((tags[idx[i]] & keep_mask) | val[i]);
+}
+
+extern "C" int phx_overwrite_tags(phx_mesh *m, int entity_is_facet, int64_t n,
+                                  const int32_t *indices, const int32_t *values) {
+  PHX_HIP(hipSetDevice(m->device));
+  PHX_REQUIRE(entity_is_facet ? m->have_facet_tags : m->have_cell_tags, PHX_ERR_VALUE,
+              "tags must be computed before they can be overwritten");
+  const int64_t nent = entity_is_facet ? m->nf : m->nc;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t v = values[i];
+    if (entity_is_facet) {
+      // mesh_scripts.py:613-614
+      PHX_REQUIRE(!((v >= 1 && v <= 6) || v == 100 || v == 101), PHX_ERR_VALUE,
+                  "Cannot overwrite facets tags with values 1, 2, 3, 4, 5, 6, 100 or 101.");
+    } else {
+      // mesh_scripts.py:608-609
+      PHX_REQUIRE(!(v >= 1 && v <= 3), PHX_ERR_VALUE,
+                  "Cannot overwrite cells tags with values 1, 2 or 3.");
+    }
+    PHX_REQUIRE(v >= 0 && v <= 127, PHX_ERR_NOT_IMPLEMENTED, "user tag values must lie in 0..127");
+    PHX_REQUIRE(indices[i] >= 0 && indices[i] < nent, PHX_ERR_VALUE, "entity index out of range");
+  }
+  if (n == 0) return PHX_OK;
+  int32_t *di = nullptr, *dv = nullptr;
+  PHX_HIP(hipMalloc(&di, sizeof(int32_t) * (size_t)n));
+  PHX_HIP(hipMalloc(&dv, sizeof(int32_t) * (size_t)n));
+  PHX_HIP(hipMemcpyAsync(di, indices, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, m->stream));
+  PHX_HIP(hipMemcpyAsync(dv, values, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, m->stream));
+  k_scatter_tags<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, m->stream>>>(
+      n, di, dv, entity_is_facet ? m->facet_tags : m->cell_tags, entity_is_facet ? 0 : PHX_BCUT_BIT);
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(di));
+  PHX_HIP(hipFree(dv));
+  if (entity_is_facet) PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist));
+  else PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist));
+  m->have_entities = false;
+  return PHX_OK;
+}
+
+__global__ void k_narrow_tags(int64_t n, const int32_t *__restrict__ in, int8_t *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int8_t)(in[i] & PHX_TAG_MASK);
+}
+
+extern "C" int phx_set_tags(phx_mesh *m, int entity_is_facet, const int32_t *values, int loc) {
+  PHX_HIP(hipSetDevice(m->device));
+  const int64_t n = entity_is_facet ? m->nf : m->nc;
+  const int32_t *src = values;
+  int32_t *tmp = nullptr;
+  if (loc != PHX_DEVICE) {
+    PHX_HIP(hipMalloc(&tmp, sizeof(int32_t) * (size_t)n));
+    PHX_HIP(hipMemcpyAsync(tmp, values, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, m->stream));
+    src = tmp;
+  }
+  k_narrow_tags<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, m->stream>>>(
+      n, src, entity_is_facet ? m->facet_tags : m->cell_tags);
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  if (tmp) PHX_HIP(hipFree(tmp));
+  if (entity_is_facet) {
+    PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist));
+    m->have_facet_tags = true;
+  } else {
+    PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist));
+    m->have_cell_tags = true;
+  }
+  m->have_entities = false;
+  return PHX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Integration entities: device collection (unordered), cached per tag state.
+int phx_collect_entities(phx_mesh *m) {
+  if (m->have_entities) return PHX_OK;
+  PHX_REQUIRE(m->have_cell_tags && m->have_facet_tags, PHX_ERR_VALUE,
+              "cell and facet tags must be computed first");
+  // which 0 -> ds(100): facets tagged 4 seen from cells {1,2}   (mesh_scripts.py:619-622)
+  // which 1 -> ds(101): facets tagged 3 seen from cells {2,3}   (mesh_scripts.py:623-626)
+  const int ftag[2] = {4, 3};
+  const int cmask[2] = {(1 << 1) | (1 << 2), (1 << 2) | (1 << 3)};
+  unsigned long long *dcount = nullptr;
+  PHX_HIP(hipMalloc(&dcount, sizeof(unsigned long long)));
+  for (int w = 0; w < 2; ++w) {
+    if (m->ent_buf[w]) { PHX_HIP(hipFree(m->ent_buf[w])); m->ent_buf[w] = nullptr; }
+    const int64_t cap = 2 * m->ftag_hist[ftag[w]] + 1;
+    PHX_HIP(hipMalloc(&m->ent_buf[w], sizeof(int64_t) * 2 * (size_t)cap));
+    PHX_HIP(hipMemsetAsync(dcount, 0, sizeof(unsigned long long), m->stream));
+    k_collect_entities<<<dim3((unsigned)phx_div_up(m->nf, 256)), dim3(256), 0, m->stream>>>(
+        m->nf, ftag[w], cmask[w], m->f2c, m->c2f, m->ci.nfpc, m->cell_tags, m->facet_tags, cap,
+        m->ent_buf[w], dcount);
+    PHX_HIP(hipGetLastError());
+    unsigned long long cnt = 0;
+    PHX_HIP(hipMemcpyAsync(&cnt, dcount, sizeof(cnt), hipMemcpyDeviceToHost, m->stream));
+    PHX_HIP(hipStreamSynchronize(m->stream));
+    PHX_REQUIRE((int64_t)cnt <= cap, PHX_ERR_HIP, "entity buffer overflow");
+    m->ent_count[w] = (int64_t)cnt;
+  }
+  PHX_HIP(hipFree(dcount));
+  m->have_entities = true;
+  return PHX_OK;
+}
+
+extern "C" int phx_integration_entities(phx_mesh *m, int which, int32_t *out, int64_t *n_pairs) {
+  PHX_HIP(hipSetDevice(m->device));
+  PHX_REQUIRE(which == 100 || which == 101, PHX_ERR_VALUE, "which must be 100 or 101");
+  PHX_CHECK(phx_collect_entities(m));
+  const int w = which == 100 ? 0 : 1;
+  const int64_t n = m->ent_count[w];
+  *n_pairs = n;
+  if (!out || n == 0) return PHX_OK;
+  std::vector<int64_t> h(2 * (size_t)n);
+  PHX_HIP(hipMemcpy(h.data(), m->ent_buf[w], sizeof(int64_t) * 2 * (size_t)n, hipMemcpyDeviceToHost));
+  struct Rec { int64_t key; int32_t cell; int32_t lf; int64_t first; };
+  std::vector<Rec> r((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    r[i].key = h[2 * i];
+    r[i].cell = (int32_t)(h[2 * i + 1] >> 8);
+    r[i].lf = (int32_t)(h[2 * i + 1] & 0xff);
+  }
+  // first-seen order of the cells (np.unique(..., return_index) at mesh_scripts.py:168-170),
+  // then ascending local facet inside a cell (:173-185)
+  std::sort(r.begin(), r.end(), [](const Rec &a, const Rec &b) {
+    return a.cell != b.cell ? a.cell < b.cell : a.key < b.key;
+  });
+  for (size_t i = 0; i < r.size();) {
+    size_t j = i;
+    while (j < r.size() && r[j].cell == r[i].cell) { r[j].first = r[i].key; ++j; }
+    i = j;
+  }
+  std::sort(r.begin(), r.end(), [](const Rec &a, const Rec &b) {
+    return a.first != b.first ? a.first < b.first : a.lf < b.lf;
+  });
+  for (int64_t i = 0; i < n; ++i) { out[2 * i] = r[i].cell; out[2 * i + 1] = r[i].lf; }
+  return PHX_OK;
+}

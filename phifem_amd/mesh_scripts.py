@@ -1,0 +1,228 @@
+"""Host mirror of `phifem.mesh_scripts` (src/phifem/mesh_scripts.py) over the C ABI.
+
+Same entry point, argument meaning, return shape and error behaviour as the reference's
+`compute_tags_measures` (mesh_scripts.py:571-653); the classification itself runs in HIP.
+"""
+import ctypes as C
+import os
+import warnings
+
+import numpy as np
+
+from . import _lib as L
+from .mesh import Mesh, MeshTags
+
+# mesh_scripts.py:22-25
+debug_mode = os.environ.get("MODE", "") == "debug"
+
+_ZERO_DEN_MSG = ("The detection function is zero everywhere on a cell. We mark it as 'cut' but "
+                 "this can be incorrect and should be carefully checked.")
+
+
+class NodalFunction:
+    """A P1 function on a mesh given by its vertex values (stands in for a
+    `dolfinx.fem.Function` in a first-order Lagrange space).  `values` may be a numpy array or
+    a torch tensor living on the mesh's GPU."""
+
+    def __init__(self, values):
+        self.values = values
+
+
+class Quadric:
+    """phi(x) = sum_a (s_a x_a - c_a)^2 + c0, evaluated on the device at the detection points
+    (the closed form behind `gen_levelset` of tests/test_compute_meshtags.py:18-25 and the
+    spherical level-sets of the BASELINE configurations)."""
+
+    def __init__(self, centre, scale, c0):
+        p = np.zeros(7)
+        p[0:len(centre)] = centre
+        p[3:3 + len(scale)] = scale
+        p[6] = c0
+        self.params = p
+
+
+class BoundaryMeasure:
+    """Stand-in for the `ufl.Measure("ds", subdomain_data=...)` the reference returns
+    (mesh_scripts.py:631-633,644): `measure(100)` / `measure(101)` give the flat int32
+    [cell, local facet, ...] integration entities; on a sub-mesh the measure covers every
+    exterior facet."""
+
+    def __init__(self, mesh, box_mode):
+        self._mesh = mesh
+        self._box = box_mode
+        self._cache = {}
+
+    def __call__(self, tag):
+        if not self._box:
+            return self._mesh.boundary_facets.reshape(-1)
+        if tag not in self._cache:
+            n = C.c_int64(0)
+            L.check(L.lib.phx_integration_entities(self._mesh._h, tag, None, C.byref(n)))
+            out = np.empty(2 * n.value, dtype=np.int32)
+            if n.value:
+                L.check(L.lib.phx_integration_entities(
+                    self._mesh._h, tag, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+            self._cache[tag] = out
+        return self._cache[tag]
+
+
+def _levelset_args(mesh, levelset, degree):
+    """-> (phi_kind, pointer, loc, keepalive)."""
+    if isinstance(levelset, NodalFunction):
+        v = levelset.values
+        if not hasattr(v, "data_ptr"):
+            v = np.ascontiguousarray(v, dtype=np.float64)
+            if v.shape[0] != mesh.nv:
+                raise ValueError("nodal level-set must have one value per mesh vertex")
+        p, loc = L.ptr(v)
+        return L.PHI_NODAL_P1, p, loc, v
+    if isinstance(levelset, Quadric):
+        p, loc = L.ptr(levelset.params)
+        return L.PHI_QUADRIC, p, loc, levelset.params
+    if callable(levelset):
+        # "UFL expression" mode (tests/test_compute_meshtags.py:159-161): the host evaluates
+        # the callable at the physical detection points, the device does the classification.
+        vals = _evaluate_callable(mesh, levelset, degree)
+        p, loc = L.ptr(vals)
+        return L.PHI_POINTS, p, loc, vals
+    raise TypeError("discrete_levelset must be a NodalFunction, a Quadric or a callable x -> phi")
+
+
+def _ref_points(cell_type, degree, which):
+    n = C.c_int64(0)
+    ct = L.CELL_TYPES[cell_type]
+    L.check(L.lib.phx_detection_points(ct, degree, which, None, C.byref(n)))
+    dim = {"triangle": 2, "quadrilateral": 2, "tetrahedron": 3}[cell_type] - which
+    out = np.empty((n.value, dim))
+    L.check(L.lib.phx_detection_points(ct, degree, which, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return out
+
+
+def _shape(kind, pts):
+    x = pts[:, 0]
+    if kind == "interval":
+        return np.stack([1.0 - x, x], axis=1)
+    y = pts[:, 1]
+    if kind == "triangle":
+        return np.stack([(1.0 - x) - y, x, y], axis=1)
+    if kind == "quadrilateral":
+        return np.stack([(1.0 - x) * (1.0 - y), x * (1.0 - y), (1.0 - x) * y, x * y], axis=1)
+    z = pts[:, 2]
+    return np.stack([((1.0 - x) - y) - z, x, y, z], axis=1)
+
+
+_FACET_VERTS = {
+    "triangle": np.array([[1, 2], [0, 2], [0, 1]]),
+    "quadrilateral": np.array([[0, 1], [0, 2], [1, 3], [2, 3]]),
+    "tetrahedron": np.array([[1, 2, 3], [0, 2, 3], [0, 1, 3], [0, 1, 2]]),
+}
+
+
+def _push(N, xv):
+    """x_q = sum_i N[q,i] x_i, accumulated left to right (same order as the device code)."""
+    acc = N[None, :, 0, None] * xv[:, None, 0, :]
+    for i in range(1, N.shape[1]):
+        acc = acc + N[None, :, i, None] * xv[:, None, i, :]
+    return acc  # (n, npts, gdim)
+
+
+def _evaluate_callable(mesh, f, degree):
+    x = mesh.x
+    cells = mesh.cells
+    Nc = _shape(mesh.cell_type, _ref_points(mesh.cell_type, degree, 0))
+    xq = _push(Nc, x[cells])
+    with np.errstate(all="ignore"):
+        vc = np.asarray(f(xq.reshape(-1, mesh.gdim).T), dtype=np.float64).reshape(-1)
+    bf = mesh.boundary_facets
+    ftype = "interval" if mesh.tdim == 2 else "triangle"
+    Nf = _shape(ftype, _ref_points(mesh.cell_type, degree, 1))
+    fv = _FACET_VERTS[mesh.cell_type][bf[:, 1]]
+    xf = _push(Nf, x[np.take_along_axis(cells[bf[:, 0]], fv, axis=1)])
+    with np.errstate(all="ignore"):
+        vf = np.asarray(f(xf.reshape(-1, mesh.gdim).T), dtype=np.float64).reshape(-1)
+    return np.ascontiguousarray(np.concatenate([vc, vf]))
+
+
+def _tag_cells(mesh, levelset, detection_degree, single_layer_cut=False):
+    """mesh_scripts.py:284-390."""
+    kind, p, loc, keep = _levelset_args(mesh, levelset, detection_degree)
+    warn = C.c_int(0)
+    L.check(L.lib.phx_tag_cells(mesh._h, kind, p, loc, detection_degree,
+                                1 if single_layer_cut else 0, C.byref(warn)))
+    if warn.value:
+        warnings.warn(_ZERO_DEN_MSG, RuntimeWarning)  # mesh_scripts.py:129-133
+    return (kind, p, loc, keep)
+
+
+def _tag_facets(mesh, staged, detection_degree):
+    """mesh_scripts.py:393-558."""
+    kind, p, loc, keep = staged
+    L.check(L.lib.phx_tag_facets(mesh._h, kind, p, loc, detection_degree))
+    if mesh.nbf < mesh.nc:
+        # the reference's `ds` detection has a zero denominator on every cell without a
+        # background-boundary facet, so its RuntimeWarning always fires here
+        warnings.warn(_ZERO_DEN_MSG, RuntimeWarning)
+
+
+def _meshtags(mesh, facets):
+    vals = mesh.facet_tag_values() if facets else mesh.cell_tag_values()
+    idx = np.flatnonzero(vals > 0).astype(np.int32)
+    return MeshTags(mesh.tdim - 1 if facets else mesh.tdim, idx, vals[idx])
+
+
+def compute_tags_measures(mesh, discrete_levelset, detection_degree, box_mode=False,
+                          single_layer_cut=False, overwrite_tags={}):
+    """Compute the mesh (cells and facets) tags as well as the discrete boundary measures.
+
+    Mirrors src/phifem/mesh_scripts.py:571-653.
+
+    Args:
+        mesh: a `phifem_amd.Mesh`.
+        discrete_levelset: `NodalFunction` (P1 values), `Quadric`, or a callable x -> phi in
+            the reference's numpy convention (x[0], x[1], ...), evaluated like a UFL expression.
+        detection_degree: degree of the boundary-point detection rule.
+        box_mode: False -> tags on the sub-mesh of cells tagged 1/2; True -> on the input mesh.
+        single_layer_cut: force a single layer of cut cells.
+        overwrite_tags: {"cells": MeshTags, "facets": MeshTags} user tags that win.
+
+    Returns (cells_tags, facets_tags, submesh|None, boundaries_measure, submesh_maps|None).
+    """
+    staged = _tag_cells(mesh, discrete_levelset, detection_degree, single_layer_cut)
+    if debug_mode:
+        cv = mesh.cell_tag_values()
+        if not np.any(cv == 1):
+            raise ValueError("No interior cells (1)!")          # mesh_scripts.py:361-362
+        if not np.any(cv == 2):
+            print("WARNING: no cut cells computed in the partition.")
+    _tag_facets(mesh, staged, detection_degree)
+    if debug_mode:
+        fv = mesh.facet_tag_values()
+        if not np.any(fv == 1):
+            raise ValueError("No interior facets (1)!")         # mesh_scripts.py:500-501
+        if not np.any(fv == 2):
+            print("WARNING: no cut facet computed in the partition.")
+        if not np.any(fv == 4):
+            raise ValueError("No boundary facets (4)!")         # mesh_scripts.py:504-505
+
+    for key, is_facet in (("cells", 0), ("facets", 1)):
+        if key in overwrite_tags:
+            ow = overwrite_tags[key]
+            idx = np.ascontiguousarray(ow.indices, dtype=np.int32)
+            val = np.ascontiguousarray(ow.values, dtype=np.int32)
+            L.check(L.lib.phx_overwrite_tags(mesh._h, is_facet, idx.size,
+                                             idx.ctypes.data_as(C.c_void_p),
+                                             val.ctypes.data_as(C.c_void_p)))
+
+    if box_mode:
+        return (_meshtags(mesh, False), _meshtags(mesh, True), None,
+                BoundaryMeasure(mesh, True), None)
+
+    h = C.c_void_p()
+    L.check(L.lib.phx_submesh_create(mesh._h, C.byref(h)))
+    sub = Mesh(h, parent=mesh)
+    c_map = np.empty(sub.nc, dtype=np.int32)
+    v_map = np.empty(sub.nv, dtype=np.int32)
+    L.check(L.lib.phx_submesh_maps(sub._h, c_map.ctypes.data_as(C.c_void_p),
+                                   v_map.ctypes.data_as(C.c_void_p)))
+    return (_meshtags(sub, False), _meshtags(sub, True), sub, BoundaryMeasure(sub, False),
+            [c_map, v_map, v_map.copy()])

@@ -1,0 +1,108 @@
+"""PhiFEMSolver: the assemble -> solve sequence of the weak-Dirichlet demo over the C ABI.
+
+The reference writes this sequence out in each demo (demo/weak-dirichlet/flower/main.py:102-186:
+UFL forms, dolfinx assemble_matrix/assemble_vector, PETSc KSP + MUMPS); ROADMAP.md:15 plans a
+class-based interface for it.  This class is that interface for the P1 x P1 weak-Dirichlet
+Poisson problem, with the element integration, scatter and Krylov solve in HIP.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class PhiFEMSolver:
+    def __init__(self, mesh, pen_coef=1.0, stab_coef=1.0):
+        """mesh: a tagged `phifem_amd.Mesh` (box mode) or the sub-mesh returned by
+        `compute_tags_measures(..., box_mode=False)`; coefficients as main.py:42-43."""
+        self.mesh = mesh
+        self.pen_coef = float(pen_coef)
+        self.stab_coef = float(stab_coef)
+        self._sys = None
+        self.stats = {}
+
+    def __del__(self):
+        self._free()
+
+    def _free(self):
+        try:
+            if self._sys is not None:
+                L.lib.phx_system_destroy(self._sys)
+                self._sys = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def _arr(a, n):
+        if hasattr(a, "data_ptr"):
+            return a
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape[0] != n:
+            raise ValueError("nodal arrays must have one value per mesh vertex")
+        return a
+
+    def assemble(self, phi_h, f_h, u_D):
+        """Bilinear + linear form of main.py:112-154 (nodal P1 data, numpy or device tensors)."""
+        self._free()
+        nv = self.mesh.nv
+        phi_h, f_h, u_D = (self._arr(a, nv) for a in (phi_h, f_h, u_D))
+        locs = {L.ptr(a)[1] for a in (phi_h, f_h, u_D)}
+        if len(locs) != 1:
+            raise ValueError("phi_h, f_h and u_D must all live on the host or all on the device")
+        h = C.c_void_p()
+        L.check(L.lib.phx_assemble_poisson_wd(
+            self.mesh._h, self.pen_coef, self.stab_coef, L.ptr(phi_h)[0], L.ptr(f_h)[0],
+            L.ptr(u_D)[0], locs.pop(), C.byref(h)))
+        self._sys = h
+        return self.info()
+
+    def info(self):
+        i = (C.c_int64 * 8)()
+        L.check(L.lib.phx_system_info(self._sys, i))
+        keys = ("n_active", "n_active_u", "nnz", "n_full", "sell_padded_nnz", "slot_capacity",
+                "sell_nnz", "n_slices")
+        return dict(zip(keys, (int(v) for v in i)))
+
+    def export_csr(self):
+        """(scipy-style rowptr, col, val, rhs, dof) of the active system, for inspection/tests."""
+        i = self.info()
+        n, nnz = i["n_active"], i["nnz"]
+        rowptr = np.empty(n + 1, dtype=np.int64)
+        col = np.empty(nnz, dtype=np.int32)
+        val = np.empty(nnz, dtype=np.float64)
+        rhs = np.empty(n, dtype=np.float64)
+        dof = np.empty(n, dtype=np.int64)
+        L.check(L.lib.phx_system_export(self._sys, *(a.ctypes.data_as(C.c_void_p)
+                                                     for a in (rowptr, col, val, rhs, dof))))
+        return rowptr, col, val, rhs, dof
+
+    def solve(self, rtol=1e-8, max_iter=20000, out=None):
+        """Replaces the KSP/MUMPS block of main.py:162-182.  Returns the mixed solution in the
+        full numbering [u (nv), p (nv)] with inactive DoFs at zero; `out` may be a device
+        tensor of 2*nv doubles."""
+        nfull = 2 * self.mesh.nv
+        if out is None:
+            out = np.empty(nfull, dtype=np.float64)
+        p, loc = L.ptr(out)
+        st = (C.c_double * 4)()
+        L.check(L.lib.phx_solve(self._sys, 0, float(rtol), int(max_iter), p, loc, st))
+        self.stats = {"iterations": int(st[0]), "relres": st[1], "seconds": st[2],
+                      "spmv": int(st[3])}
+        return out
+
+    def split(self, w):
+        """solution_wh.split() (main.py:185): (u, p) views of the mixed vector."""
+        nv = self.mesh.nv
+        return w[:nv], w[nv:]
+
+    def spmv(self, x):
+        y = np.empty_like(x)
+        L.check(L.lib.phx_spmv(self._sys, x.ctypes.data_as(C.c_void_p),
+                               y.ctypes.data_as(C.c_void_p), L.HOST))
+        return y
+
+    def spmv_bench(self, reps=50):
+        o = (C.c_double * 3)()
+        L.check(L.lib.phx_spmv_bench(self._sys, int(reps), o))
+        return {"ms": o[0], "algorithmic_bytes": o[1], "padded_bytes": o[2]}

@@ -1,0 +1,146 @@
+"""GPU parity of assembly (a9, a10) and solve (a11) through the C ABI against the numpy oracle.
+
+Floating point: the HIP path sums element contributions with f64 atomics in arbitrary order and
+uses FMA, the oracle sums in COO order without FMA.  Tolerances (relative to the largest matrix
+/ vector entry): matrix and rhs 1e-12; solution 1e-6 at solver rtol 1e-10."""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import assembly as OA
+from oracle import tagging as T
+from oracle.topology import Topology
+
+pytestmark = pytest.mark.gpu
+MAT_TOL = 1e-12
+SOL_TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def P():
+    import phifem_amd
+    assert phifem_amd._lib.device_count() > 0
+    return phifem_amd
+
+
+def setup_problem(P, d, n, box_mode=True, centre=None, lin=False):
+    from phifem_amd.mesh_scripts import NodalFunction
+    lo, hi = [-1.5] * d, [1.5] * d
+    mesh = P.create_box(lo, hi, [n] * d)
+    x = mesh.x
+    centre = np.zeros(d) if centre is None else np.asarray(centre)
+    phi = ((x - centre) ** 2).sum(axis=1) - 1.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ct, ft, sub, meas, maps = P.compute_tags_measures(
+            mesh, NodalFunction(phi), 1, box_mode=box_mode, single_layer_cut=True)
+    work = mesh if box_mode else sub
+    xw = work.x
+    phiw = ((xw - centre) ** 2).sum(axis=1) - 1.0
+    if lin:
+        uex = xw @ np.arange(1, d + 1) + 0.5
+        f = np.zeros(work.nv)
+    else:
+        uex = np.prod(np.sin(xw), axis=1)
+        f = d * uex
+    ctype = "triangle" if d == 2 else "tetrahedron"
+    topo = Topology(ctype, work.cells.astype(np.int64), work.nv)
+    topo.c2f = work.c2f.astype(np.int64)
+    topo.f2c = work.f2c.astype(np.int64)
+    topo.nf = work.nf
+    ds = meas(100) if box_mode else work.boundary_facets.reshape(-1)
+    A, b, act = OA.assemble_poisson_wd(topo, xw, work.cell_tag_values(), work.facet_tag_values(),
+                                       ds, phiw, f, uex)
+    return work, phiw, f, uex, A, b, act
+
+
+def hip_matrix(solver):
+    rowptr, col, val, rhs, dof = solver.export_csr()
+    n = rowptr.size - 1
+    return sp.csr_matrix((val, col, rowptr), shape=(n, n)), rhs, dof
+
+
+@pytest.mark.parametrize("d,n,box", [(2, 24, True), (2, 40, True), (3, 8, True), (3, 12, True),
+                                     (2, 24, False), (3, 8, False)])
+def test_matrix_and_rhs_vs_oracle(P, d, n, box):
+    work, phi, f, uex, A, b, act = setup_problem(P, d, n, box_mode=box, centre=[0.03, -0.02, 0.01][:d])
+    s = P.PhiFEMSolver(work)
+    info = s.assemble(phi, f, uex)
+    H, rhs, dof = hip_matrix(s)
+    idx = np.flatnonzero(act)
+    assert info["n_active"] == idx.size
+    assert np.array_equal(dof, idx), "active DoF numbering differs"
+    Ao = A[idx][:, idx].tocsr()
+    Ao.sort_indices()
+    # same structural pattern (sorted columns), same values
+    assert np.array_equal(H.indptr, Ao.indptr)
+    assert np.array_equal(H.indices, Ao.indices)
+    scale = np.abs(Ao.data).max()
+    assert np.abs(H.data - Ao.data).max() <= MAT_TOL * scale
+    assert np.abs(rhs - b[idx]).max() <= MAT_TOL * max(np.abs(b).max(), 1e-300)
+    # SpMV kernel (SELL copy without the explicit zeros) against the CSR product
+    rng = np.random.default_rng(0)
+    xv = rng.standard_normal(idx.size)
+    y = s.spmv(xv)
+    yo = Ao @ xv
+    assert np.abs(y - yo).max() <= 1e-12 * np.abs(yo).max()
+    assert info["sell_nnz"] <= info["nnz"] and info["sell_padded_nnz"] >= info["sell_nnz"]
+
+
+@pytest.mark.parametrize("d,n", [(2, 32), (3, 10)])
+def test_patch_test_linear_solution(P, d, n):
+    """f = 0, u_D = u linear: P1 reproduces u exactly and p = 0 (consistency of main.py:112-151)."""
+    work, phi, f, uex, A, b, act = setup_problem(P, d, n, lin=True)
+    s = P.PhiFEMSolver(work)
+    s.assemble(phi, f, uex)
+    w = s.solve(rtol=1e-13, max_iter=5000)
+    u, p = s.split(w)
+    ua = act[:work.nv]
+    assert np.abs(u[ua] - uex[ua]).max() < 1e-8
+    assert np.abs(p).max() < 1e-6
+    assert np.all(w[~act] == 0.0)  # MUMPS ICNTL(24)=1 semantics: null-space components at zero
+
+
+@pytest.mark.parametrize("d,n,box", [(2, 48, True), (3, 12, True), (3, 16, True), (2, 32, False)])
+def test_solve_vs_direct(P, d, n, box):
+    work, phi, f, uex, A, b, act = setup_problem(P, d, n, box_mode=box)
+    s = P.PhiFEMSolver(work)
+    s.assemble(phi, f, uex)
+    w = s.solve(rtol=1e-10)
+    assert s.stats["relres"] <= 1e-10 and s.stats["iterations"] > 0
+    wo = OA.solve_direct(A, b, act)
+    assert np.abs(w - wo).max() <= SOL_TOL * np.abs(wo).max()
+    assert np.all(w[~act] == 0.0)
+    # true residual of the returned vector on the oracle's matrix
+    r = A @ w - b
+    assert np.linalg.norm(r[act]) <= 1e-8 * np.linalg.norm(b)
+
+
+def test_device_resident_inputs_and_outputs(P):
+    import torch
+    work, phi, f, uex, A, b, act = setup_problem(P, 3, 10)
+    s = P.PhiFEMSolver(work)
+    dev = torch.device("cuda:0")
+    tphi, tf, tu = (torch.from_numpy(a).to(dev) for a in (phi, f, uex))
+    s.assemble(tphi, tf, tu)
+    out = torch.empty(2 * work.nv, dtype=torch.float64, device=dev)
+    s.solve(rtol=1e-10, out=out)
+    torch.cuda.synchronize()
+    wo = OA.solve_direct(A, b, act)
+    assert np.abs(out.cpu().numpy() - wo).max() <= SOL_TOL * np.abs(wo).max()
+
+
+def test_convergence_rate_2d(P):
+    """L2-type error at the inside vertices falls ~4x per halving of h (P1, smooth solution),
+    mirroring the slope check of demo/interface-elasticity/main.py:392-400."""
+    errs = []
+    for n in (32, 64):
+        work, phi, f, uex, A, b, act = setup_problem(P, 2, n)
+        s = P.PhiFEMSolver(work)
+        s.assemble(phi, f, uex)
+        w = s.solve(rtol=1e-11)
+        inside = np.unique(work.cells[work.cell_tag_values() == 1])
+        errs.append(np.sqrt(np.mean((w[:work.nv][inside] - uex[inside]) ** 2)))
+    assert errs[0] / errs[1] > 3.0

@@ -1,0 +1,267 @@
+"""GPU parity of the tagging path (a1-a8) through the C ABI: HIP vs the numpy oracle, bit-exact,
+and HIP vs the reference's committed goldens."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import meshgen
+from oracle import tagging as T
+from oracle.topology import Topology
+
+from datasets import (FP_FRAGILE, FP_FRAGILE_DISCRETIZED, MESHTAG_DATA, ONE_SIDED_DATA,
+                      load_mesh)
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(__file__)
+
+
+@pytest.fixture(scope="module")
+def P():
+    import phifem_amd
+    assert phifem_amd._lib.device_count() > 0, "no GPU: the HIP path cannot run"
+    return phifem_amd
+
+
+_mesh_cache = {}
+
+
+def get_mesh(P, name):
+    if name not in _mesh_cache:
+        ctype, x, cells = load_mesh(name)
+        m = P.Mesh.from_arrays(ctype, x, cells)
+        topo = Topology(ctype, cells, x.shape[0])
+        _mesh_cache[name] = (m, topo, x)
+    return _mesh_cache[name]
+
+
+def test_topology_upload_matches_oracle(P):
+    for name in ("disk", "square_tri", "square_quad", "coarse_square"):
+        m, topo, x = get_mesh(P, name)
+        assert m.nf == topo.nf and m.nbf == topo.boundary_facets.size
+        assert np.array_equal(m.c2f, topo.c2f)
+        assert np.array_equal(m.f2c, topo.f2c)
+        bf = m.boundary_facets
+        assert np.array_equal(topo.c2f[bf[:, 0], bf[:, 1]], topo.boundary_facets)
+
+
+def levelset_variants(P, f, x):
+    from phifem_amd.mesh_scripts import NodalFunction, Quadric
+    out = [("callable", f, f)]
+    with np.errstate(all="ignore"):
+        nod = np.asarray(f(x.T), dtype=np.float64)
+    if np.all(np.isfinite(nod)):
+        out.append(("nodal", NodalFunction(nod), T.NodalP1(nod)))
+    if hasattr(f, "quadric"):
+        x0, a, x1, b, c = f.quadric
+        out.append(("quadric", Quadric([x0, x1], [a, b], c), f))
+    return out
+
+
+@pytest.mark.parametrize("name", list(MESHTAG_DATA))
+@pytest.mark.parametrize("deg", [1, 2, 3])
+@pytest.mark.parametrize("sl", [False, True])
+def test_tags_bit_exact_vs_oracle(P, name, deg, sl):
+    mesh_name, f = MESHTAG_DATA[name]
+    m, topo, x = get_mesh(P, mesh_name)
+    for label, ls_hip, ls_ora in levelset_variants(P, f, x):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                oc, of, _, omeas, _, _ = T.compute_tags_measures(
+                    topo.cell_type, x, topo, ls_ora, deg, box_mode=True, single_layer_cut=sl)
+            except ValueError:
+                with pytest.raises(ValueError):
+                    P.compute_tags_measures(m, ls_hip, deg, box_mode=True, single_layer_cut=sl)
+                continue
+            hc, hf, sub, hmeas, maps = P.compute_tags_measures(
+                m, ls_hip, deg, box_mode=True, single_layer_cut=sl)
+        assert sub is None and maps is None
+        assert np.array_equal(hc.indices, oc.indices), label
+        assert np.array_equal(hc.values, oc.values), label
+        assert np.array_equal(hf.indices, of.indices), label
+        assert np.array_equal(hf.values, of.values), label
+        assert hc.values.dtype == np.int32 and hc.indices.dtype == np.int32
+        for tag in (100, 101):
+            assert np.array_equal(hmeas(tag), omeas(tag)), (label, tag)
+        assert np.array_equal(hc.find(2), oc.find(2))
+
+
+@pytest.mark.parametrize("name", ["circle_in_circle", "boundary_crossing_circle",
+                                  "ellipse_in_square", "circle_near_boundary"])
+@pytest.mark.parametrize("deg", [1, 3])
+def test_submesh_mode_vs_oracle(P, name, deg):
+    mesh_name, f = MESHTAG_DATA[name]
+    m, topo, x = get_mesh(P, mesh_name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        oc, of, osub, _, omaps, _ = T.compute_tags_measures(
+            topo.cell_type, x, topo, f, deg, box_mode=False, single_layer_cut=True)
+        hc, hf, hsub, hmeas, hmaps = P.compute_tags_measures(
+            m, f, deg, box_mode=False, single_layer_cut=True)
+    assert np.array_equal(hmaps[0], omaps[0]) and np.array_equal(hmaps[1], omaps[1])
+    assert np.array_equal(hsub.cells, osub.topology.cells)
+    assert np.array_equal(hsub.x, osub.x)
+    assert np.array_equal(hsub.c2f, osub.topology.c2f)
+    assert np.array_equal(hc.values, oc.values) and np.array_equal(hc.indices, oc.indices)
+    assert np.array_equal(hf.values, of.values) and np.array_equal(hf.indices, of.indices)
+
+
+# ----------------------------------------------------------------------------------------------
+GOLD = np.load(os.path.join(HERE, "golden", "tags_golden.npz"))
+
+
+def hist(v, hi):
+    return np.bincount(np.asarray(v, dtype=np.int64), minlength=hi + 1)[1:hi + 1]
+
+
+@pytest.mark.parametrize("name", list(MESHTAG_DATA))
+@pytest.mark.parametrize("deg", [1, 2, 3])
+@pytest.mark.parametrize("box", [True, False])
+@pytest.mark.parametrize("sl", [False, True])
+def test_hip_vs_reference_goldens(P, name, deg, box, sl):
+    """tests/test_compute_meshtags.py:239-243 on the HIP path (histograms: SURVEY 4.3)."""
+    mesh_name, f = MESHTAG_DATA[name]
+    m, topo, x = get_mesh(P, mesh_name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hc, hf = P.compute_tags_measures(m, f, deg, box_mode=box, single_layer_cut=sl)[:2]
+    for disc in (False, True):
+        mid = "_" + ("discretize_" if disc else "") + ("" if box else "submesh_") + \
+            ("single_layer_" if sl else "")
+        gc = GOLD[f"{name}_{deg}{mid}cells_tags:v"]
+        gf = GOLD[f"{name}_{deg}{mid}facets_tags:v"]
+        ok = np.array_equal(hist(hc.values, 3), hist(gc, 3)) and \
+            np.array_equal(hist(hf.values, 6), hist(gf, 6))
+        if name in (FP_FRAGILE_DISCRETIZED if disc else FP_FRAGILE):
+            continue  # decided by FFCx/basix round-off [3P]; reported by the oracle test
+        assert ok, (name, deg, box, sl, disc)
+        assert np.array_equal(hc.indices, GOLD[f"{name}_{deg}{mid}cells_tags:i"])
+        assert np.array_equal(hf.indices, GOLD[f"{name}_{deg}{mid}facets_tags:i"])
+
+
+KAT = json.load(open(os.path.join(HERE, "golden", "one_sided_kat.json")))
+
+
+@pytest.mark.parametrize("name", list(ONE_SIDED_DATA))
+@pytest.mark.parametrize("deg", [1, 2, 3])
+def test_one_sided_integrals_hip(P, name, deg):
+    """tests/test_one_sided_integral.py:135-168 with the HIP integration entities."""
+    mesh_name, f, integrand = ONE_SIDED_DATA[name]
+    m, topo, x = get_mesh(P, mesh_name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _, _, _, meas, _ = P.compute_tags_measures(m, f, deg, box_mode=True)
+    v100 = T.one_sided_integral_2d(topo, x, meas(100), integrand)
+    v101 = T.one_sided_integral_2d(topo, x, meas(101), integrand)
+    assert np.isclose(v100, KAT[name]["values"][0], atol=1.0e-20)
+    assert np.isclose(v101, KAT[name]["values"][1], atol=1.0e-20)
+
+
+# ----------------------------------------------------------------------------------------------
+def facet_keys(cells, c2f, nf, fv):
+    keys = np.zeros((nf, fv.shape[1]), dtype=np.int64)
+    for lf in range(fv.shape[0]):
+        keys[c2f[:, lf]] = np.sort(cells[:, fv[lf]], axis=1)
+    return keys
+
+
+@pytest.mark.parametrize("d,n", [(2, (7, 5)), (3, (4, 3, 5))])
+def test_device_box_generator(P, d, n):
+    from oracle.points import FACET_VERTS
+    lo, hi = [-1.5, -1.0, -0.5][:d], [1.5, 2.0, 1.0][:d]
+    m = P.create_box(lo, hi, n)
+    xo, co = meshgen.create_box(lo, hi, n)
+    assert np.array_equal(m.x, xo)
+    assert np.array_equal(m.cells, co)
+    ctype = "triangle" if d == 2 else "tetrahedron"
+    topo = Topology(ctype, co, xo.shape[0])
+    assert m.nf == topo.nf and m.nbf == topo.boundary_facets.size
+    # numbering-free comparison through the facets' sorted vertex tuples
+    fv = FACET_VERTS[ctype]
+    hk = facet_keys(m.cells.astype(np.int64), m.c2f, m.nf, fv)
+    assert np.unique(hk, axis=0).shape[0] == m.nf
+    okm = topo.facet_key_map()
+    to_oracle = np.array([okm[tuple(k)] for k in hk])
+    assert np.array_equal(to_oracle[m.c2f], topo.c2f)
+    assert np.array_equal(m.f2c, topo.f2c[to_oracle])
+    bf = m.boundary_facets
+    assert np.array_equal(np.sort(to_oracle[m.c2f[bf[:, 0], bf[:, 1]]]), topo.boundary_facets)
+
+
+def test_box_slab_coordinates_are_bit_identical(P):
+    full = P.create_box([-1.5] * 3, [1.5] * 3, [6, 5, 8])
+    slab = P.create_box([-1.5] * 3, [1.5] * 3, [6, 5, 3], offset=[0, 0, 2], n_global=[6, 5, 8])
+    xf = full.x.reshape(9, 6, 7, 3)
+    assert np.array_equal(slab.x.reshape(4, 6, 7, 3), xf[2:6])
+
+
+@pytest.mark.parametrize("d,n,deg", [(2, 24, 1), (2, 16, 3), (3, 10, 1), (3, 6, 2), (3, 5, 3)])
+@pytest.mark.parametrize("mode", ["nodal", "quadric"])
+def test_box_tags_vs_oracle(P, d, n, deg, mode):
+    from oracle.points import FACET_VERTS
+    from phifem_amd.mesh_scripts import NodalFunction, Quadric
+    lo, hi = [-1.5] * d, [1.5] * d
+    m = P.create_box(lo, hi, [n] * d)
+    x = m.x
+    ctype = "triangle" if d == 2 else "tetrahedron"
+    topo = Topology(ctype, m.cells.astype(np.int64), x.shape[0])
+    # run the oracle on the library's own facet numbering
+    topo.c2f = m.c2f.astype(np.int64)
+    topo.f2c = m.f2c.astype(np.int64)
+    topo.boundary_facets = np.flatnonzero(topo.f2c[:, 1] < 0)
+    centre = [0.1, -0.2, 0.05][:d]
+
+    def f(xx):
+        acc = (1.0 * xx[0] - centre[0]) ** 2 + (1.0 * xx[1] - centre[1]) ** 2
+        if d == 3:
+            acc = acc + (1.0 * xx[2] - centre[2]) ** 2
+        return acc + (-1.0)
+
+    if mode == "nodal":
+        nod = f(x.T)
+        lh, lo_ = NodalFunction(nod), T.NodalP1(nod)
+    else:
+        lh, lo_ = Quadric(centre, [1.0] * d, -1.0), f
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for sl in (False, True):
+            oc, of, _, om, _, _ = T.compute_tags_measures(ctype, x, topo, lo_, deg, box_mode=True,
+                                                          single_layer_cut=sl)
+            hc, hf, _, hm, _ = P.compute_tags_measures(m, lh, deg, box_mode=True,
+                                                       single_layer_cut=sl)
+            assert np.array_equal(hc.values, oc.values)
+            assert np.array_equal(hf.values, of.values)
+            assert np.array_equal(hm(100), om(100)) and np.array_equal(hm(101), om(101))
+            assert set(np.unique(hc.values)) == {1, 2, 3}
+
+
+def test_overwrite_and_errors(P):
+    from phifem_amd import MeshTags
+    mesh_name, f = MESHTAG_DATA["circle_in_square"]
+    m, topo, x = get_mesh(P, mesh_name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ow = {"cells": MeshTags(2, [3, 10], [7, 9]), "facets": MeshTags(1, [0, 5], [11, 12])}
+        hc, hf = P.compute_tags_measures(m, f, 1, box_mode=True, overwrite_tags=ow)[:2]
+        assert list(hc.values[[3, 10]]) == [7, 9] and list(hf.values[[0, 5]]) == [11, 12]
+        # mesh_scripts.py:608-614
+        with pytest.raises(ValueError, match="Cannot overwrite cells tags"):
+            P.compute_tags_measures(m, f, 1, box_mode=True,
+                                    overwrite_tags={"cells": MeshTags(2, [0], [2])})
+        with pytest.raises(ValueError, match="Cannot overwrite facets tags"):
+            P.compute_tags_measures(m, f, 1, box_mode=True,
+                                    overwrite_tags={"facets": MeshTags(1, [0], [100])})
+    with pytest.raises(NotImplementedError):  # mesh_scripts.py:326-329
+        P.Mesh.from_arrays("hexahedron", x, topo.cells)
+
+
+def test_zero_denominator_warning(P):
+    # mesh_scripts.py:129-133
+    m, topo, x = get_mesh(P, "coarse_square")
+    from phifem_amd.mesh_scripts import NodalFunction
+    with pytest.warns(RuntimeWarning, match="zero everywhere on a cell"):
+        P.compute_tags_measures(m, NodalFunction(np.zeros(m.nv)), 1, box_mode=True)
+    assert np.all(m.cell_tag_values() == 2)
