@@ -10,6 +10,16 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(or `make -C phifem_amd/csrc`).  phifem_amd has no CPU fallback.")
 
+# One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7).
+# Loading torch FIRST makes the dynamic linker resolve this library's DT_NEEDED libamdhip64.so.7
+# to the copy torch already mapped; the other order maps two runtimes and the second one finds
+# "No HIP GPUs".  A pure C/C++ host links /opt/rocm's runtime directly and skips this.
+if os.environ.get("PHIFEM_NO_TORCH", "") != "1":
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover
+        pass
+
 lib = C.CDLL(LIB_PATH)
 
 HOST, DEVICE = 0, 1
