@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Headline benchmark: assembled+solved DoF/s of the 3-D weak-Dirichlet phi-FEM Poisson path.
+
+One "step" = one full pass of the hot path over one synthetic problem already resident in HBM:
+  tag cells + facets  ->  assemble (element integration, scatter, CSR, SELL)  ->  Krylov solve.
+Workload at N=1: BASELINE.json configs[1] -- spherical level-set, P1 x P1, 256^3 Kuhn box
+(100 663 296 tetrahedra, 16 974 593 vertices) on [-1.5,1.5]^3, manufactured f / u_D,
+gamma = sigma = 1, detection degree 1, single-layer cut, box mode.
+N>1: weak scaling -- every rank owns a 256x256x256 slab of a 256x256x(256 N) box around the
+ellipsoid x^2 + y^2 + (z/N)^2 = 1 (same h, same per-GPU work), see phifem_amd/distributed.py.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=256, help="cubes per axis per GPU")
+    ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--cpu-n", type=int, default=40, help="box size of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, rtol):
+    """The numpy/scipy oracle ("port", 1 core) on a bounded sample of the same workload:
+    the same sphere problem on an n^3 box; tag + assemble + Jacobi-BiCGStab (scipy)."""
+    import numpy as np
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from oracle import assembly as OA, meshgen, tagging as OT
+    from oracle.topology import Topology
+    x, cells = meshgen.create_box([-1.5] * 3, [1.5] * 3, [n] * 3)
+    topo = Topology("tetrahedron", cells, x.shape[0])  # mesh/topology setup: untimed, as on the GPU
+    phi = (x ** 2).sum(axis=1) - 1.0
+    uex = np.prod(np.sin(x), axis=1)
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ct, ft, _, meas, _, _ = OT.compute_tags_measures("tetrahedron", x, topo, OT.NodalP1(phi), 1,
+                                                         box_mode=True, single_layer_cut=True)
+    cv = np.zeros(topo.nc, dtype=np.int64)
+    cv[ct.indices] = ct.values
+    A, b, act = OA.assemble_poisson_wd(topo, x, cv, ft.values, meas(100), phi, 3.0 * uex, uex)
+    idx = np.flatnonzero(act)
+    Aa = A[idx][:, idx].tocsr()
+    d = Aa.diagonal()
+    its = [0]
+    xs, info = spla.bicgstab(Aa, b[idx], M=sp.diags(1.0 / d), rtol=rtol, maxiter=20000,
+                             callback=lambda _: its.__setitem__(0, its[0] + 1))
+    dt = time.perf_counter() - t0
+    return {"value": idx.size / dt, "unit": "DoF/s", "cores": 1, "kind": "port",
+            "sample": f"numpy/scipy oracle, same sphere problem on a {n}^3 box: {idx.size} active "
+                      f"DoFs, tag+assemble+Jacobi-BiCGStab ({its[0]} it, rtol {rtol:g}) in {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import phifem_amd as P
+    from phifem_amd import distributed as D
+
+    n = args.n
+    prob = D.SlabProblem(n_per_rank=n, rank=rank, world=world, device=local_rank, rtol=args.rtol)
+    prob.setup()  # mesh generation + nodal data on the device: inputs resident before timing
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(args.warmup):
+            prob.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = prob.step(profile_spmv=True)
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([res["n_active_owned"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        n_active = int(tot.item())
+    else:
+        n_active = res["n_active_owned"]
+
+    if rank == 0:
+        value = n_active * args.steps / dt
+        spmv_s = res["spmv_avg_s"]
+        achieved = res["spmv_algorithmic_bytes"] / spmv_s / 1e9 if spmv_s > 0 else 0.0
+        out = {
+            "metric": "assembled+solved DoF/s, 3D Poisson phi-FEM (tag+assemble+solve)",
+            "value": value, "unit": "DoF/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"3D weak-Dirichlet Poisson phi-FEM, P1xP1, spherical level-set, "
+                            f"{n}^3 Kuhn box per GPU ({6 * n ** 3} tets), box mode, "
+                            f"single-layer cut, gamma=sigma=1",
+                "active_dofs": n_active, "krylov": "BiCGStab + Jacobi (right)",
+                "rtol": args.rtol, "iterations": res["iterations"], "relres": res["relres"],
+                "stage_ms": {k: 1e3 * v for k, v in res["stage_s"].items()},
+                "parallelism": f"slab{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_spmv_sell (SELL-64 SpMV, f64 values / i32 columns)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": res.get("spmv_traffic_bytes"),
+                "bytes_per_launch": res["spmv_algorithmic_bytes"],
+                "avg_launch_us": 1e6 * spmv_s, "launches_timed": res["spmv_count"],
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.rtol)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,6 +112,18 @@ int phx_mesh_get_array(phx_mesh *m, int which, void *out, int loc);
 /* The HIP stream all work of this mesh is enqueued on (as uintptr). */
 int phx_mesh_stream(phx_mesh *m, uint64_t *stream);
 int phx_mesh_synchronize(phx_mesh *m);
+/* Enqueue all further work of this mesh on a caller stream (e.g. torch's current stream, so that
+ * torch.distributed collectives and the kernels order without extra synchronisation). */
+int phx_mesh_set_stream(phx_mesh *m, uint64_t stream);
+enum phx_option {
+  PHX_OPT_PROFILE_SPMV = 1, /* bracket every SpMV launch of a solve with HIP events            */
+  PHX_OPT_HAS_EXTERIOR = 2  /* -1: `len(exterior_cells) == 0` (mesh_scripts.py:469) is decided
+                               from this mesh's tags; 0/1: imposed by a multi-GPU driver that
+                               reduced it over all slabs                                        */
+};
+int phx_set_option(phx_mesh *m, int option, int64_t value);
+/* Tag counts of the current tagging: cells4[t] for t = 0..3, facets7[t] for t = 0..6. */
+int phx_mesh_tag_histogram(const phx_mesh *m, int64_t *cells4, int64_t *facets7);
 
 /* ------------------------------------------------------------------ tagging ---------- */
 /* _tag_cells (mesh_scripts.py:284-390) incl. _compute_detection_vector (:95-134):
@@ -167,9 +179,25 @@ int phx_system_export(phx_system *s, int64_t *rowptr, int32_t *col, double *val,
 enum phx_method { PHX_BICGSTAB_JACOBI = 0 };
 /* Replaces KSP preonly + LU/MUMPS with null-pivot detection (main.py:162-182): solves the active
  * system, returns x in FULL numbering [2*nv] with inactive DoFs = 0 (what ICNTL(24)=1 yields).
- * stats[4] = {iterations, relative residual ||b-Ax||/||b||, seconds, spmv_count}. */
+ * stats[6] = {iterations, relative residual ||b-Ax||/||b||, seconds, spmv_count,
+ *            average SpMV seconds and launches timed (PHX_OPT_PROFILE_SPMV)}. */
 int phx_solve(phx_system *s, int method, double rtol, int64_t max_iter, double *x, int loc,
               double *stats);
+
+/* --- pieces of the solve for externally driven (multi-GPU) iterations ------------------------
+ * The driver owns the loop, does the halo exchange of p / s before phases 2 / 4 and all-reduces
+ * the 8 reduction scalars (scal[8..15]) after phases 0, 2, 4 and 5.  Vectors are in SOLVER order
+ * (row i of the solver = active row perm[i]).
+ *   work: 8 vectors of n doubles {r, rhat, p, v, s, t, y, b};  scal: 4112 doubles (16 scalars + 8 x 64 dot-product slots of 64 B)
+ *   own : n bytes in solver order, 1 = this rank owns the row (NULL = all)                     */
+int phx_krylov_attach(phx_system *s, double *work, double *scal, const uint8_t *own);
+/* phase 0 begin, 1 begin2, 2 v=Ap, 3 s-update, 4 t=As, 5 x/r-update, 6 p-update + roll */
+int phx_krylov_phase(phx_system *s, int phase);
+int phx_krylov_finish(phx_system *s, double *x, int loc);
+/* reset != 0: arm the SpMV event profile; else collect {average seconds, launches timed}. */
+int phx_krylov_profile(phx_system *s, int reset, double *avg_seconds, int64_t *count);
+/* perm[n] (solver position -> active row), dof_u[nv] / dof_p[nv] (vertex -> active row or -1). */
+int phx_system_get_perm(phx_system *s, int32_t *perm, int32_t *dof_u, int32_t *dof_p, int loc);
 
 /* y = A x on the active system (solver ordering is internal; x, y are in active numbering).
  * For tests and halo-exchange driven (multi-GPU) solvers. */

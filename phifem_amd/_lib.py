@@ -27,6 +27,7 @@ TRIANGLE, QUADRILATERAL, TETRAHEDRON = 0, 1, 2
 CELL_TYPES = {"triangle": TRIANGLE, "quadrilateral": QUADRILATERAL, "tetrahedron": TETRAHEDRON}
 CELL_NAMES = {v: k for k, v in CELL_TYPES.items()}
 PHI_NODAL_P1, PHI_POINTS, PHI_QUADRIC = 0, 1, 2
+OPT_PROFILE_SPMV, OPT_HAS_EXTERIOR = 1, 2
 (ARR_COORDS, ARR_CELLS, ARR_C2F, ARR_F2C, ARR_CELL_TAGS, ARR_FACET_TAGS, ARR_BFACETS) = range(7)
 
 OK, ERR_VALUE, ERR_NOT_IMPLEMENTED, ERR_HIP, ERR_PARTITION, ERR_CAPACITY, ERR_BREAKDOWN = (
@@ -50,6 +51,14 @@ SIGNATURES = {
     "phx_mesh_get_array": ([_vp, _i, _vp, _i], _i),
     "phx_mesh_stream": ([_vp, C.POINTER(C.c_uint64)], _i),
     "phx_mesh_synchronize": ([_vp], _i),
+    "phx_mesh_set_stream": ([_vp, C.c_uint64], _i),
+    "phx_set_option": ([_vp, _i, _i64], _i),
+    "phx_mesh_tag_histogram": ([_vp, _pi64, _pi64], _i),
+    "phx_krylov_attach": ([_vp, _vp, _vp, _vp], _i),
+    "phx_krylov_phase": ([_vp, _i], _i),
+    "phx_krylov_finish": ([_vp, _vp, _i], _i),
+    "phx_krylov_profile": ([_vp, _i, _pd, _pi64], _i),
+    "phx_system_get_perm": ([_vp, _vp, _vp, _vp, _i], _i),
     "phx_tag_cells": ([_vp, _i, _vp, _i, _i, _i, _pi], _i),
     "phx_tag_facets": ([_vp, _i, _vp, _i, _i], _i),
     "phx_overwrite_tags": ([_vp, _i, _i64, _vp, _vp], _i),

@@ -168,113 +168,152 @@ __device__ __forceinline__ double mult4(int i, int j, int k, int l) {
   return r;
 }
 
-// --- cells: main.py:113 (stiffness, dx((1,2))), :115-122 (penalisation, dx(2)), :143-149 (rhs) ---
+// Work lists: the element kernels run over COMPACTED lists (inside cells, cut cells, stabilised
+// facets) with one lane per entry of the element tensor, so a wavefront issues 64 independent
+// slot updates instead of one lane walking a whole element matrix.
+struct SelInside { const int8_t *t; __host__ __device__ bool operator()(const int32_t &c) const { return (t[c] & PHX_TAG_MASK) == 1; } };
+struct SelCut { const int8_t *t; __host__ __device__ bool operator()(const int32_t &c) const { return (t[c] & PHX_TAG_MASK) == 2; } };
+struct SelGhostFacet {
+  const int8_t *ft; const int32_t *f2c;
+  __host__ __device__ bool operator()(const int32_t &f) const {
+    const int t = ft[f];
+    return (t == 2 || t == 3) && f2c[2 * (int64_t)f + 1] >= 0;  // dS: interior facets only
+  }
+};
+
+// --- inside cells, main.py:113 + :143: 16 lanes per cell, lane = (i, j) of the u-u block --------
 template <int D>
-__global__ void __launch_bounds__(256) k_assemble_cells(int64_t nc, AsmArgs A) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= nc) return;
-  const int t = A.ctags[c] & PHX_TAG_MASK;
-  if (t != 1 && t != 2) return;
+__global__ void __launch_bounds__(256) k_assemble_inside(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
+  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  // The four cells of a wavefront come from the four quarters of the list: neighbouring cells
+  // share rows, and same-address atomics inside one wave-instruction serialise.
+  const int64_t quarter = (nlist + 3) >> 2;
+  const int64_t e = (gid >> 6) + ((gid >> 4) & 3) * quarter;
+  if ((gid >> 6) >= quarter || e >= nlist) return;
   constexpr int N = D + 1;
+  const int i = (int)(gid & 15) >> 2, j = (int)(gid & 3);
+  if (i >= N || j >= N) return;
+  const int64_t c = list[e];
   int32_t v[N];
   double X[N][D];
   load_cell<D>(A.cells, A.x, c, v, X);
   Geo<D> G;
   simplex_geometry<D>(X, G);
-  int32_t ru[N];
-  for (int i = 0; i < N; ++i) ru[i] = A.du[v[i]];
+  double k = 0.0;
+  for (int d = 0; d < D; ++d) k += G.g[i][d] * G.g[j][d];
+  const int32_t ri = A.du[v[i]];
+  slot_add(A.slots, ri, A.du[v[j]], k * G.vol);
+  if (j == 0) {
+    constexpr double c2 = D == 3 ? 1.0 / 20.0 : 1.0 / 12.0;
+    double sf = 0.0;
+    for (int q = 0; q < N; ++q) sf += A.f[v[q]];
+    unsafeAtomicAdd(&A.rhs[ri], G.vol * c2 * (sf + A.f[v[i]]));  // int f_h N_i
+  }
+}
+
+// --- cut cells, main.py:113,115-122,143-149: 64 lanes per cell, lane = (a, b) of the mixed
+// (u,p) x (u,p) element tensor, a = i (u_i) or N + i (p_i) ---------------------------------------
+template <int D>
+__global__ void __launch_bounds__(256) k_assemble_cut(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
+  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t e = gid >> 6;
+  if (e >= nlist) return;
+  constexpr int N = D + 1;
+  const int a = (int)(gid & 63) >> 3, b = (int)(gid & 7);
+  if (a >= 2 * N || b >= 2 * N) return;
+  const int64_t c = list[e];
+  int32_t v[N];
+  double X[N][D];
+  load_cell<D>(A.cells, A.x, c, v, X);
+  Geo<D> G;
+  simplex_geometry<D>(X, G);
   constexpr double c2 = D == 3 ? 1.0 / 20.0 : 1.0 / 12.0;    // (1+d_ij) c2  = int N_i N_j / |K|
   constexpr double c3 = D == 3 ? 1.0 / 120.0 : 1.0 / 60.0;   // alpha! c3
   constexpr double c4 = D == 3 ? 1.0 / 840.0 : 1.0 / 360.0;  // alpha! c4
-  double fl[N], sf = 0.0;
-  for (int i = 0; i < N; ++i) { fl[i] = A.f[v[i]]; sf += fl[i]; }
-  double pen_uu = 0.0;
-  if (t == 2) pen_uu = A.gamma * G.vol / (G.h * G.h);
-  for (int i = 0; i < N; ++i) {
-    for (int j = 0; j < N; ++j) {
-      double k = 0.0;
-      for (int d = 0; d < D; ++d) k += G.g[i][d] * G.g[j][d];
-      k *= G.vol;
-      if (t == 2) k += pen_uu * c2 * (i == j ? 2.0 : 1.0);
-      slot_add(A.slots, ru[i], ru[j], k);
-    }
-    // int f_h N_i = |K| c2 (sum_j f_j + f_i)
-    unsafeAtomicAdd(&A.rhs[ru[i]], G.vol * c2 * (sf + fl[i]));
-  }
-  if (t != 2) return;
-  int32_t rp[N];
-  double ph[N], ud[N], sp = 0.0, sud = 0.0;
-  for (int i = 0; i < N; ++i) {
-    rp[i] = A.dp[v[i]];
-    ph[i] = A.phi[v[i]];
-    ud[i] = A.ud[v[i]];
-    sp += ph[i];
-    sud += ud[i];
-  }
+  const int i = a % N, j = b % N;
+  const bool ap = a >= N, bp = b >= N;
+  double ph[N], sp = 0.0;
+  for (int q = 0; q < N; ++q) { ph[q] = A.phi[v[q]]; sp += ph[q]; }
   const double h1 = 1.0 / G.h;
-  const double w3 = -A.gamma * G.vol * h1 * h1 * h1 * c3;
-  const double w4 = A.gamma * G.vol * h1 * h1 * h1 * h1 * c4;
-  for (int i = 0; i < N; ++i) {
-    double bq = 0.0;
-    for (int j = 0; j < N; ++j) {
-      // int N_i N_j phi_h = |K| c3 (1+d_ij)(S + phi_i + phi_j)
-      const double m3 = (i == j ? 2.0 : 1.0) * (sp + ph[i] + ph[j]);
-      slot_add(A.slots, ru[i], rp[j], w3 * m3);
-      slot_add(A.slots, rp[i], ru[j], w3 * m3);
-      double m4 = 0.0;
-      for (int k = 0; k < N; ++k)
-        for (int l = 0; l < N; ++l) m4 += mult4(i, j, k, l) * ph[k] * ph[l];
-      slot_add(A.slots, rp[i], rp[j], w4 * m4);
-      bq += ud[j] * m3;
+  const double gam = A.gamma * G.vol;
+  double val;
+  if (!ap && !bp) {
+    double k = 0.0;
+    for (int d = 0; d < D; ++d) k += G.g[i][d] * G.g[j][d];
+    val = k * G.vol + gam * h1 * h1 * c2 * (i == j ? 2.0 : 1.0);          // :113 + :115-122 (u,v)
+  } else if (ap != bp) {
+    // int N_i N_j phi_h = |K| c3 (1+d_ij)(S + phi_i + phi_j)
+    val = -gam * h1 * h1 * h1 * c3 * (i == j ? 2.0 : 1.0) * (sp + ph[i] + ph[j]);   // (u,q),(p,v)
+  } else {
+    double m4 = 0.0;
+    for (int k = 0; k < N; ++k)
+      for (int l = 0; l < N; ++l) m4 += mult4(i, j, k, l) * ph[k] * ph[l];
+    val = gam * h1 * h1 * h1 * h1 * c4 * m4;                               // (p,q)
+  }
+  const int32_t row = ap ? A.dp[v[i]] : A.du[v[i]];
+  const int32_t col = bp ? A.dp[v[j]] : A.du[v[j]];
+  slot_add(A.slots, row, col, val);
+  if (b == 0) {
+    double ud[N], sud = 0.0;
+    for (int q = 0; q < N; ++q) { ud[q] = A.ud[v[q]]; sud += ud[q]; }
+    double r;
+    if (!ap) {
+      double sf = 0.0;
+      for (int q = 0; q < N; ++q) sf += A.f[v[q]];
+      r = G.vol * c2 * (sf + A.f[v[i]])                                    // :143
+          + gam * h1 * h1 * c2 * (sud + ud[i]);                            // :147 (v part)
+    } else {
+      double bq = 0.0;
+      for (int q = 0; q < N; ++q) bq += ud[q] * (i == q ? 2.0 : 1.0) * (sp + ph[i] + ph[q]);
+      r = -gam * h1 * h1 * h1 * c3 * bq;                                   // :147 (q part)
     }
-    unsafeAtomicAdd(&A.rhs[ru[i]], pen_uu * c2 * (sud + ud[i]));   // main.py:147 (v part)
-    unsafeAtomicAdd(&A.rhs[rp[i]], w3 * bq);                       // main.py:147 (q part)
+    unsafeAtomicAdd(&A.rhs[row], r);
   }
   // main.py:123-128,150: div(grad(.)) of a P1 function is identically zero.
 }
 
 // --- one-sided boundary term, main.py:114:  -int_F (grad u . n) v  over (cell, local facet) ---
 // With n = -g_lf/|g_lf|, |F| = D |K| |g_lf| and int_F N_i = |F|/D (i on F) the entry is
-// |K| (g_j . g_lf) for every row i != lf and every column j.
+// |K| (g_j . g_lf) for every row i != lf and every column j.  16 lanes per entity.
 template <int D>
 __global__ void k_assemble_ds(int64_t nent, const int64_t *__restrict__ ent_packed,
                               const int32_t *__restrict__ ent_pairs, AsmArgs A) {
-  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t e = gid >> 4;
   if (e >= nent) return;
+  constexpr int N = D + 1;
+  const int i = (int)(gid & 15) >> 2, j = (int)(gid & 3);
+  if (i >= N || j >= N) return;
   int64_t c;
   int lf;
   if (ent_packed) { c = ent_packed[2 * e + 1] >> 8; lf = (int)(ent_packed[2 * e + 1] & 0xff); }
   else { c = ent_pairs[2 * e]; lf = ent_pairs[2 * e + 1]; }
-  constexpr int N = D + 1;
+  if (i == lf) return;
   int32_t v[N];
   double X[N][D];
   load_cell<D>(A.cells, A.x, c, v, X);
   Geo<D> G;
   simplex_geometry<D>(X, G);
-  for (int j = 0; j < N; ++j) {
-    double k = 0.0;
-    for (int d = 0; d < D; ++d) k += G.g[j][d] * G.g[lf][d];
-    k *= G.vol;
-    for (int i = 0; i < N; ++i)
-      if (i != lf) slot_add(A.slots, A.du[v[i]], A.du[v[j]], k);
-  }
+  double k = 0.0;
+  for (int d = 0; d < D; ++d) k += G.g[j][d] * G.g[lf][d];
+  slot_add(A.slots, A.du[v[i]], A.du[v[j]], k * G.vol);
 }
 
 // --- ghost penalty, main.py:129-134:  sigma avg(h) int_F [grad u . n][grad v . n] on dS((2,3)) ---
+// 64 lanes per facet, lane = (a, b) over the 2(D+1) vertices of the two cells.
 template <int D>
-__global__ void k_assemble_facets(int64_t nf, AsmArgs A) {
-  const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (f >= nf) return;
-  const int ft = A.ftags[f];
-  if (ft != 2 && ft != 3) return;
-  const int32_t cp = A.f2c[2 * f], cm = A.f2c[2 * f + 1];
-  if (cm < 0) return;  // dS integrates interior facets only
+__global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
+  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t e = gid >> 6;
+  if (e >= nlist) return;
   constexpr int N = D + 1;
-  int32_t dofs[2 * N];
-  double J[2 * N];
-  double hsum = 0.0, area = 0.0;
+  const int a = (int)(gid & 63) >> 3, b = (int)(gid & 7);
+  if (a >= 2 * N || b >= 2 * N) return;
+  const int64_t f = list[e];
+  double Ja = 0.0, Jb = 0.0, hsum = 0.0, area = 0.0;
+  int32_t da = -1, db = -1;
   for (int side = 0; side < 2; ++side) {
-    const int64_t c = side == 0 ? cp : cm;
+    const int64_t c = A.f2c[2 * f + side];
     int32_t v[N];
     double X[N][D];
     load_cell<D>(A.cells, A.x, c, v, X);
@@ -288,16 +327,39 @@ __global__ void k_assemble_facets(int64_t nf, AsmArgs A) {
     gn = sqrt(gn);
     if (side == 0) area = D * G.vol * gn;
     hsum += G.h;
-    for (int j = 0; j < N; ++j) {
+    // grad N_j . n with n outward from this side's cell
+    if (a / N == side) {
       double s = 0.0;
-      for (int d = 0; d < D; ++d) s += G.g[j][d] * G.g[lf][d];
-      J[side * N + j] = -s / gn;  // grad N_j . n, n outward from this side's cell
-      dofs[side * N + j] = A.du[v[j]];
+      for (int d = 0; d < D; ++d) s += G.g[a % N][d] * G.g[lf][d];
+      Ja = -s / gn;
+      da = A.du[v[a % N]];
+    }
+    if (b / N == side) {
+      double s = 0.0;
+      for (int d = 0; d < D; ++d) s += G.g[b % N][d] * G.g[lf][d];
+      Jb = -s / gn;
+      db = A.du[v[b % N]];
     }
   }
-  const double w = A.sigma * 0.5 * hsum * area;
-  for (int a = 0; a < 2 * N; ++a)
-    for (int b = 0; b < 2 * N; ++b) slot_add(A.slots, dofs[a], dofs[b], w * J[a] * J[b]);
+  slot_add(A.slots, da, db, A.sigma * 0.5 * hsum * area * Ja * Jb);
+}
+
+template <typename Pred>
+static int build_list(phx_mesh *m, int64_t n, Pred pred, int32_t **list, int64_t *count) {
+  int64_t *dcount = nullptr;
+  PHX_HIP(hipMalloc(list, sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
+  PHX_HIP(hipMalloc(&dcount, sizeof(int64_t)));
+  hipcub::CountingInputIterator<int32_t> it(0);
+  size_t bytes = 0;
+  PHX_HIP(hipcub::DeviceSelect::If(nullptr, bytes, it, *list, dcount, (int)n, pred, m->stream));
+  void *tmp = nullptr;
+  PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(hipcub::DeviceSelect::If(tmp, bytes, it, *list, dcount, (int)n, pred, m->stream));
+  PHX_HIP(hipMemcpyAsync(count, dcount, sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(tmp));
+  PHX_HIP(hipFree(dcount));
+  return PHX_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -383,6 +445,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
                   s->sell_val_raw, s->perm, s->iperm, s->work, s->scal};
   for (void *p : ptrs) (void)hipFree(p);
   if (s->scal_h) (void)hipHostFree(s->scal_h);
+  for (auto &e : s->prof_ev) (void)hipEventDestroy(e);
   delete s;
   return PHX_OK;
 }
@@ -437,35 +500,49 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   A.c2f = m->c2f; A.f2c = m->f2c; A.du = s->dof_of_vertex_u; A.dp = s->dof_of_vertex_p;
   A.phi = dphi; A.f = df; A.ud = dud; A.gamma = pen_coef; A.sigma = stab_coef;
   A.rhs = s->rhs; A.slots = sl;
-  // ---- element kernels
-  if (D == 2) k_assemble_cells<2><<<gcells, block, 0, m->stream>>>(m->nc, A);
-  else k_assemble_cells<3><<<gcells, block, 0, m->stream>>>(m->nc, A);
+  // ---- element kernels over compacted work lists
+  int32_t *l_in = nullptr, *l_cut = nullptr, *l_fac = nullptr;
+  int64_t n_in = 0, n_cut = 0, n_fac = 0;
+  PHX_CHECK(build_list(m, m->nc, SelInside{m->cell_tags}, &l_in, &n_in));
+  PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut));
+  PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac));
+  if (n_in > 0) {
+    const dim3 g((unsigned)phx_div_up(((n_in + 3) / 4) * 64, 256));
+    if (D == 2) k_assemble_inside<2><<<g, block, 0, m->stream>>>(n_in, l_in, A);
+    else k_assemble_inside<3><<<g, block, 0, m->stream>>>(n_in, l_in, A);
+  }
+  if (n_cut > 0) {
+    const dim3 g((unsigned)phx_div_up(n_cut * 64, 256));
+    if (D == 2) k_assemble_cut<2><<<g, block, 0, m->stream>>>(n_cut, l_cut, A);
+    else k_assemble_cut<3><<<g, block, 0, m->stream>>>(n_cut, l_cut, A);
+  }
   PHX_HIP(hipGetLastError());
   if (m->is_submesh) {
     // main.py:74: ds = every exterior facet of the sub-mesh
     if (m->nbf > 0) {
-      const dim3 g((unsigned)phx_div_up(m->nbf, 256));
+      const dim3 g((unsigned)phx_div_up(m->nbf * 16, 256));
       if (D == 2) k_assemble_ds<2><<<g, block, 0, m->stream>>>(m->nbf, nullptr, m->bfacets, A);
       else k_assemble_ds<3><<<g, block, 0, m->stream>>>(m->nbf, nullptr, m->bfacets, A);
     }
   } else {
     PHX_CHECK(phx_collect_entities(m));  // main.py:65: ds = ds_bdy(100)
     if (m->ent_count[0] > 0) {
-      const dim3 g((unsigned)phx_div_up(m->ent_count[0], 256));
+      const dim3 g((unsigned)phx_div_up(m->ent_count[0] * 16, 256));
       if (D == 2) k_assemble_ds<2><<<g, block, 0, m->stream>>>(m->ent_count[0], m->ent_buf[0], nullptr, A);
       else k_assemble_ds<3><<<g, block, 0, m->stream>>>(m->ent_count[0], m->ent_buf[0], nullptr, A);
     }
   }
   PHX_HIP(hipGetLastError());
-  {
-    const dim3 g((unsigned)phx_div_up(m->nf, 256));
-    if (D == 2) k_assemble_facets<2><<<g, block, 0, m->stream>>>(m->nf, A);
-    else k_assemble_facets<3><<<g, block, 0, m->stream>>>(m->nf, A);
+  if (n_fac > 0) {
+    const dim3 g((unsigned)phx_div_up(n_fac * 64, 256));
+    if (D == 2) k_assemble_facets<2><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
+    else k_assemble_facets<3><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
   }
   PHX_HIP(hipGetLastError());
   int overflow = 0;
   PHX_HIP(hipMemcpyAsync(&overflow, sl.overflow, sizeof(int), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(l_in)); PHX_HIP(hipFree(l_cut)); PHX_HIP(hipFree(l_fac));
   if (overflow) {
     PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
     phx_system_destroy(s);
@@ -535,6 +612,16 @@ extern "C" int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab
 extern "C" int phx_system_info(const phx_system *s, int64_t *info) {
   info[0] = s->n; info[1] = s->nu; info[2] = s->nnz; info[3] = s->nfull;
   info[4] = s->sell_nnz; info[5] = s->slot_cap; info[6] = s->sell_true_nnz; info[7] = s->nslices;
+  return PHX_OK;
+}
+
+extern "C" int phx_system_get_perm(phx_system *s, int32_t *perm, int32_t *dof_u, int32_t *dof_p,
+                                   int loc) {
+  PHX_HIP(hipSetDevice(s->mesh->device));
+  const hipMemcpyKind k = loc == PHX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (perm) PHX_HIP(hipMemcpy(perm, s->perm, sizeof(int32_t) * (size_t)s->n, k));
+  if (dof_u) PHX_HIP(hipMemcpy(dof_u, s->dof_of_vertex_u, sizeof(int32_t) * (size_t)s->mesh->nv, k));
+  if (dof_p) PHX_HIP(hipMemcpy(dof_p, s->dof_of_vertex_p, sizeof(int32_t) * (size_t)s->mesh->nv, k));
   return PHX_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/phifem_hip.h"
 
@@ -74,6 +75,9 @@ struct phx_mesh {
   bool is_submesh = false;
   int32_t *c_map_h = nullptr, *v_map_h = nullptr;
   double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool own_stream = true;
+  int profile_spmv = 0;
+  int has_exterior_override = -1;  // -1: decide from the local tags; 0/1: imposed (multi-GPU)
 };
 
 struct phx_system {
@@ -101,6 +105,11 @@ struct phx_system {
   double *work = nullptr;        // 8 vectors of n
   double *scal = nullptr;        // device scalars
   double *scal_h = nullptr;      // pinned
+  // externally attached Krylov buffers (multi-GPU driver) and ownership mask (solver order)
+  double *kr_work = nullptr, *kr_scal = nullptr;
+  const uint8_t *own = nullptr;
+  std::vector<hipEvent_t> prof_ev;
+  int prof_used = 0;
 };
 
 // helpers implemented in phx_mesh.hip

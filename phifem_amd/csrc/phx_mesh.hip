@@ -537,7 +537,7 @@ extern "C" int phx_mesh_destroy(phx_mesh *m) {
   free(m->c_map_h); free(m->v_map_h);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
-  if (m->stream) (void)hipStreamDestroy(m->stream);
+  if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
   delete m;
   return PHX_OK;
 }
@@ -550,6 +550,29 @@ extern "C" int phx_mesh_counts(const phx_mesh *m, int64_t *counts) {
 
 extern "C" int phx_mesh_stream(phx_mesh *m, uint64_t *stream) {
   *stream = (uint64_t)(uintptr_t)m->stream;
+  return PHX_OK;
+}
+
+extern "C" int phx_mesh_set_stream(phx_mesh *m, uint64_t stream) {
+  PHX_HIP(hipSetDevice(m->device));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  if (m->own_stream) PHX_HIP(hipStreamDestroy(m->stream));
+  m->stream = (hipStream_t)(uintptr_t)stream;
+  m->own_stream = false;
+  return PHX_OK;
+}
+
+extern "C" int phx_set_option(phx_mesh *m, int option, int64_t value) {
+  switch (option) {
+    case PHX_OPT_PROFILE_SPMV: m->profile_spmv = value != 0; return PHX_OK;
+    case PHX_OPT_HAS_EXTERIOR: m->has_exterior_override = (int)value; return PHX_OK;
+    default: phx_set_error("unknown option %d", option); return PHX_ERR_VALUE;
+  }
+}
+
+extern "C" int phx_mesh_tag_histogram(const phx_mesh *m, int64_t *cells4, int64_t *facets7) {
+  if (cells4) for (int i = 0; i < 4; ++i) cells4[i] = m->tag_hist[i];
+  if (facets7) for (int i = 0; i < 7; ++i) facets7[i] = m->ftag_hist[i];
   return PHX_OK;
 }
 

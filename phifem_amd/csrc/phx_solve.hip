@@ -6,11 +6,12 @@
 // SpMV layout: rows are grouped in slices of 64 (one wavefront per slice, one lane per row);
 // inside a slice entries are stored column-major, so lane r reads val[base + k*64 + r]:
 // every wave-instruction is one contiguous 512 B (f64) / 256 B (i32) segment.  Rows are sorted
-// by length inside windows of 4096 rows (keeps x-gather locality, removes most padding), and the
-// whole system is renumbered into that order so y is written coalesced.  Explicitly stored zeros
+// by length with a STABLE sort (removes the padding, keeps equal-length rows in natural order), and
+// the whole system is renumbered into that order so y is written coalesced.  Explicitly stored zeros
 // of the assembled CSR are not carried into the SELL copy.
 #include <hipcub/hipcub.hpp>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -19,7 +20,18 @@
 #include "phx_common.h"
 
 #define SELL_C 64
-#define SELL_WINDOW 4096
+// Rows per length-sorting window.  Measured on the 256^3 system (2.9 M rows): no sort 180 us,
+// 512 -> 113 us, 4096 -> 184 us, 32768 -> 122 us, one global window -> 81 us per SpMV; the stable
+// global sort keeps the 7-point interior rows in natural order and only moves the few long
+// (cut-region) rows, so the x-gather locality survives.  PHX_SELL_WINDOW overrides (tuning aid).
+static int64_t g_sell_window = (int64_t)1 << 40;
+// Dot products: every block adds its partial sum to one of NSLOT accumulators (one 64-byte line
+// each, so the memory-side atomics of different blocks do not queue on one address); a one-wave
+// kernel folds the slots into the scalar the next phase reads.
+#define NSLOT 64
+#define SLOT_STRIDE 8
+#define P_OFF 16
+#define PHX_SCAL_DOUBLES (P_OFF + 8 * NSLOT * SLOT_STRIDE)
 
 // ---------------------------------------------------------------------------------------------
 // SELL construction
@@ -27,7 +39,7 @@
 __global__ void k_row_lengths(int64_t n, const int64_t *__restrict__ rowptr,
                               const int32_t *__restrict__ col, const double *__restrict__ val,
                               uint32_t *__restrict__ keys, int32_t *__restrict__ rows,
-                              unsigned long long *__restrict__ total) {
+                              unsigned long long *__restrict__ total, int64_t window) {
   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (r >= n) return;
   int len = 0;
@@ -36,7 +48,7 @@ __global__ void k_row_lengths(int64_t n, const int64_t *__restrict__ rowptr,
   if (len > 255) len = 255;
   atomicAdd(total, (unsigned long long)len);
   // ascending key = (window, 255-len): descending length inside each window
-  keys[r] = ((uint32_t)(r / SELL_WINDOW) << 8) | (uint32_t)(255 - len);
+  keys[r] = ((uint32_t)(r / window) << 8) | (uint32_t)(255 - len);
   rows[r] = (int32_t)r;
 }
 
@@ -95,7 +107,8 @@ __global__ void k_sell_fill(int64_t n, const int64_t *__restrict__ rowptr,
 int phx_system_build_sell(phx_system *s) {
   phx_mesh *m = s->mesh;
   const int64_t n = s->n;
-  PHX_REQUIRE(n / SELL_WINDOW < (1 << 23), PHX_ERR_VALUE, "system too large for the SELL sort key");
+  if (const char *e = getenv("PHX_SELL_WINDOW")) g_sell_window = atoll(e) > 0 ? atoll(e) : g_sell_window;
+  PHX_REQUIRE(n / g_sell_window < (1 << 23), PHX_ERR_VALUE, "system too large for the SELL sort key");
   uint32_t *keys = nullptr, *keys2 = nullptr;
   int32_t *rows = nullptr;
   PHX_HIP(hipMalloc(&keys, sizeof(uint32_t) * (size_t)n));
@@ -107,7 +120,7 @@ int phx_system_build_sell(phx_system *s) {
   unsigned long long *dtotal = nullptr;
   PHX_HIP(hipMalloc(&dtotal, sizeof(unsigned long long)));
   PHX_HIP(hipMemsetAsync(dtotal, 0, sizeof(unsigned long long), m->stream));
-  k_row_lengths<<<grid, block, 0, m->stream>>>(n, s->rowptr, s->col, s->val, keys, rows, dtotal);
+  k_row_lengths<<<grid, block, 0, m->stream>>>(n, s->rowptr, s->col, s->val, keys, rows, dtotal, g_sell_window);
   unsigned long long htotal = 0;
   PHX_HIP(hipMemcpyAsync(&htotal, dtotal, sizeof(htotal), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
@@ -147,7 +160,7 @@ int phx_system_build_sell(phx_system *s) {
   PHX_HIP(hipFree(widths));
   // solver workspace: 9 vectors + scalars
   PHX_HIP(hipMalloc(&s->work, sizeof(double) * (size_t)n * 9));
-  PHX_HIP(hipMalloc(&s->scal, sizeof(double) * 16));
+  PHX_HIP(hipMalloc(&s->scal, sizeof(double) * PHX_SCAL_DOUBLES));
   PHX_HIP(hipHostMalloc(&s->scal_h, sizeof(double) * 16));
   return PHX_OK;
 }
@@ -166,8 +179,8 @@ __global__ void __launch_bounds__(256)
 k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
             const int32_t *__restrict__ scol, const double *__restrict__ sval,
             const double *__restrict__ x, double *__restrict__ y,
-            const double *__restrict__ d0, double *__restrict__ out0,
-            double *__restrict__ out1) {
+            const uint8_t *__restrict__ own, const double *__restrict__ d0,
+            double *__restrict__ out0, double *__restrict__ out1) {
   const int lane = threadIdx.x & 63;
   const int64_t s = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   double acc = 0.0;
@@ -190,7 +203,12 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
     }
     for (; k < width; ++k) acc += v[k * SELL_C] * x[c[k * SELL_C]];
     row = s * SELL_C + lane;
-    if (row < n) y[row] = acc; else row = -1;
+    if (row < n) {
+      if (own && !own[row]) acc = 0.0;  // ghost rows stay zero; the halo exchange refreshes them
+      y[row] = acc;
+    } else {
+      row = -1;
+    }
   }
   if (DOTS > 0) {
     // DOTS == 1: out0 += (y, d0);  DOTS == 2: also out1 += (y, y)
@@ -206,86 +224,128 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
     if (lane == 0) { red[0][w] = p0; red[1][w] = p1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      unsafeAtomicAdd(out0, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-      if (DOTS > 1) unsafeAtomicAdd(out1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+      const int slot = (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE;
+      unsafeAtomicAdd(out0 + slot, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+      if (DOTS > 1) unsafeAtomicAdd(out1 + slot, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// BiCGStab vector kernels.  Scalars live on the device (S[...]); every kernel derives alpha /
-// omega / beta from them, so an iteration is a fixed launch sequence without host round trips.
+// BiCGStab.  All scalars live on the device: S[0..7] is solver state, R = S+8 holds the dot
+// products of the running iteration (local partial sums; a multi-GPU driver all-reduces R between
+// phases).  Every kernel derives alpha / omega / beta from them, so an iteration is a fixed
+// launch sequence with no host round trip.  `own` (nullable) masks the rows this rank owns:
+// ghost rows are kept at zero and refreshed by the halo exchange of the driver.
 // ---------------------------------------------------------------------------------------------
-enum { S_RHO0 = 0, S_RHO1 = 1, S_RV = 2, S_TS = 3, S_TT = 4, S_RR = 5, S_SS = 6, S_ALPHA = 7,
-       S_OMEGA = 8, S_BB = 9, S_FLAG = 10 };
+enum { S_RHO = 0, S_ALPHA = 1, S_OMEGA = 2, S_BB = 3, S_RR = 4 };
+enum { R_RV = 0, R_TS = 1, R_TT = 2, R_SS = 3, R_RHO = 4, R_RR = 5 };
+#define R_OFF 8
 
 __device__ __forceinline__ void block_atomic_sum(double v, double *out) {
   __shared__ double red[4];
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0)
+    unsafeAtomicAdd(out + (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE, red[0] + red[1] + red[2] + red[3]);
   __syncthreads();
 }
 
-// s = r - alpha v, alpha = rho/(rhat,v); accumulates (s,s); zeroes the slots of the next products
-__global__ void __launch_bounds__(256)
-k_update_s(int64_t n, int it, const double *__restrict__ r, const double *__restrict__ v,
-           double *__restrict__ sv, double *__restrict__ S) {
-  const double alpha = S[it & 1] / S[S_RV];
-  double acc = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double t = r[i] - alpha * v[i];
-    sv[i] = t;
-    acc += t * t;
+__host__ __device__ __forceinline__ double *slot_base(double *S, int q) { return S + P_OFF + q * NSLOT * SLOT_STRIDE; }
+
+// fold the slots of quantities q0..q0+nq-1 into R and clear them (one wave)
+__global__ void k_reduce_slots(double *S, int q0, int nq) {
+  const int lane = threadIdx.x;
+  for (int q = q0; q < q0 + nq; ++q) {
+    double *p = slot_base(S, q) + lane * SLOT_STRIDE;
+    double v = *p;
+    *p = 0.0;
+    v = wave_sum(v);
+    if (lane == 0) S[R_OFF + q] = v;
   }
-  block_atomic_sum(acc, &S[S_SS]);
+}
+
+#define GRID_STRIDE(i, n) \
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+// r = rhat = p = own ? b : 0; y = 0; R_RHO += (b,b)
+__global__ void __launch_bounds__(256)
+k_kr_begin(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ rhs,
+           const uint8_t *__restrict__ own, double *__restrict__ b, double *__restrict__ r,
+           double *__restrict__ rhat, double *__restrict__ p, double *__restrict__ y,
+           double *__restrict__ S) {
+  double acc = 0.0;
+  GRID_STRIDE(i, n) {
+    const bool mine = !own || own[i];
+    const double bi = mine ? rhs[perm[i]] : 0.0;
+    b[i] = bi; r[i] = bi; rhat[i] = bi; p[i] = bi; y[i] = 0.0;
+    acc += bi * bi;
+  }
+  block_atomic_sum(acc, slot_base(S, R_RHO));
+}
+
+// after the (optional) all-reduce of R: rho = bb = R_RHO; clear R
+__global__ void k_kr_begin2(double *S) {
+  S[S_RHO] = S[R_OFF + R_RHO];
+  S[S_BB] = S[R_OFF + R_RHO];
+  S[S_RR] = S[R_OFF + R_RHO];
+}
+
+// s = r - alpha v, alpha = rho/(rhat,v)
+__global__ void __launch_bounds__(256)
+k_update_s(int64_t n, const uint8_t *__restrict__ own, const double *__restrict__ r,
+           const double *__restrict__ v, double *__restrict__ sv, double *__restrict__ S) {
+  const double alpha = S[S_RHO] / S[R_OFF + R_RV];
+  GRID_STRIDE(i, n) {
+    const bool mine = !own || own[i];
+    sv[i] = mine ? r[i] - alpha * v[i] : 0.0;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) S[S_ALPHA] = alpha;
 }
 
 // x += alpha p + omega s;  r = s - omega t;  accumulates rho_next = (rhat,r) and (r,r)
 __global__ void __launch_bounds__(256)
-k_update_xr(int64_t n, int it, const double *__restrict__ p, const double *__restrict__ sv,
-            const double *__restrict__ t, const double *__restrict__ rhat, double *__restrict__ x,
-            double *__restrict__ r, double *__restrict__ S) {
+k_update_xr(int64_t n, const uint8_t *__restrict__ own, const double *__restrict__ p,
+            const double *__restrict__ sv, const double *__restrict__ t,
+            const double *__restrict__ rhat, double *__restrict__ x, double *__restrict__ r,
+            double *__restrict__ S) {
   const double alpha = S[S_ALPHA];
-  const double omega = S[S_TS] / S[S_TT];
+  const double omega = S[R_OFF + R_TS] / S[R_OFF + R_TT];
   double a0 = 0.0, a1 = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  GRID_STRIDE(i, n) {
+    const bool mine = !own || own[i];
     const double si = sv[i];
-    x[i] += alpha * p[i] + omega * si;
-    const double ri = si - omega * t[i];
+    double ri = 0.0;
+    if (mine) {
+      x[i] += alpha * p[i] + omega * si;
+      ri = si - omega * t[i];
+    }
     r[i] = ri;
     a0 += rhat[i] * ri;
     a1 += ri * ri;
   }
-  block_atomic_sum(a0, &S[(it + 1) & 1]);
-  block_atomic_sum(a1, &S[S_RR]);
+  block_atomic_sum(a0, slot_base(S, R_RHO));
+  block_atomic_sum(a1, slot_base(S, R_RR));
   if (blockIdx.x == 0 && threadIdx.x == 0) S[S_OMEGA] = omega;
 }
 
-// p = r + beta (p - omega v), beta = (rho_next/rho)(alpha/omega); clears the per-iteration sums
+// p = r + beta (p - omega v), beta = (rho_next/rho)(alpha/omega)
 __global__ void __launch_bounds__(256)
-k_update_p(int64_t n, int it, const double *__restrict__ r, const double *__restrict__ v,
-           double *__restrict__ p, double *__restrict__ S, double *__restrict__ Snext) {
-  const double beta = (S[(it + 1) & 1] / S[it & 1]) * (S[S_ALPHA] / S[S_OMEGA]);
+k_update_p(int64_t n, const uint8_t *__restrict__ own, const double *__restrict__ r,
+           const double *__restrict__ v, double *__restrict__ p, const double *__restrict__ S) {
+  const double beta = (S[R_OFF + R_RHO] / S[S_RHO]) * (S[S_ALPHA] / S[S_OMEGA]);
   const double omega = S[S_OMEGA];
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    p[i] = r[i] + beta * (p[i] - omega * v[i]);
+  GRID_STRIDE(i, n) {
+    const bool mine = !own || own[i];
+    p[i] = mine ? r[i] + beta * (p[i] - omega * v[i]) : 0.0;
+  }
 }
 
-__global__ void k_clear_iter_scalars(int it, double *S) {
-  // the sums the coming iteration accumulates into (rho of iteration it+1 lives in S[(it+1)&1])
-  S[S_RV] = 0.0; S[S_TS] = 0.0; S[S_TT] = 0.0; S[S_RR] = 0.0; S[S_SS] = 0.0;
-  S[(it + 1) & 1] = 0.0;
-}
-
-__global__ void k_dot2(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
-                       double *__restrict__ out) {
-  double acc = 0.0;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    acc += a[i] * b[i];
-  block_atomic_sum(acc, out);
+// end of an iteration: roll rho, remember (r,r), clear the reduction slots
+__global__ void k_kr_roll(double *S) {
+  S[S_RHO] = S[R_OFF + R_RHO];
+  S[S_RR] = S[R_OFF + R_RR];
 }
 
 __global__ void k_gather(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ in,
@@ -311,13 +371,152 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
                        const double *d0, double *o0, double *o1) {
   hipStream_t st = s->mesh->stream;
   const dim3 block(256), grid((unsigned)phx_div_up(s->nslices, 4));
+  const uint8_t *own = s->own;
   if (dots == 0)
-    k_spmv_sell<0><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, d0, o0, o1);
+    k_spmv_sell<0><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1);
   else if (dots == 1)
-    k_spmv_sell<1><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, d0, o0, o1);
+    k_spmv_sell<1><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1);
   else
-    k_spmv_sell<2><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, d0, o0, o1);
+    k_spmv_sell<2><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1);
   PHX_HIP(hipGetLastError());
+  return PHX_OK;
+}
+
+struct KrVecs {
+  double *r, *rhat, *p, *v, *sv, *t, *y, *b;
+};
+static inline KrVecs kr_vecs(phx_system *s) {
+  double *w = s->kr_work ? s->kr_work : s->work;
+  const int64_t n = s->n;
+  return {w, w + n, w + 2 * n, w + 3 * n, w + 4 * n, w + 5 * n, w + 6 * n, w + 7 * n};
+}
+static inline double *kr_scal(phx_system *s) { return s->kr_scal ? s->kr_scal : s->scal; }
+
+// SpMV launches inside the solve can be bracketed by HIP events on the launch stream
+// (phx_set_option PHX_OPT_PROFILE_SPMV): the roofline figure of bench.py comes from here.
+static int prof_begin(phx_system *s) {
+  if (!s->mesh->profile_spmv || s->prof_used >= (int)s->prof_ev.size() / 2) return PHX_OK;
+  PHX_HIP(hipEventRecord(s->prof_ev[2 * s->prof_used], s->mesh->stream));
+  return PHX_OK;
+}
+static int prof_end(phx_system *s) {
+  if (!s->mesh->profile_spmv || s->prof_used >= (int)s->prof_ev.size() / 2) return PHX_OK;
+  PHX_HIP(hipEventRecord(s->prof_ev[2 * s->prof_used + 1], s->mesh->stream));
+  s->prof_used++;
+  return PHX_OK;
+}
+static int prof_reset(phx_system *s) {
+  s->prof_used = 0;
+  if (s->mesh->profile_spmv && s->prof_ev.empty()) {
+    s->prof_ev.resize(2 * 1024);
+    for (auto &e : s->prof_ev) PHX_HIP(hipEventCreate(&e));
+  }
+  return PHX_OK;
+}
+static int prof_collect(phx_system *s, double *avg_s, int *count) {
+  *avg_s = 0.0;
+  *count = 0;
+  if (!s->mesh->profile_spmv || s->prof_used == 0) return PHX_OK;
+  PHX_HIP(hipEventSynchronize(s->prof_ev[2 * s->prof_used - 1]));
+  double tot = 0.0;
+  for (int i = 0; i < s->prof_used; ++i) {
+    float ms = 0.f;
+    PHX_HIP(hipEventElapsedTime(&ms, s->prof_ev[2 * i], s->prof_ev[2 * i + 1]));
+    tot += ms;
+  }
+  *avg_s = tot * 1e-3 / s->prof_used;
+  *count = s->prof_used;
+  s->mesh->timings[4] = *avg_s;
+  s->mesh->timings[5] = (double)*count;
+  return PHX_OK;
+}
+
+// phases: 0 begin (local (b,b) -> R_RHO), 1 begin2 (after all-reduce), 2 v = A p (+R_RV),
+// 3 s-update, 4 t = A s (+R_TS, R_TT), 5 x/r-update (+R_RHO, R_RR), 6 p-update + roll
+extern "C" int phx_krylov_phase(phx_system *s, int phase) {
+  phx_mesh *m = s->mesh;
+  PHX_HIP(hipSetDevice(m->device));
+  const int64_t n = s->n;
+  hipStream_t st = m->stream;
+  const KrVecs V = kr_vecs(s);
+  double *S = kr_scal(s);
+  const dim3 block(256);
+  switch (phase) {
+    case 0:
+      PHX_HIP(hipMemsetAsync(S, 0, sizeof(double) * PHX_SCAL_DOUBLES, st));
+      k_kr_begin<<<vec_grid(n), block, 0, st>>>(n, s->perm, s->rhs, s->own, V.b, V.r, V.rhat, V.p, V.y, S);
+      k_reduce_slots<<<1, 64, 0, st>>>(S, R_RHO, 1);
+      break;
+    case 1:
+      k_kr_begin2<<<1, 1, 0, st>>>(S);
+      break;
+    case 2:
+      PHX_CHECK(prof_begin(s));
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.p, V.v, 1, V.rhat, slot_base(S, R_RV), nullptr));
+      PHX_CHECK(prof_end(s));
+      k_reduce_slots<<<1, 64, 0, st>>>(S, R_RV, 1);
+      break;
+    case 3:
+      k_update_s<<<vec_grid(n), block, 0, st>>>(n, s->own, V.r, V.v, V.sv, S);
+      break;
+    case 4:
+      PHX_CHECK(prof_begin(s));
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.sv, V.t, 2, V.sv, slot_base(S, R_TS), slot_base(S, R_TT)));
+      PHX_CHECK(prof_end(s));
+      k_reduce_slots<<<1, 64, 0, st>>>(S, R_TS, 2);
+      break;
+    case 5:
+      k_update_xr<<<vec_grid(n), block, 0, st>>>(n, s->own, V.p, V.sv, V.t, V.rhat, V.y, V.r, S);
+      k_reduce_slots<<<1, 64, 0, st>>>(S, R_RHO, 2);
+      break;
+    case 6:
+      k_update_p<<<vec_grid(n), block, 0, st>>>(n, s->own, V.r, V.v, V.p, S);
+      k_kr_roll<<<1, 1, 0, st>>>(S);
+      break;
+    default:
+      phx_set_error("unknown Krylov phase %d", phase);
+      return PHX_ERR_VALUE;
+  }
+  PHX_HIP(hipGetLastError());
+  return PHX_OK;
+}
+
+// x = D^-1 y scattered to FULL numbering, inactive (and non-owned) DoFs = 0
+extern "C" int phx_krylov_finish(phx_system *s, double *x_out, int loc) {
+  phx_mesh *m = s->mesh;
+  PHX_HIP(hipSetDevice(m->device));
+  const int64_t n = s->n;
+  hipStream_t st = m->stream;
+  const KrVecs V = kr_vecs(s);
+  double *xfull = x_out;
+  double *owned = nullptr;
+  if (loc != PHX_DEVICE) { PHX_HIP(hipMalloc(&owned, sizeof(double) * (size_t)s->nfull)); xfull = owned; }
+  PHX_HIP(hipMemsetAsync(xfull, 0, sizeof(double) * (size_t)s->nfull, st));
+  k_scatter_solution<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, st>>>(
+      n, s->perm, s->full_of_active, s->diag, V.y, xfull);
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipStreamSynchronize(st));
+  if (owned) {
+    PHX_HIP(hipMemcpy(x_out, owned, sizeof(double) * (size_t)s->nfull, hipMemcpyDeviceToHost));
+    PHX_HIP(hipFree(owned));
+  }
+  return PHX_OK;
+}
+
+extern "C" int phx_krylov_attach(phx_system *s, double *work, double *scal, const uint8_t *own) {
+  s->kr_work = work;
+  s->kr_scal = scal;
+  s->own = own;
+  return PHX_OK;
+}
+
+extern "C" int phx_krylov_profile(phx_system *s, int reset, double *avg_seconds, int64_t *count) {
+  if (reset) return prof_reset(s);
+  int c = 0;
+  double a = 0.0;
+  PHX_CHECK(prof_collect(s, &a, &c));
+  if (avg_seconds) *avg_seconds = a;
+  if (count) *count = c;
   return PHX_OK;
 }
 
@@ -326,78 +525,52 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
   phx_mesh *m = s->mesh;
   PHX_HIP(hipSetDevice(m->device));
   PHX_REQUIRE(method == PHX_BICGSTAB_JACOBI, PHX_ERR_NOT_IMPLEMENTED, "unknown method %d", method);
-  const int64_t n = s->n;
   hipStream_t st = m->stream;
-  double *r = s->work, *rhat = r + n, *p = r + 2 * n, *v = r + 3 * n, *sv = r + 4 * n,
-         *t = r + 5 * n, *y = r + 6 * n, *b = r + 7 * n;
-  double *S = s->scal;
-  const dim3 block(256);
-  const dim3 gn((unsigned)phx_div_up(n, 256));
+  double *S = kr_scal(s);
   const int check_every = 8;
+  PHX_CHECK(prof_reset(s));
   PHX_CHECK(phx_begin_timing(m));
-  // solver ordering; x0 = 0 => r = b; rhat = r; p = r
-  k_gather<<<gn, block, 0, st>>>(n, s->perm, s->rhs, b);
-  PHX_HIP(hipMemcpyAsync(r, b, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
-  PHX_HIP(hipMemcpyAsync(rhat, b, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
-  PHX_HIP(hipMemcpyAsync(p, b, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
-  PHX_HIP(hipMemsetAsync(y, 0, sizeof(double) * n, st));
-  PHX_HIP(hipMemsetAsync(S, 0, sizeof(double) * 16, st));
-  k_dot2<<<vec_grid(n), block, 0, st>>>(n, b, b, &S[S_RHO0]);  // rho_0 = (rhat, r) = (b, b)
+  PHX_CHECK(phx_krylov_phase(s, 0));
+  PHX_CHECK(phx_krylov_phase(s, 1));
   PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
   PHX_HIP(hipStreamSynchronize(st));
-  const double bb = s->scal_h[S_RHO0];
+  const double bb = s->scal_h[S_BB];
   int64_t it = 0, spmvs = 0;
-  double relres = 0.0;
+  double relres = bb == 0.0 ? 0.0 : 1.0;
   int rc = PHX_OK;
-  if (bb == 0.0) {
-    relres = 0.0;
-  } else {
-    relres = 1.0;
-    while (it < max_iter) {
-      // v = A D^-1 p, (rhat, v)
-      PHX_CHECK(launch_spmv(s, s->sell_val, p, v, 1, rhat, &S[S_RV], nullptr));
-      k_update_s<<<vec_grid(n), block, 0, st>>>(n, (int)(it & 1), r, v, sv, S);
-      // t = A D^-1 s, (t,s), (t,t)
-      PHX_CHECK(launch_spmv(s, s->sell_val, sv, t, 2, sv, &S[S_TS], &S[S_TT]));
-      k_update_xr<<<vec_grid(n), block, 0, st>>>(n, (int)(it & 1), p, sv, t, rhat, y, r, S);
-      spmvs += 2;
-      ++it;
-      const bool check = (it % check_every == 0) || it == max_iter;
-      if (check) {
-        PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
-        PHX_HIP(hipStreamSynchronize(st));
-        const double rr = s->scal_h[S_RR];
-        relres = sqrt(rr / bb);
-        if (!(rr == rr) || !(s->scal_h[S_OMEGA] == s->scal_h[S_OMEGA]) ||
-            s->scal_h[((it)&1)] == 0.0) {
-          phx_set_error("BiCGStab breakdown at iteration %lld (rho=%g omega=%g rr=%g)",
-                        (long long)it, s->scal_h[it & 1], s->scal_h[S_OMEGA], rr);
-          rc = PHX_ERR_BREAKDOWN;
-          break;
-        }
-        if (relres <= rtol) break;
+  while (bb != 0.0 && it < max_iter) {
+    for (int ph = 2; ph <= 5; ++ph) PHX_CHECK(phx_krylov_phase(s, ph));
+    spmvs += 2;
+    ++it;
+    if ((it % check_every == 0) || it == max_iter) {
+      PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+      PHX_HIP(hipStreamSynchronize(st));
+      const double rr = s->scal_h[R_OFF + R_RR], rho = s->scal_h[R_OFF + R_RHO];
+      const double omega = s->scal_h[S_OMEGA];
+      relres = sqrt(rr / bb);
+      if (!(rr == rr) || !(omega == omega) || rho == 0.0 || omega == 0.0) {
+        phx_set_error("BiCGStab breakdown at iteration %lld (rho=%g omega=%g rr=%g)",
+                      (long long)it, rho, omega, rr);
+        rc = PHX_ERR_BREAKDOWN;
+        break;
       }
-      k_update_p<<<vec_grid(n), block, 0, st>>>(n, (int)((it - 1) & 1), r, v, p, S, S);
-      k_clear_iter_scalars<<<1, 1, 0, st>>>((int)(it & 1), S);
+      if (relres <= rtol) break;
     }
+    PHX_CHECK(phx_krylov_phase(s, 6));
   }
-  PHX_HIP(hipGetLastError());
   // back to full numbering, x = D^-1 y, inactive DoFs = 0 (MUMPS ICNTL(24)=1 semantics)
-  double *xfull = x_out;
-  double *owned = nullptr;
-  if (loc != PHX_DEVICE) { PHX_HIP(hipMalloc(&owned, sizeof(double) * (size_t)s->nfull)); xfull = owned; }
-  PHX_HIP(hipMemsetAsync(xfull, 0, sizeof(double) * (size_t)s->nfull, st));
-  k_scatter_solution<<<gn, block, 0, st>>>(n, s->perm, s->full_of_active, s->diag, y, xfull);
+  PHX_CHECK(phx_krylov_finish(s, x_out, loc));
   PHX_CHECK(phx_end_timing(m, 3));
-  if (owned) {
-    PHX_HIP(hipMemcpy(x_out, owned, sizeof(double) * (size_t)s->nfull, hipMemcpyDeviceToHost));
-    PHX_HIP(hipFree(owned));
-  }
+  double pavg = 0.0;
+  int pcount = 0;
+  PHX_CHECK(prof_collect(s, &pavg, &pcount));
   if (stats) {
     stats[0] = (double)it;
     stats[1] = relres;
     stats[2] = m->timings[3];
     stats[3] = (double)spmvs;
+    stats[4] = pavg;
+    stats[5] = (double)pcount;
   }
   return rc;
 }

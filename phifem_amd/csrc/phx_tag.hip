@@ -386,7 +386,9 @@ static int run_facet_rule(phx_mesh *m) {
   PHX_HIP(hipMalloc(&dbad, sizeof(unsigned long long)));
   PHX_HIP(hipMemsetAsync(dbad, 0, sizeof(unsigned long long), m->stream));
   k_tag_facets<<<dim3((unsigned)phx_div_up(m->nf, 256)), dim3(256), 0, m->stream>>>(
-      m->nf, m->f2c, m->cell_tags, m->tag_hist[3] == 0 ? 1 : 0, m->facet_tags, dbad);
+      m->nf, m->f2c, m->cell_tags,
+      m->has_exterior_override >= 0 ? (m->has_exterior_override ? 0 : 1) : (m->tag_hist[3] == 0 ? 1 : 0),
+      m->facet_tags, dbad);
   PHX_HIP(hipGetLastError());
   PHX_CHECK(phx_end_timing(m, 1));
   unsigned long long bad = 0;

@@ -1,0 +1,86 @@
+"""Slab-partitioned problem driver: one process per GPU (torch.distributed over RCCL/xGMI).
+
+The background box is cut into slabs of cube layers along the last axis; every rank generates
+its slab plus GHOST cube layers on the device (same global coordinates bit for bit), tags and
+assembles it redundantly -- no matrix contribution ever crosses a rank -- and owns the rows of
+the vertex planes inside its slab.  The only data-path exchanges are the halo of vector entries
+before each SpMV and the batched scalar all-reduce of the Krylov dot products.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .mesh import create_box
+from .mesh_scripts import NodalFunction, _tag_cells, _tag_facets
+from .solver import PhiFEMSolver
+
+GHOST_LAYERS = 4  # see DESIGN.md "Multi-GPU": tags/active flags exact on every referenced plane
+
+
+def slab_layout(n_per_rank, rank, world, ghost=GHOST_LAYERS):
+    """Cube-layer bookkeeping of rank `rank`: owned layers [L0, L1), local box [k0, k1),
+    owned vertex planes [L0, P1) (the last rank also owns the closing plane)."""
+    nz = n_per_rank * world
+    L0, L1 = rank * n_per_rank, (rank + 1) * n_per_rank
+    k0, k1 = max(0, L0 - ghost), min(nz, L1 + ghost)
+    P1 = L1 + 1 if rank == world - 1 else L1
+    return {"nz": nz, "L0": L0, "L1": L1, "k0": k0, "k1": k1, "P0": L0, "P1": P1}
+
+
+class SlabProblem:
+    """BASELINE configs[1] per GPU, weak-scaled: n^3 cubes per rank of an n x n x (n*world) box
+    on [-1.5,1.5]^2 x [-1.5*world, 1.5*world] around x^2 + y^2 + (z/world)^2 = 1."""
+
+    def __init__(self, n_per_rank, rank=0, world=1, device=0, rtol=1e-8, max_iter=20000):
+        self.n, self.rank, self.world, self.device = n_per_rank, rank, world, device
+        self.rtol, self.max_iter = rtol, max_iter
+        self.lay = slab_layout(n_per_rank, rank, world)
+
+    def setup(self):
+        import torch
+        n, w, lay = self.n, self.world, self.lay
+        lo = [-1.5, -1.5, -1.5 * w]
+        hi = [1.5, 1.5, 1.5 * w]
+        self.mesh = create_box(lo, hi, [n, n, lay["k1"] - lay["k0"]], device=self.device,
+                               offset=[0, 0, lay["k0"]], n_global=[n, n, lay["nz"]])
+        dev = torch.device("cuda", self.device)
+        x = torch.empty((self.mesh.nv, 3), dtype=torch.float64, device=dev)
+        L.check(L.lib.phx_mesh_get_array(self.mesh._h, L.ARR_COORDS, C.c_void_p(x.data_ptr()), L.DEVICE))
+        zs = x[:, 2] / float(w)
+        self.phi = x[:, 0] ** 2 + x[:, 1] ** 2 + zs ** 2 - 1.0
+        # manufactured solution u = sin x sin y sin(z/w):  -Laplace(u) = (2 + 1/w^2) u
+        self.u_ex = torch.sin(x[:, 0]) * torch.sin(x[:, 1]) * torch.sin(zs)
+        self.f = (2.0 + 1.0 / float(w * w)) * self.u_ex
+        self.out = torch.empty(2 * self.mesh.nv, dtype=torch.float64, device=dev)
+        del x
+        torch.cuda.synchronize()
+        self.solver = PhiFEMSolver(self.mesh)
+        if w > 1:
+            from .dist_solver import DistributedKrylov
+            self.dk = DistributedKrylov(self)
+
+    def step(self, profile_spmv=False):
+        """tag -> assemble -> solve, everything resident on the device."""
+        mesh = self.mesh
+        staged = _tag_cells(mesh, NodalFunction(self.phi), 1, single_layer_cut=True)
+        if self.world > 1:
+            self.dk.agree_on_exterior()
+        _tag_facets(mesh, staged, 1)
+        info = self.solver.assemble(self.phi, self.f, self.u_ex)
+        if self.world == 1:
+            self.solver.solve(rtol=self.rtol, max_iter=self.max_iter, out=self.out,
+                              profile_spmv=profile_spmv)
+            st = self.solver.stats
+            n_owned = info["n_active"]
+        else:
+            st = self.dk.solve(self.out, profile_spmv=profile_spmv)
+            n_owned = st["n_owned"]
+        t = mesh.timings()
+        return {
+            "n_active_owned": n_owned, "iterations": st["iterations"], "relres": st["relres"],
+            "stage_s": {"tag": t["tag_cells"] + t["tag_facets"], "assemble": t["assemble"],
+                        "solve": st["seconds"]},
+            "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),
+            "spmv_algorithmic_bytes": 12.0 * info["sell_nnz"] + 20.0 * info["n_active"],
+        }

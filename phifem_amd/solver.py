@@ -77,7 +77,7 @@ class PhiFEMSolver:
                                                      for a in (rowptr, col, val, rhs, dof))))
         return rowptr, col, val, rhs, dof
 
-    def solve(self, rtol=1e-8, max_iter=20000, out=None):
+    def solve(self, rtol=1e-8, max_iter=20000, out=None, profile_spmv=False):
         """Replaces the KSP/MUMPS block of main.py:162-182.  Returns the mixed solution in the
         full numbering [u (nv), p (nv)] with inactive DoFs at zero; `out` may be a device
         tensor of 2*nv doubles."""
@@ -85,10 +85,11 @@ class PhiFEMSolver:
         if out is None:
             out = np.empty(nfull, dtype=np.float64)
         p, loc = L.ptr(out)
-        st = (C.c_double * 4)()
+        st = (C.c_double * 6)()
+        L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_PROFILE_SPMV, 1 if profile_spmv else 0))
         L.check(L.lib.phx_solve(self._sys, 0, float(rtol), int(max_iter), p, loc, st))
         self.stats = {"iterations": int(st[0]), "relres": st[1], "seconds": st[2],
-                      "spmv": int(st[3])}
+                      "spmv": int(st[3]), "spmv_avg_s": st[4], "spmv_timed": int(st[5])}
         return out
 
     def split(self, w):
