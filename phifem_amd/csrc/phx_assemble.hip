@@ -52,8 +52,8 @@ __global__ void k_finish_numbering(int64_t nv, const uint8_t *__restrict__ fu,
 }
 
 // ---------------------------------------------------------------------------------------------
-// row slots: W (col,val) pairs per row, filled front to back.  A column claims the first free slot
-// with a CAS; values accumulate with hardware f64 atomics (global_atomic_add_f64).
+// row slots: a small open-addressing table of W (col,val) pairs per row.  A column claims a free
+// slot with a CAS; values accumulate with hardware f64 atomics (global_atomic_add_f64).
 // ---------------------------------------------------------------------------------------------
 struct Slots {
   int32_t *cols;
@@ -66,7 +66,11 @@ __device__ __forceinline__ void slot_add(const Slots &s, int32_t row, int32_t co
   if (row < 0 || col < 0) return;  // inactive DoF (only reachable through user-overwritten tags)
   int32_t *rc = s.cols + (int64_t)row * s.W;
   double *rv = s.vals + (int64_t)row * s.W;
-  for (int k = 0; k < s.W; ++k) {
+  // open addressing inside the row: start at a hash of the column (W is a power of two), so a
+  // lookup costs ~1-2 probes instead of a walk over the row's whole prefix
+  const int mask = s.W - 1;
+  int k = (int)(((uint32_t)col * 2654435761u) >> 16) & mask;
+  for (int t = 0; t < s.W; ++t, k = (k + 1) & mask) {
     int32_t cur = __hip_atomic_load(&rc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == -1) {
       cur = atomicCAS(&rc[k], -1, col);
