@@ -77,9 +77,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PHIFEM_DIST_BACKEND=gloo: rehearsal of the N>1 path with several ranks on ONE GPU (RCCL
+    # refuses two ranks per device); the driver's runs use nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("PHIFEM_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

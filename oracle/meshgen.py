@@ -16,12 +16,17 @@ PERMS2 = [(0, 1), (1, 0)]
 PERMS3 = list(itertools.permutations((0, 1, 2)))
 
 
-def create_box(lo, hi, n):
+def create_box(lo, hi, n, offset=None, n_global=None):
+    """n cubes per axis; with offset / n_global the box is a sub-box of a larger lattice and
+    reproduces its coordinates bit for bit (multi-GPU slabs):
+        x_a(i) = lo_a + (hi_a - lo_a) * ((offset_a + i) / n_global_a)."""
     lo = np.asarray(lo, dtype=np.float64)
     hi = np.asarray(hi, dtype=np.float64)
     n = np.asarray(n, dtype=np.int64)
     d = lo.size
-    axes = [lo[a] + (hi[a] - lo[a]) * (np.arange(n[a] + 1) / n[a]) for a in range(d)]
+    off = np.zeros(d, dtype=np.int64) if offset is None else np.asarray(offset, dtype=np.int64)
+    ng = n if n_global is None else np.asarray(n_global, dtype=np.int64)
+    axes = [lo[a] + (hi[a] - lo[a]) * ((off[a] + np.arange(n[a] + 1)) / ng[a]) for a in range(d)]
     if d == 2:
         X, Y = np.meshgrid(axes[0], axes[1], indexing="xy")
         x = np.stack([X.reshape(-1), Y.reshape(-1)], axis=1)

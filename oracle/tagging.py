@@ -143,7 +143,7 @@ def tag_cells_values(topo, x, levelset, degree, single_layer_cut=False, warn=Tru
     return tags
 
 
-def tag_facets_values(topo, cell_tags, bnd_cell_cut):
+def tag_facets_values(topo, cell_tags, bnd_cell_cut, no_ext=None):
     """Per-facet predicates equivalent to the set algebra of mesh_scripts.py:454-496.
     Returns (tag int8[nf], membership_count int8[nf]); count != 1 means the reference's
     sets overlap (or miss) on that facet and dolfinx's MeshTags would reject the input."""
@@ -157,7 +157,8 @@ def tag_facets_values(topo, cell_tags, bnd_cell_cut):
     C = (t0 == 2) | (t1 == 2)
     E = (t0 == 3) | (t1 == 3)
     B = ~has1
-    no_ext = not np.any(cell_tags == 3)
+    if no_ext is None:  # a slab of a partitioned mesh gets the global answer from its driver
+        no_ext = not np.any(cell_tags == 3)
     cellcut = bnd_cell_cut[c0]
     CB = B & cellcut                              # :454-456
     UB = B & ~cellcut & ~E & ~I                   # :457-461

@@ -1,0 +1,260 @@
+"""Multi-GPU Jacobi-BiCGStab over slabs: torch.distributed (RCCL over xGMI, or gloo in CPU tests)
+drives the phase kernels of the C ABI (`phx_krylov_phase`).
+
+Per iteration the data path has exactly two kinds of exchange:
+  * halo: the entries of p (before phase 2) and s (before phase 4) on the two vertex planes either
+    side of a slab interface, point-to-point with the (at most two) neighbours -- slabs talk over
+    dedicated xGMI links, no ring;
+  * scalars: one all-reduce of 1, 2 and 2 doubles after phases 2, 4 and 5 (the dot products of a
+    phase are batched into one call).
+Nothing else crosses ranks: tagging and assembly are redundant on the ghost layers.
+
+The loop is written against a small backend interface so that the same code runs on the GPU
+(`HipBackend`, C ABI) and in the CPU tests (a numpy stand-in under tests/).
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+HALO_PLANES = 2   # a row reaches vertices two planes away (facet macro-elements, main.py:129-134)
+SCAL_DOUBLES = 16 + 8 * 64 * 8
+R_OFF = 8
+R_RV, R_TS, R_TT, R_RHO, R_RR = 0, 1, 2, 4, 5
+S_BB = 3
+
+
+class HipBackend:
+    """The assembled local system of a `PhiFEMSolver` seen through the phase API."""
+
+    def __init__(self, solver, torch_device):
+        import torch
+        from . import _lib as L
+        self.L, self.torch = L, torch
+        self.sys = solver._sys
+        self.mesh = solver.mesh
+        info = solver.info()
+        self.n, self.nv = info["n_active"], solver.mesh.nv
+        self.dev = torch_device
+        perm = torch.empty(self.n, dtype=torch.int32, device=self.dev)
+        dof_u = torch.empty(self.nv, dtype=torch.int32, device=self.dev)
+        dof_p = torch.empty(self.nv, dtype=torch.int32, device=self.dev)
+        L.check(L.lib.phx_system_get_perm(self.sys, C.c_void_p(perm.data_ptr()),
+                                          C.c_void_p(dof_u.data_ptr()), C.c_void_p(dof_p.data_ptr()),
+                                          L.DEVICE))
+        self.perm, self.dof_u, self.dof_p = perm.long(), dof_u.long(), dof_p.long()
+
+    def use_current_stream(self):
+        st = self.torch.cuda.current_stream(self.dev).cuda_stream
+        self.L.check(self.L.lib.phx_mesh_set_stream(self.mesh._h, C.c_uint64(st)))
+
+    def attach(self, work, scal, own):
+        self._keep = (work, scal, own)
+        L = self.L
+        L.check(L.lib.phx_krylov_attach(self.sys, C.c_void_p(work.data_ptr()),
+                                        C.c_void_p(scal.data_ptr()), C.c_void_p(own.data_ptr())))
+
+    def phase(self, k):
+        self.L.check(self.L.lib.phx_krylov_phase(self.sys, k))
+
+    def finish(self, out):
+        self.L.check(self.L.lib.phx_krylov_finish(self.sys, C.c_void_p(out.data_ptr()), self.L.DEVICE))
+
+    def profile(self, reset):
+        L = self.L
+        if reset:
+            L.check(L.lib.phx_krylov_profile(self.sys, 1, None, None))
+            return None
+        a, c = C.c_double(0.0), C.c_int64(0)
+        L.check(L.lib.phx_krylov_profile(self.sys, 0, C.byref(a), C.byref(c)))
+        return a.value, c.value
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.dev)
+
+
+def ownership_and_halos(torch, backend, plane_size, k0, P0, P1, rank, world, n_planes_local):
+    """Owned-row mask (solver order) and the per-neighbour halo index lists (solver positions).
+
+    Local vertex v sits on global vertex plane k0 + v // plane_size.  A rank owns planes
+    [P0, P1).  Lists are ordered (u before p, ascending global vertex id) so that the sender's
+    and the receiver's enumerations coincide."""
+    dev = backend.perm.device
+    nv, n = backend.nv, backend.n
+    plane = torch.arange(nv, device=dev) // plane_size + k0
+    owned_v = (plane >= P0) & (plane < P1)
+    owned_a = torch.zeros(n, dtype=torch.bool, device=dev)
+    for dof in (backend.dof_u, backend.dof_p):
+        act = dof >= 0
+        owned_a[dof[act]] = owned_v[act]
+    iperm = torch.empty(n, dtype=torch.long, device=dev)
+    iperm[backend.perm] = torch.arange(n, device=dev)
+    own_s = owned_a[backend.perm].to(torch.uint8).contiguous()
+
+    def positions(lo, hi):
+        """solver positions + global ids of the active DoFs on global planes [lo, hi)."""
+        sel = (plane >= lo) & (plane < hi)
+        pos, gid = [], []
+        for kind, dof in enumerate((backend.dof_u, backend.dof_p)):
+            v = torch.nonzero(sel & (dof >= 0)).flatten()
+            pos.append(iperm[dof[v]])
+            gid.append((v + k0 * plane_size) * 2 + kind)
+        return torch.cat(pos), torch.cat(gid)
+
+    halos = []
+    H = HALO_PLANES
+    if rank > 0:         # lower neighbour owns planes < P0
+        send = positions(P0, min(P0 + H, P1))
+        recv = positions(max(P0 - H, k0), P0)
+        halos.append({"peer": rank - 1, "send": send, "recv": recv})
+    if rank < world - 1:  # upper neighbour owns planes >= P1
+        send = positions(max(P1 - H, P0), P1)
+        recv = positions(P1, min(P1 + H, k0 + n_planes_local))
+        halos.append({"peer": rank + 1, "send": send, "recv": recv})
+    return own_s, halos
+
+
+class DistributedSolver:
+    """BiCGStab (right Jacobi) on a slab-partitioned system."""
+
+    def __init__(self, backend, dist, torch, rank, world, plane_size, k0, P0, P1, n_planes_local,
+                 rtol=1e-8, max_iter=20000, check_every=8):
+        self.b, self.dist, self.torch = backend, dist, torch
+        self.rank, self.world = rank, world
+        # rehearsal mode: gloo cannot move CUDA tensors point-to-point, so stage through the host
+        self.stage_cpu = bool(world > 1 and dist.get_backend() == "gloo"
+                              and backend.perm.device.type == "cuda")
+        self.rtol, self.max_iter, self.check_every = rtol, max_iter, check_every
+        dev = backend.perm.device
+        self.own, self.halos = ownership_and_halos(torch, backend, plane_size, k0, P0, P1, rank,
+                                                   world, n_planes_local)
+        n = backend.n
+        self.work = torch.zeros(8 * n, dtype=torch.float64, device=dev)
+        self.scal = torch.zeros(SCAL_DOUBLES, dtype=torch.float64, device=dev)
+        self.p = self.work[2 * n:3 * n]
+        self.s = self.work[4 * n:5 * n]
+        backend.attach(self.work, self.scal, self.own)
+        self.n_owned = int(self.own.sum().item())
+        self._verify_halos()
+
+    def _verify_halos(self):
+        """Both sides of an interface must enumerate the same DoFs: compare the global ids."""
+        torch, dist = self.torch, self.dist
+        for h in self.halos:
+            mine = torch.tensor([h["send"][1].numel(), h["recv"][1].numel()], dtype=torch.long,
+                                device=h["send"][1].device)
+            theirs = torch.empty_like(mine)
+            self._sendrecv(h["peer"], mine, theirs)
+            if int(theirs[0]) != h["recv"][1].numel() or int(theirs[1]) != h["send"][1].numel():
+                raise RuntimeError(
+                    f"rank {self.rank}: halo size mismatch with rank {h['peer']}: they send "
+                    f"{int(theirs[0])} / expect {int(theirs[1])}, I expect "
+                    f"{h['recv'][1].numel()} / send {h['send'][1].numel()}")
+            got = torch.empty_like(h["recv"][1])
+            self._sendrecv(h["peer"], h["send"][1].contiguous(), got)
+            if not torch.equal(got, h["recv"][1]):
+                raise RuntimeError(f"rank {self.rank}: halo DoF sets differ from rank {h['peer']}")
+            h["sbuf"] = torch.empty(h["send"][0].numel(), dtype=torch.float64, device=got.device)
+            h["rbuf"] = torch.empty(h["recv"][0].numel(), dtype=torch.float64, device=got.device)
+
+    def _sendrecv(self, peer, out_t, in_t):
+        dist = self.dist
+        so, si = (out_t.cpu(), in_t.cpu()) if self.stage_cpu else (out_t, in_t)
+        ops = [dist.P2POp(dist.isend, so, peer), dist.P2POp(dist.irecv, si, peer)]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        if self.stage_cpu:
+            in_t.copy_(si)
+
+    def halo_exchange(self, vec):
+        dist, torch = self.dist, self.torch
+        ops, staged = [], []
+        for h in self.halos:
+            torch.index_select(vec, 0, h["send"][0], out=h["sbuf"])
+            sb, rb = (h["sbuf"].cpu(), h["rbuf"].cpu()) if self.stage_cpu else (h["sbuf"], h["rbuf"])
+            staged.append(rb)
+            ops.append(dist.P2POp(dist.isend, sb, h["peer"]))
+            ops.append(dist.P2POp(dist.irecv, rb, h["peer"]))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        for h, rb in zip(self.halos, staged):
+            if self.stage_cpu:
+                h["rbuf"].copy_(rb)
+            vec.index_copy_(0, h["recv"][0], h["rbuf"])
+
+    def _allreduce(self, lo, hi):
+        if self.world > 1:
+            self.dist.all_reduce(self.scal[R_OFF + lo:R_OFF + hi])
+
+    def solve(self, out, profile_spmv=False):
+        b = self.b
+        if profile_spmv:
+            b.profile(True)
+        b.synchronize()
+        t0 = time.perf_counter()
+        b.phase(0)
+        self._allreduce(R_RHO, R_RHO + 1)
+        b.phase(1)
+        bb = float(self.scal[S_BB].item())
+        it, relres = 0, (0.0 if bb == 0.0 else 1.0)
+        while bb != 0.0 and it < self.max_iter:
+            self.halo_exchange(self.p)
+            b.phase(2)
+            self._allreduce(R_RV, R_RV + 1)
+            b.phase(3)
+            self.halo_exchange(self.s)
+            b.phase(4)
+            self._allreduce(R_TS, R_TT + 1)
+            b.phase(5)
+            self._allreduce(R_RHO, R_RR + 1)
+            it += 1
+            if it % self.check_every == 0 or it == self.max_iter:
+                rr = float(self.scal[R_OFF + R_RR].item())
+                relres = (rr / bb) ** 0.5
+                if not np.isfinite(rr):
+                    raise ArithmeticError(f"BiCGStab breakdown at iteration {it}")
+                if relres <= self.rtol:
+                    break
+            b.phase(6)
+        b.finish(out)
+        b.synchronize()
+        dt = time.perf_counter() - t0
+        st = {"iterations": it, "relres": relres, "seconds": dt, "n_owned": self.n_owned}
+        if profile_spmv:
+            prof = b.profile(False)
+            if prof:
+                st["spmv_avg_s"], st["spmv_timed"] = prof
+        return st
+
+
+class DistributedKrylov:
+    """Glue between `SlabProblem` (phifem_amd/distributed.py) and `DistributedSolver`."""
+
+    def __init__(self, prob):
+        import torch
+        import torch.distributed as dist
+        self.prob, self.torch, self.dist = prob, torch, dist
+        self.dev = torch.device("cuda", prob.device)
+
+    def agree_on_exterior(self):
+        """`len(exterior_cells) == 0` (mesh_scripts.py:469) must be decided over ALL slabs."""
+        from . import _lib as L
+        hist = (C.c_int64 * 4)()
+        L.check(L.lib.phx_mesh_tag_histogram(self.prob.mesh._h, hist, None))
+        flag = self.torch.tensor([1 if hist[3] > 0 else 0], dtype=self.torch.int32, device=self.dev)
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+        L.check(L.lib.phx_set_option(self.prob.mesh._h, L.OPT_HAS_EXTERIOR, int(flag.item())))
+
+    def solve(self, out, profile_spmv=False):
+        from . import _lib as L
+        prob = self.prob
+        lay = prob.lay
+        backend = HipBackend(prob.solver, self.dev)
+        backend.use_current_stream()
+        L.check(L.lib.phx_set_option(prob.mesh._h, L.OPT_PROFILE_SPMV, 1 if profile_spmv else 0))
+        plane = (prob.n + 1) * (prob.n + 1)
+        ds = DistributedSolver(backend, self.dist, self.torch, prob.rank, prob.world, plane,
+                               lay["k0"], lay["P0"], lay["P1"], lay["k1"] - lay["k0"] + 1,
+                               rtol=prob.rtol, max_iter=prob.max_iter)
+        return ds.solve(out, profile_spmv=profile_spmv)

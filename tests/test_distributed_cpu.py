@@ -1,0 +1,88 @@
+"""World-size-2 and -3 runs of the slab-partitioned solver on CPU (gloo): the multi-GPU host logic
+(slab layout, ghost layers, ownership, halo lists, halo exchange, batched scalar all-reduce) with
+the numpy stand-in of the phase kernels.  The distributed solution must equal the single-mesh
+oracle solution."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cpu_backend import CpuBackend, assemble_local
+from oracle import assembly as OA
+from phifem_amd.dist_solver import DistributedSolver
+from phifem_amd.distributed import GHOST_LAYERS, slab_layout
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def worker(rank, world, n, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lay = slab_layout(n, rank, world)
+        x, topo, cv, A, b, act = assemble_local(n, world, lay["k0"], lay["k1"], has_exterior=True)
+        be = CpuBackend(A, b, act, topo.nv)
+        plane = (n + 1) * (n + 1)
+        ds = DistributedSolver(be, dist, torch, rank, world, plane, lay["k0"], lay["P0"], lay["P1"],
+                               lay["k1"] - lay["k0"] + 1, rtol=1e-11, max_iter=4000, check_every=4)
+        out = torch.zeros(2 * topo.nv, dtype=torch.float64)
+        st = ds.solve(out)
+        # owned entries in global vertex numbering
+        w = out.numpy()
+        nv = topo.nv
+        vplane = np.arange(nv) // plane + lay["k0"]
+        owned = (vplane >= lay["P0"]) & (vplane < lay["P1"])
+        gid = np.arange(nv) + lay["k0"] * plane
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), gid=gid[owned], u=w[:nv][owned],
+                 p=w[nv:][owned], it=st["iterations"], relres=st["relres"], n_owned=st["n_owned"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_solver_matches_single_mesh(world, tmp_path):
+    n = 8
+    port = free_port()
+    mp.spawn(worker, args=(world, n, port, str(tmp_path)), nprocs=world, join=True)
+    # single-mesh reference
+    x, topo, cv, A, b, act = assemble_local(n, world, 0, n * world)
+    wref = OA.solve_direct(A, b, act)
+    nvg = topo.nv
+    u = np.full(nvg, np.nan)
+    p = np.full(nvg, np.nan)
+    n_owned = 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert np.all(np.isnan(u[d["gid"]])), "a vertex is owned by two ranks"
+        u[d["gid"]] = d["u"]
+        p[d["gid"]] = d["p"]
+        n_owned += int(d["n_owned"])
+        assert d["relres"] <= 1e-11 and d["it"] > 0
+    assert not np.any(np.isnan(u)), "a vertex is owned by no rank"
+    assert n_owned == int(act.sum()), "owned active DoFs do not add up to the global system"
+    scale = np.abs(wref).max()
+    assert np.abs(u - wref[:nvg]).max() <= 1e-7 * scale
+    assert np.abs(p - wref[nvg:]).max() <= 1e-7 * scale
+
+
+def test_slab_layout_covers_the_box():
+    for world in (1, 2, 3, 8):
+        n = 16
+        planes = []
+        for r in range(world):
+            lay = slab_layout(n, r, world)
+            assert lay["k0"] == max(0, r * n - GHOST_LAYERS)
+            assert lay["k1"] == min(n * world, (r + 1) * n + GHOST_LAYERS)
+            planes += list(range(lay["P0"], lay["P1"]))
+        assert planes == list(range(n * world + 1))

@@ -144,3 +144,28 @@ def test_convergence_rate_2d(P):
         inside = np.unique(work.cells[work.cell_tag_values() == 1])
         errs.append(np.sqrt(np.mean((w[:work.nv][inside] - uex[inside]) ** 2)))
     assert errs[0] / errs[1] > 3.0
+
+
+def test_phase_api_equals_native_solve(P):
+    """The externally driven iteration (multi-GPU driver, world = 1: no halo, no all-reduce) must
+    reproduce the native solver loop on the same system."""
+    import torch
+    from phifem_amd.dist_solver import DistributedSolver, HipBackend
+    from phifem_amd.distributed import SlabProblem
+    prob = SlabProblem(16, rank=0, world=1, device=0, rtol=1e-10)
+    prob.setup()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = prob.step()
+    native = prob.out.clone()
+    dev = torch.device("cuda", 0)
+    be = HipBackend(prob.solver, dev)
+    be.use_current_stream()
+    lay = prob.lay
+    ds = DistributedSolver(be, None, torch, 0, 1, (prob.n + 1) ** 2, lay["k0"], lay["P0"], lay["P1"],
+                           lay["k1"] - lay["k0"] + 1, rtol=1e-10)
+    assert ds.n_owned == prob.solver.info()["n_active"] and not ds.halos
+    out = torch.zeros_like(native)
+    st = ds.solve(out, profile_spmv=False)
+    assert st["iterations"] == res["iterations"]
+    assert torch.allclose(out, native, rtol=0, atol=1e-9 * float(native.abs().max()))
