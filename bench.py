@@ -29,7 +29,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=256, help="cubes per axis per GPU")
+    ap.add_argument("--cubes", type=int, default=256, help="cubes per axis per GPU")
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--cpu-n", type=int, default=40, help="box size of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,7 +93,7 @@ def main():
     import phifem_amd as P
     from phifem_amd import distributed as D
 
-    n = args.n
+    n = args.cubes
     prob = D.SlabProblem(n_per_rank=n, rank=rank, world=world, device=local_rank, rtol=args.rtol)
     prob.setup()  # mesh generation + nodal data on the device: inputs resident before timing
 

@@ -104,6 +104,10 @@ int phx_mesh_create_box(int gdim, const double *lo, const double *hi, const int6
                         const int64_t *offset, const int64_t *n_global, int device,
                         phx_mesh **out);
 
+/* Multi-GPU slabs: declare that the lower / upper end plane of the LAST axis of a device-generated
+ * box is a cut through the global mesh, not part of its boundary.  Facets on such a plane stay
+ * untagged (0) and take no part in the `ds` detection of mesh_scripts.py:434-461. */
+int phx_mesh_set_slab_faces(phx_mesh *m, int lower_is_cut, int upper_is_cut);
 int phx_mesh_destroy(phx_mesh *m);
 /* counts[6] = {gdim, cell_type, nv, nc, nf, nbf} */
 int phx_mesh_counts(const phx_mesh *m, int64_t *counts);

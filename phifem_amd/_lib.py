@@ -46,6 +46,7 @@ SIGNATURES = {
     "phx_topology_build_host": ([_i, _i64, _i64, _vp, _vp, _vp, _pi64], _i),
     "phx_mesh_create": ([_i, _i, _i64, _vp, _i64, _vp, _i, C.POINTER(_vp)], _i),
     "phx_mesh_create_box": ([_i, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp)], _i),
+    "phx_mesh_set_slab_faces": ([_vp, _i, _i], _i),
     "phx_mesh_destroy": ([_vp], _i),
     "phx_mesh_counts": ([_vp, _pi64], _i),
     "phx_mesh_get_array": ([_vp, _i, _vp, _i], _i),

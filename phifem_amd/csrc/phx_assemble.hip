@@ -442,8 +442,9 @@ static int scan_flags(phx_mesh *m, const uint8_t *flags, int32_t *out, int64_t n
 
 extern "C" int phx_system_destroy(phx_system *s) {
   if (!s) return PHX_OK;
-  (void)hipSetDevice(s->mesh->device);
-  (void)hipStreamSynchronize(s->mesh->stream);
+  // the mesh handle may already be gone (interpreter shutdown destroys in arbitrary order)
+  (void)hipSetDevice(s->device);
+  (void)hipDeviceSynchronize();
   void *ptrs[] = {s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active, s->rowptr, s->col,
                   s->val, s->rhs, s->diag, s->slice_ptr, s->sell_col, s->sell_val,
                   s->sell_val_raw, s->perm, s->iperm, s->work, s->scal};
@@ -459,6 +460,7 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
                                   phx_system **out) {
   phx_system *s = new phx_system();
   s->mesh = m;
+  s->device = m->device;
   s->nfull = 2 * m->nv;
   s->slot_cap = W;
   const int D = m->gdim;

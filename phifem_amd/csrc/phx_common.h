@@ -62,6 +62,11 @@ struct phx_mesh {
   int32_t *f2c = nullptr;     // [nf*2]
   int32_t *bfacets = nullptr; // [nbf*2] (cell, local facet), ascending facet id
   int32_t *bfacet_ids = nullptr; // [nbf] facet ids, ascending
+  // slab of a partitioned box: facets on an ARTIFICIAL end plane are not background-boundary
+  // facets; they stay untagged (0) and are left out of the `ds` detection
+  uint8_t *facet_exempt = nullptr;  // [nf] or NULL
+  bool is_box = false;
+  int64_t box_plane = 0, box_nlast = 0;
   int8_t *cell_tags = nullptr;   // [nc]
   int8_t *facet_tags = nullptr;  // [nf]
   bool have_cell_tags = false, have_facet_tags = false;
@@ -82,6 +87,7 @@ struct phx_mesh {
 
 struct phx_system {
   phx_mesh *mesh = nullptr;
+  int device = 0;
   int64_t n = 0, nu = 0, nnz = 0, nfull = 0;
   int slot_cap = 0;
   // original active numbering

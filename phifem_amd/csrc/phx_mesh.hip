@@ -511,6 +511,9 @@ extern "C" int phx_mesh_create_box(int gdim, const double *lo, const double *hi,
   m->cell_type = gdim == 3 ? PHX_TETRAHEDRON : PHX_TRIANGLE;
   PHX_CHECK(phx_get_cell_info(m->cell_type, &m->ci));
   m->nv = nv; m->nc = nc; m->nf = nf;
+  m->is_box = true;
+  m->box_plane = gdim == 3 ? (b.n[0] + 1) * (b.n[1] + 1) : (b.n[0] + 1);
+  m->box_nlast = b.n[gdim - 1];
   PHX_HIP(hipMalloc(&m->x, sizeof(double) * (size_t)nv * gdim));
   PHX_HIP(hipMalloc(&m->cells, sizeof(int32_t) * (size_t)nc * (gdim + 1)));
   PHX_HIP(hipMalloc(&m->c2f, sizeof(int32_t) * (size_t)nc * (gdim + 1)));
@@ -527,12 +530,50 @@ extern "C" int phx_mesh_create_box(int gdim, const double *lo, const double *hi,
   return PHX_OK;
 }
 
+// Slab of a partitioned box: the end planes of the LAST axis that are cuts through the global
+// mesh (not part of its boundary) are marked; see phx_common.h.
+__global__ void k_mark_exempt(int64_t nbf, const int32_t *__restrict__ bfacets,
+                              const int32_t *__restrict__ bfacet_ids,
+                              const int32_t *__restrict__ cells, int nvpc, int nvpf, int lower,
+                              int upper, int64_t plane, int64_t nlast,
+                              uint8_t *__restrict__ exempt) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nbf) return;
+  const int32_t c = bfacets[2 * i];
+  const int lf = bfacets[2 * i + 1];
+  // simplex: local facet lf is opposite local vertex lf
+  bool all_lo = true, all_hi = true;
+  for (int j = 0; j < nvpc; ++j) {
+    if (j == lf) continue;
+    const int64_t k = cells[(int64_t)c * nvpc + j] / plane;
+    all_lo = all_lo && (k == 0);
+    all_hi = all_hi && (k == nlast);
+  }
+  if ((lower && all_lo) || (upper && all_hi)) exempt[bfacet_ids[i]] = 1;
+}
+
+extern "C" int phx_mesh_set_slab_faces(phx_mesh *m, int lower_is_cut, int upper_is_cut) {
+  PHX_HIP(hipSetDevice(m->device));
+  PHX_REQUIRE(m->is_box, PHX_ERR_VALUE, "slab faces exist on device-generated boxes only");
+  if (!m->facet_exempt) PHX_HIP(hipMalloc(&m->facet_exempt, (size_t)m->nf));
+  PHX_HIP(hipMemsetAsync(m->facet_exempt, 0, (size_t)m->nf, m->stream));
+  if ((lower_is_cut || upper_is_cut) && m->nbf > 0)
+    k_mark_exempt<<<dim3((unsigned)phx_div_up(m->nbf, 256)), dim3(256), 0, m->stream>>>(
+        m->nbf, m->bfacets, m->bfacet_ids, m->cells, m->ci.nvpc, m->ci.nvpf, lower_is_cut,
+        upper_is_cut, m->box_plane, m->box_nlast, m->facet_exempt);
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  m->have_facet_tags = false;
+  m->have_entities = false;
+  return PHX_OK;
+}
+
 extern "C" int phx_mesh_destroy(phx_mesh *m) {
   if (!m) return PHX_OK;
   (void)hipSetDevice(m->device);
-  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  (void)hipDeviceSynchronize();
   void *ptrs[] = {m->x, m->cells, m->c2f, m->f2c, m->bfacets, m->bfacet_ids, m->cell_tags,
-                  m->facet_tags, m->ent_buf[0], m->ent_buf[1]};
+                  m->facet_tags, m->ent_buf[0], m->ent_buf[1], m->facet_exempt};
   for (void *p : ptrs) (void)hipFree(p);
   free(m->c_map_h); free(m->v_map_h);
   if (m->ev0) (void)hipEventDestroy(m->ev0);

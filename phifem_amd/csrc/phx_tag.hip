@@ -153,17 +153,22 @@ __global__ void k_boundary_cell_cut(int64_t nbf, DetTab tab, FacetVerts fvs, int
                                     const int32_t *__restrict__ f2c,
                                     const double *__restrict__ phi,
                                     const double *__restrict__ x, Quadric quad,
+                                    const uint8_t *__restrict__ exempt,
                                     int8_t *__restrict__ tags) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= nbf) return;
   const int32_t c = bfacets[2 * i];
   const int lf0 = bfacets[2 * i + 1];
-  for (int k = 0; k < lf0; ++k)
-    if (f2c[2 * (int64_t)c2f[(int64_t)c * fvs.nfpc + k] + 1] < 0) return;  // not the first
+  if (exempt && exempt[bfacet_ids[i]]) return;
+  for (int k = 0; k < lf0; ++k) {
+    const int32_t fk = c2f[(int64_t)c * fvs.nfpc + k];
+    if (f2c[2 * (int64_t)fk + 1] < 0 && !(exempt && exempt[fk])) return;  // not the first
+  }
   double num = 0.0, den = 0.0;
   for (int k = lf0; k < fvs.nfpc; ++k) {
     const int32_t f = c2f[(int64_t)c * fvs.nfpc + k];
     if (f2c[2 * (int64_t)f + 1] >= 0) continue;
+    if (exempt && exempt[f]) continue;
     int32_t v[3];
     for (int j = 0; j < fvs.nvpf; ++j) v[j] = cells[(int64_t)c * nvpc + fvs.fv[k][j]];
     int64_t base = 0;
@@ -184,9 +189,11 @@ __global__ void k_boundary_cell_cut(int64_t nbf, DetTab tab, FacetVerts fvs, int
 // --- a4: facet tags; per-facet predicates equivalent to the set algebra of :454-496 ----------
 __global__ void __launch_bounds__(256)
 k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restrict__ ctags,
-             int no_ext, int8_t *__restrict__ ftags, unsigned long long *__restrict__ bad) {
+             int no_ext, const uint8_t *__restrict__ exempt, int8_t *__restrict__ ftags,
+             unsigned long long *__restrict__ bad) {
   const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (f >= nf) return;
+  if (exempt && exempt[f]) { ftags[f] = 0; return; }  // cut through the global mesh: no tag
   const int2 cc = *reinterpret_cast<const int2 *>(f2c + 2 * f);
   const int b0 = (int)(uint8_t)ctags[cc.x];
   const int t0 = b0 & PHX_TAG_MASK;
@@ -369,9 +376,9 @@ static int launch_bcut(phx_mesh *m, const DetTab &tab, const FacetVerts &fvs, co
   if (m->nbf == 0) return PHX_OK;
   const dim3 grid((unsigned)phx_div_up(m->nbf, 256)), block(256);
   if (m->gdim == 2)
-    k_boundary_cell_cut<KIND, 2><<<grid, block, 0, m->stream>>>(m->nbf, tab, fvs, m->ci.nvpc, m->bfacets, m->bfacet_ids, m->cells, m->c2f, m->f2c, dphi, m->x, q, m->cell_tags);
+    k_boundary_cell_cut<KIND, 2><<<grid, block, 0, m->stream>>>(m->nbf, tab, fvs, m->ci.nvpc, m->bfacets, m->bfacet_ids, m->cells, m->c2f, m->f2c, dphi, m->x, q, m->facet_exempt, m->cell_tags);
   else
-    k_boundary_cell_cut<KIND, 3><<<grid, block, 0, m->stream>>>(m->nbf, tab, fvs, m->ci.nvpc, m->bfacets, m->bfacet_ids, m->cells, m->c2f, m->f2c, dphi, m->x, q, m->cell_tags);
+    k_boundary_cell_cut<KIND, 3><<<grid, block, 0, m->stream>>>(m->nbf, tab, fvs, m->ci.nvpc, m->bfacets, m->bfacet_ids, m->cells, m->c2f, m->f2c, dphi, m->x, q, m->facet_exempt, m->cell_tags);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
 }
@@ -388,7 +395,7 @@ static int run_facet_rule(phx_mesh *m) {
   k_tag_facets<<<dim3((unsigned)phx_div_up(m->nf, 256)), dim3(256), 0, m->stream>>>(
       m->nf, m->f2c, m->cell_tags,
       m->has_exterior_override >= 0 ? (m->has_exterior_override ? 0 : 1) : (m->tag_hist[3] == 0 ? 1 : 0),
-      m->facet_tags, dbad);
+      m->facet_exempt, m->facet_tags, dbad);
   PHX_HIP(hipGetLastError());
   PHX_CHECK(phx_end_timing(m, 1));
   unsigned long long bad = 0;

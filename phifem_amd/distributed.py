@@ -44,6 +44,9 @@ class SlabProblem:
         hi = [1.5, 1.5, 1.5 * w]
         self.mesh = create_box(lo, hi, [n, n, lay["k1"] - lay["k0"]], device=self.device,
                                offset=[0, 0, lay["k0"]], n_global=[n, n, lay["nz"]])
+        # the slab's end planes inside the global box are cuts, not background boundary
+        L.check(L.lib.phx_mesh_set_slab_faces(self.mesh._h, 1 if lay["k0"] > 0 else 0,
+                                              1 if lay["k1"] < lay["nz"] else 0))
         dev = torch.device("cuda", self.device)
         x = torch.empty((self.mesh.nv, 3), dtype=torch.float64, device=dev)
         L.check(L.lib.phx_mesh_get_array(self.mesh._h, L.ARR_COORDS, C.c_void_p(x.data_ptr()), L.DEVICE))
