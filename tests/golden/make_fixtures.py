@@ -19,6 +19,10 @@ Outputs (small, committed):
                                    once dolfinx's renumbering is restated)
   * tests/golden/one_sided_kat.json  the 9 known answers of
                                    tests/test_one_sided_integral.py:32,63,88
+  * tests/golden/flower_data.npz   input points + outputs of the four problem-data functions of
+                                   demo/weak-dirichlet/flower/data.py (pure numpy, so this one
+                                   module of the reference IS importable here): golden vectors
+                                   for the restatement in tests/flower_data.py (a13)
 The known-answer values are plain numbers asserted by the reference's test; they are
 restated here as data.
 """
@@ -97,6 +101,20 @@ def main():
     }
     with open(os.path.join(HERE, "one_sided_kat.json"), "w") as f:
         json.dump(kat, f, indent=1)
+
+    # golden vectors of the demo's data functions, produced by the reference itself
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ref_flower_data", "/root/reference/demo/weak-dirichlet/flower/data.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    rng = np.random.default_rng(20261003)
+    x = np.concatenate([rng.uniform(-4.5, 4.5, (2, 4000)),
+                        np.stack(np.meshgrid(np.linspace(-4.5, 4.5, 33),
+                                             np.linspace(-4.5, 4.5, 33))).reshape(2, -1)], axis=1)
+    np.savez_compressed(os.path.join(HERE, "flower_data.npz"), x=x,
+                        levelset=ref.levelset(x), detection_levelset=ref.detection_levelset(x),
+                        source_term=ref.source_term(x), dirichlet_data=ref.dirichlet_data(x))
 
 
 if __name__ == "__main__":

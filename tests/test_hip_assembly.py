@@ -169,3 +169,49 @@ def test_phase_api_equals_native_solve(P):
     st = ds.solve(out, profile_spmv=False)
     assert st["iterations"] == res["iterations"]
     assert torch.allclose(out, native, rtol=0, atol=1e-9 * float(native.abs().max()))
+
+
+def test_config0_flower_2d(P):
+    """BASELINE configs[0]: 2-D weak-Dirichlet Poisson, 'flower' level-set, P1, 128x128 background
+    mesh on [-4.5,4.5]^2, detection degree 1, box mode, single-layer cut, gamma = sigma = 1
+    (demo/weak-dirichlet/flower/main.py:42-62): HIP vs the CPU oracle, stage by stage."""
+    import flower_data as F
+    from oracle import meshgen
+    from phifem_amd.mesh_scripts import NodalFunction
+    n = 128
+    mesh = P.create_rectangle([[-4.5, -4.5], [4.5, 4.5]], [n, n])
+    x = mesh.x
+    xo, co = meshgen.create_box([-4.5, -4.5], [4.5, 4.5], [n, n])
+    assert np.array_equal(x, xo) and np.array_equal(mesh.cells, co)
+    assert (mesh.nc, mesh.nv, mesh.nf) == (32768, 16641, 49408)   # SURVEY 8(a) sizes
+    det = F.detection_levelset(x.T)
+    phi = F.levelset(x.T)
+    f = F.source_term(x.T)
+    ud = F.dirichlet_data(x.T)
+    topo = Topology("triangle", co, x.shape[0])
+    topo.c2f, topo.f2c, topo.nf = mesh.c2f.astype(np.int64), mesh.f2c.astype(np.int64), mesh.nf
+    topo.boundary_facets = np.flatnonzero(topo.f2c[:, 1] < 0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hc, hf, _, hmeas, _ = P.compute_tags_measures(mesh, NodalFunction(det), 1, box_mode=True,
+                                                      single_layer_cut=True)
+        oc, of, _, omeas, _, _ = T.compute_tags_measures("triangle", x, topo, T.NodalP1(det), 1,
+                                                         box_mode=True, single_layer_cut=True)
+    assert np.array_equal(hc.values, oc.values) and np.array_equal(hf.values, of.values)
+    assert np.array_equal(hmeas(100), omeas(100)) and np.array_equal(hmeas(101), omeas(101))
+    assert set(np.unique(hc.values)) == {1, 2, 3}
+    A, b, act = OA.assemble_poisson_wd(topo, x, mesh.cell_tag_values(), mesh.facet_tag_values(),
+                                       hmeas(100), phi, f, ud)
+    s = P.PhiFEMSolver(mesh, pen_coef=1.0, stab_coef=1.0)
+    s.assemble(phi, f, ud)
+    H, rhs, dof = hip_matrix(s)
+    idx = np.flatnonzero(act)
+    Ao = A[idx][:, idx].tocsr()
+    Ao.sort_indices()
+    assert np.array_equal(dof, idx) and np.array_equal(H.indices, Ao.indices)
+    assert np.abs(H.data - Ao.data).max() <= MAT_TOL * np.abs(Ao.data).max()
+    assert np.abs(rhs - b[idx]).max() <= MAT_TOL * np.abs(b).max()
+    w = s.solve(rtol=1e-11)
+    wo = OA.solve_direct(A, b, act)
+    assert np.abs(w - wo).max() <= SOL_TOL * np.abs(wo).max()
+    assert w[:mesh.nv].max() > 0.0 and np.all(w[~act] == 0.0)

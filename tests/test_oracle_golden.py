@@ -96,3 +96,14 @@ def test_one_sided_integrals(name, deg):
     # tests/test_one_sided_integral.py:167-168 (np.isclose, atol=1e-20, default rtol)
     assert np.isclose(v100, KAT[name]["values"][0], atol=1.0e-20)
     assert np.isclose(v101, KAT[name]["values"][1], atol=1.0e-20)
+
+
+def test_flower_data_against_reference_vectors():
+    """a13: tests/flower_data.py against vectors produced by the reference's own
+    demo/weak-dirichlet/flower/data.py (tests/golden/make_fixtures.py)."""
+    import flower_data as F
+    g = np.load(os.path.join(HERE, "golden", "flower_data.npz"))
+    x = g["x"]
+    for name in ("levelset", "detection_levelset", "source_term", "dirichlet_data"):
+        got = getattr(F, name)(x)
+        assert np.array_equal(got, g[name]), name
