@@ -148,7 +148,11 @@ __device__ __forceinline__ void load_cell(const int32_t *__restrict__ cells,
   }
 }
 
+// Column keys inside the slot tables are FULL DoF indices (u: v, p: nv + v), straight from the
+// connectivity; the compaction kernel translates them to active rows (one dof-map lookup per
+// stored entry instead of one per contribution).
 struct AsmArgs {
+  int32_t nv;
   const int32_t *cells;
   const double *x;
   const int8_t *ctags;
@@ -175,7 +179,6 @@ __device__ __forceinline__ double mult4(int i, int j, int k, int l) {
 // Work lists: the element kernels run over COMPACTED lists (inside cells, cut cells, stabilised
 // facets) with one lane per entry of the element tensor, so a wavefront issues 64 independent
 // slot updates instead of one lane walking a whole element matrix.
-struct SelInside { const int8_t *t; __host__ __device__ bool operator()(const int32_t &c) const { return (t[c] & PHX_TAG_MASK) == 1; } };
 struct SelCut { const int8_t *t; __host__ __device__ bool operator()(const int32_t &c) const { return (t[c] & PHX_TAG_MASK) == 2; } };
 struct SelGhostFacet {
   const int8_t *ft; const int32_t *f2c;
@@ -185,37 +188,101 @@ struct SelGhostFacet {
   }
 };
 
-// --- inside cells, main.py:113 + :143: 16 lanes per cell, lane = (i, j) of the u-u block --------
+// --- vertex -> cell adjacency (once per mesh) ---------------------------------------------------
+__global__ void k_v2c_count(int64_t nc, int nvpc, const int32_t *__restrict__ cells,
+                            unsigned long long *__restrict__ cnt) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nc * nvpc) return;
+  atomicAdd(&cnt[cells[i]], 1ull);
+}
+__global__ void k_v2c_fill(int64_t nc, int nvpc, const int32_t *__restrict__ cells,
+                           const int64_t *__restrict__ ptr, unsigned long long *__restrict__ cursor,
+                           int32_t *__restrict__ idx) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nc * nvpc) return;
+  const int32_t v = cells[i];
+  const unsigned long long k = atomicAdd(&cursor[v], 1ull);
+  idx[ptr[v] + (int64_t)k] = (int32_t)(i / nvpc);
+}
+
+// plain (non-atomic) insert into a row this thread owns exclusively; same hash as slot_add
+__device__ __forceinline__ void slot_add_owned(const Slots &s, int32_t row, int32_t col, double v) {
+  int32_t *rc = s.cols + (int64_t)row * s.W;
+  double *rv = s.vals + (int64_t)row * s.W;
+  const int mask = s.W - 1;
+  int k = (int)(((uint32_t)col * 2654435761u) >> 16) & mask;
+  for (int t = 0; t < s.W; ++t, k = (k + 1) & mask) {
+    const int32_t cur = rc[k];
+    if (cur == -1) { rc[k] = col; rv[k] = v; return; }
+    if (cur == col) { rv[k] += v; return; }
+  }
+  atomicOr(s.overflow, 1);
+}
+
+// --- stiffness + source rows, main.py:113 + :143 over dx((1,2)): one thread per ACTIVE VERTEX
+// gathers row i of every incident element tensor into a thread-private table in LDS (32 slots,
+// slot-major so that lanes sit on consecutive banks), then writes the row once.  No atomics: the
+// kernel runs first on the cleared slot tables and every row has exactly one writer. --------------
+#define ROW_LDS_SLOTS 32
+#define ROW_THREADS 128
+struct RowAcc {
+  int32_t *col;   // [ROW_LDS_SLOTS][ROW_THREADS]
+  double *val;
+  int t;
+  const Slots *spill;
+  int32_t row;
+  __device__ __forceinline__ void add(int32_t key, double v) {
+    int k = (int)(((uint32_t)key * 2654435761u) >> 16) & (ROW_LDS_SLOTS - 1);
+    for (int q = 0; q < ROW_LDS_SLOTS; ++q, k = (k + 1) & (ROW_LDS_SLOTS - 1)) {
+      const int32_t cur = col[k * ROW_THREADS + t];
+      if (cur == -1) { col[k * ROW_THREADS + t] = key; val[k * ROW_THREADS + t] = v; return; }
+      if (cur == key) { val[k * ROW_THREADS + t] += v; return; }
+    }
+    slot_add_owned(*spill, row, key, v);  // vertex of very high valence: straight to the row
+  }
+};
+
 template <int D>
-__global__ void __launch_bounds__(256) k_assemble_inside(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
-  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  // The four cells of a wavefront come from the four quarters of the list: neighbouring cells
-  // share rows, and same-address atomics inside one wave-instruction serialise.
-  const int64_t quarter = (nlist + 3) >> 2;
-  const int64_t e = (gid >> 6) + ((gid >> 4) & 3) * quarter;
-  if ((gid >> 6) >= quarter || e >= nlist) return;
+__global__ void __launch_bounds__(ROW_THREADS)
+k_assemble_rows(int64_t nv, const int64_t *__restrict__ v2c_ptr, const int32_t *__restrict__ v2c_idx, AsmArgs A) {
+  __shared__ int32_t lcol[ROW_LDS_SLOTS * ROW_THREADS];
+  __shared__ double lval[ROW_LDS_SLOTS * ROW_THREADS];
+  const int64_t vtx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (vtx >= nv) return;
+  const int32_t row = A.du[vtx];
+  if (row < 0) return;
+  RowAcc acc{lcol, lval, (int)threadIdx.x, &A.slots, row};
+  for (int k = 0; k < ROW_LDS_SLOTS; ++k) lcol[k * ROW_THREADS + threadIdx.x] = -1;
   constexpr int N = D + 1;
-  const int i = (int)(gid & 15) >> 2, j = (int)(gid & 3);
-  if (i >= N || j >= N) return;
-  const int64_t c = list[e];
-  int32_t v[N];
-  double X[N][D];
-  load_cell<D>(A.cells, A.x, c, v, X);
-  Geo<D> G;
-  simplex_geometry<D>(X, G);
-  double k = 0.0;
-  for (int d = 0; d < D; ++d) k += G.g[i][d] * G.g[j][d];
-  const int32_t ri = A.du[v[i]];
-  slot_add(A.slots, ri, A.du[v[j]], k * G.vol);
-  if (j == 0) {
-    constexpr double c2 = D == 3 ? 1.0 / 20.0 : 1.0 / 12.0;
+  constexpr double c2 = D == 3 ? 1.0 / 20.0 : 1.0 / 12.0;
+  double rhs = 0.0;
+  for (int64_t e = v2c_ptr[vtx]; e < v2c_ptr[vtx + 1]; ++e) {
+    const int64_t c = v2c_idx[e];
+    const int t = A.ctags[c] & PHX_TAG_MASK;
+    if (t != 1 && t != 2) continue;
+    int32_t v[N];
+    double X[N][D];
+    load_cell<D>(A.cells, A.x, c, v, X);
+    Geo<D> G;
+    simplex_geometry<D>(X, G);
+    int i = 0;
     double sf = 0.0;
-    for (int q = 0; q < N; ++q) sf += A.f[v[q]];
-    unsafeAtomicAdd(&A.rhs[ri], G.vol * c2 * (sf + A.f[v[i]]));  // int f_h N_i
+    for (int q = 0; q < N; ++q) { if (v[q] == (int32_t)vtx) i = q; sf += A.f[v[q]]; }
+    for (int j = 0; j < N; ++j) {
+      double k = 0.0;
+      for (int d = 0; d < D; ++d) k += G.g[i][d] * G.g[j][d];
+      acc.add(v[j], k * G.vol);
+    }
+    rhs += G.vol * c2 * (sf + A.f[vtx]);  // int f_h N_i
+  }
+  A.rhs[row] = rhs;
+  for (int k = 0; k < ROW_LDS_SLOTS; ++k) {
+    const int32_t key = lcol[k * ROW_THREADS + threadIdx.x];
+    if (key != -1) slot_add_owned(A.slots, row, key, lval[k * ROW_THREADS + threadIdx.x]);
   }
 }
 
-// --- cut cells, main.py:113,115-122,143-149: 64 lanes per cell, lane = (a, b) of the mixed
+// --- cut cells, main.py:115-122,144-149 (penalisation): 64 lanes per cell, lane = (a, b) of the mixed
 // (u,p) x (u,p) element tensor, a = i (u_i) or N + i (p_i) ---------------------------------------
 template <int D>
 __global__ void __launch_bounds__(256) k_assemble_cut(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
@@ -242,9 +309,8 @@ __global__ void __launch_bounds__(256) k_assemble_cut(int64_t nlist, const int32
   const double gam = A.gamma * G.vol;
   double val;
   if (!ap && !bp) {
-    double k = 0.0;
-    for (int d = 0; d < D; ++d) k += G.g[i][d] * G.g[j][d];
-    val = k * G.vol + gam * h1 * h1 * c2 * (i == j ? 2.0 : 1.0);          // :113 + :115-122 (u,v)
+    val = gam * h1 * h1 * c2 * (i == j ? 2.0 : 1.0);                      // :115-122 (u,v); :113 is
+                                                                           // in k_assemble_rows
   } else if (ap != bp) {
     // int N_i N_j phi_h = |K| c3 (1+d_ij)(S + phi_i + phi_j)
     val = -gam * h1 * h1 * h1 * c3 * (i == j ? 2.0 : 1.0) * (sp + ph[i] + ph[j]);   // (u,q),(p,v)
@@ -255,17 +321,14 @@ __global__ void __launch_bounds__(256) k_assemble_cut(int64_t nlist, const int32
     val = gam * h1 * h1 * h1 * h1 * c4 * m4;                               // (p,q)
   }
   const int32_t row = ap ? A.dp[v[i]] : A.du[v[i]];
-  const int32_t col = bp ? A.dp[v[j]] : A.du[v[j]];
+  const int32_t col = bp ? A.nv + v[j] : v[j];
   slot_add(A.slots, row, col, val);
   if (b == 0) {
     double ud[N], sud = 0.0;
     for (int q = 0; q < N; ++q) { ud[q] = A.ud[v[q]]; sud += ud[q]; }
     double r;
     if (!ap) {
-      double sf = 0.0;
-      for (int q = 0; q < N; ++q) sf += A.f[v[q]];
-      r = G.vol * c2 * (sf + A.f[v[i]])                                    // :143
-          + gam * h1 * h1 * c2 * (sud + ud[i]);                            // :147 (v part)
+      r = gam * h1 * h1 * c2 * (sud + ud[i]);                              // :147 (v part)
     } else {
       double bq = 0.0;
       for (int q = 0; q < N; ++q) bq += ud[q] * (i == q ? 2.0 : 1.0) * (sp + ph[i] + ph[q]);
@@ -300,25 +363,30 @@ __global__ void k_assemble_ds(int64_t nent, const int64_t *__restrict__ ent_pack
   simplex_geometry<D>(X, G);
   double k = 0.0;
   for (int d = 0; d < D; ++d) k += G.g[j][d] * G.g[lf][d];
-  slot_add(A.slots, A.du[v[i]], A.du[v[j]], k * G.vol);
+  slot_add(A.slots, A.du[v[i]], v[j], k * G.vol);
 }
 
 // --- ghost penalty, main.py:129-134:  sigma avg(h) int_F [grad u . n][grad v . n] on dS((2,3)) ---
-// 64 lanes per facet, lane = (a, b) over the 2(D+1) vertices of the two cells.
+// The two cells share the D vertices of F, so the macro-element has D+2 distinct vertices: the
+// jump coefficient of a shared vertex is the sum of its two one-sided ones.  One 64-lane group per
+// facet, lane = (a, b) over the D+2 distinct vertices: 25 (16) atomics per facet, not 64 (36).
 template <int D>
 __global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
   const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t e = gid >> 6;
+  const int64_t e = gid >> 5;
   if (e >= nlist) return;
-  constexpr int N = D + 1;
-  const int a = (int)(gid & 63) >> 3, b = (int)(gid & 7);
-  if (a >= 2 * N || b >= 2 * N) return;
+  constexpr int N = D + 1, M = D + 2;
+  const int a = (int)(gid & 31) / M, b = (int)(gid & 31) % M;
+  if (a >= M) return;
   const int64_t f = list[e];
-  double Ja = 0.0, Jb = 0.0, hsum = 0.0, area = 0.0;
-  int32_t da = -1, db = -1;
+  // distinct vertices: 0..D = the "+" cell's, D+1 = the "-" cell's vertex opposite F
+  int32_t vp[N], vm[N];
+  double Jp[N], Jm[N], hsum = 0.0, area = 0.0;
+  int lfm = 0;
   for (int side = 0; side < 2; ++side) {
     const int64_t c = A.f2c[2 * f + side];
-    int32_t v[N];
+    int32_t *v = side == 0 ? vp : vm;
+    double *J = side == 0 ? Jp : Jm;
     double X[N][D];
     load_cell<D>(A.cells, A.x, c, v, X);
     Geo<D> G;
@@ -326,26 +394,30 @@ __global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const in
     int lf = 0;
     for (int k = 0; k < N; ++k)
       if (A.c2f[c * N + k] == (int32_t)f) lf = k;
+    if (side == 1) lfm = lf;
     double gn = 0.0;
     for (int d = 0; d < D; ++d) gn += G.g[lf][d] * G.g[lf][d];
     gn = sqrt(gn);
     if (side == 0) area = D * G.vol * gn;
     hsum += G.h;
-    // grad N_j . n with n outward from this side's cell
-    if (a / N == side) {
+    for (int j = 0; j < N; ++j) {
       double s = 0.0;
-      for (int d = 0; d < D; ++d) s += G.g[a % N][d] * G.g[lf][d];
-      Ja = -s / gn;
-      da = A.du[v[a % N]];
-    }
-    if (b / N == side) {
-      double s = 0.0;
-      for (int d = 0; d < D; ++d) s += G.g[b % N][d] * G.g[lf][d];
-      Jb = -s / gn;
-      db = A.du[v[b % N]];
+      for (int d = 0; d < D; ++d) s += G.g[j][d] * G.g[lf][d];
+      J[j] = -s / gn;  // grad N_j . n, n outward from this side's cell
     }
   }
-  slot_add(A.slots, da, db, A.sigma * 0.5 * hsum * area * Ja * Jb);
+  // combined jump coefficients on the distinct vertices
+  int32_t vd[M];
+  double Jd[M];
+  for (int j = 0; j < N; ++j) { vd[j] = vp[j]; Jd[j] = Jp[j]; }
+  vd[N] = vm[lfm];
+  Jd[N] = Jm[lfm];
+  for (int j = 0; j < N; ++j) {
+    if (j == lfm) continue;
+    for (int q = 0; q < N; ++q)
+      if (vp[q] == vm[j]) Jd[q] += Jm[j];
+  }
+  slot_add(A.slots, A.du[vd[a]], vd[b], A.sigma * 0.5 * hsum * area * Jd[a] * Jd[b]);
 }
 
 template <typename Pred>
@@ -381,8 +453,9 @@ __global__ void k_row_counts(int64_t n, int W, const int32_t *__restrict__ cols,
 
 __global__ void k_row_fill(int64_t n, int W, const int32_t *__restrict__ cols,
                            const double *__restrict__ vals, const int64_t *__restrict__ rowptr,
-                           int32_t *__restrict__ ocol, double *__restrict__ oval,
-                           double *__restrict__ diag) {
+                           int32_t nv, const int32_t *__restrict__ du,
+                           const int32_t *__restrict__ dp, int32_t *__restrict__ ocol,
+                           double *__restrict__ oval, double *__restrict__ diag) {
   const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
@@ -390,7 +463,7 @@ __global__ void k_row_fill(int64_t n, int W, const int32_t *__restrict__ cols,
   double v = 0.0;
   if (lane < W) {
     const int32_t cc = cols[row * W + lane];
-    if (cc != -1) { c = cc; v = vals[row * W + lane]; }
+    if (cc != -1) { c = cc < nv ? du[cc] : dp[cc - nv]; v = vals[row * W + lane]; }
   }
   if (c == (int32_t)row) diag[row] = v;
   for (int k = 2; k <= 64; k <<= 1)
@@ -505,17 +578,16 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   A.cells = m->cells; A.x = m->x; A.ctags = m->cell_tags; A.ftags = m->facet_tags;
   A.c2f = m->c2f; A.f2c = m->f2c; A.du = s->dof_of_vertex_u; A.dp = s->dof_of_vertex_p;
   A.phi = dphi; A.f = df; A.ud = dud; A.gamma = pen_coef; A.sigma = stab_coef;
-  A.rhs = s->rhs; A.slots = sl;
+  A.rhs = s->rhs; A.slots = sl; A.nv = (int32_t)m->nv;
   // ---- element kernels over compacted work lists
-  int32_t *l_in = nullptr, *l_cut = nullptr, *l_fac = nullptr;
-  int64_t n_in = 0, n_cut = 0, n_fac = 0;
-  PHX_CHECK(build_list(m, m->nc, SelInside{m->cell_tags}, &l_in, &n_in));
+  int32_t *l_cut = nullptr, *l_fac = nullptr;
+  int64_t n_cut = 0, n_fac = 0;
   PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut));
   PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac));
-  if (n_in > 0) {
-    const dim3 g((unsigned)phx_div_up(((n_in + 3) / 4) * 64, 256));
-    if (D == 2) k_assemble_inside<2><<<g, block, 0, m->stream>>>(n_in, l_in, A);
-    else k_assemble_inside<3><<<g, block, 0, m->stream>>>(n_in, l_in, A);
+  {
+    const dim3 g((unsigned)phx_div_up(m->nv, ROW_THREADS)), b(ROW_THREADS);
+    if (D == 2) k_assemble_rows<2><<<g, b, 0, m->stream>>>(m->nv, m->v2c_ptr, m->v2c_idx, A);
+    else k_assemble_rows<3><<<g, b, 0, m->stream>>>(m->nv, m->v2c_ptr, m->v2c_idx, A);
   }
   if (n_cut > 0) {
     const dim3 g((unsigned)phx_div_up(n_cut * 64, 256));
@@ -540,7 +612,7 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   }
   PHX_HIP(hipGetLastError());
   if (n_fac > 0) {
-    const dim3 g((unsigned)phx_div_up(n_fac * 64, 256));
+    const dim3 g((unsigned)phx_div_up(n_fac * 32, 256));
     if (D == 2) k_assemble_facets<2><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
     else k_assemble_facets<3><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
   }
@@ -548,7 +620,7 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   int overflow = 0;
   PHX_HIP(hipMemcpyAsync(&overflow, sl.overflow, sizeof(int), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(l_in)); PHX_HIP(hipFree(l_cut)); PHX_HIP(hipFree(l_fac));
+  PHX_HIP(hipFree(l_cut)); PHX_HIP(hipFree(l_fac));
   if (overflow) {
     PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
     phx_system_destroy(s);
@@ -570,13 +642,34 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   PHX_HIP(hipMalloc(&s->val, sizeof(double) * (size_t)nnz));
   PHX_HIP(hipMalloc(&s->diag, sizeof(double) * (size_t)s->n));
   PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
-  k_row_fill<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, s->rowptr, s->col, s->val, s->diag);
+  k_row_fill<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, s->rowptr, (int32_t)m->nv,
+                                                  s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(hipFree(counts));
   PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
   PHX_CHECK(phx_system_build_sell(s));
   *out = s;
+  return PHX_OK;
+}
+
+static int build_v2c(phx_mesh *m) {
+  if (m->v2c_ptr) return PHX_OK;
+  const int nvpc = m->ci.nvpc;
+  const int64_t tot = m->nc * nvpc;
+  unsigned long long *cnt = nullptr;
+  PHX_HIP(hipMalloc(&cnt, sizeof(unsigned long long) * (size_t)(m->nv + 1)));
+  PHX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * (size_t)(m->nv + 1), m->stream));
+  PHX_HIP(hipMalloc(&m->v2c_ptr, sizeof(int64_t) * (size_t)(m->nv + 1)));
+  PHX_HIP(hipMalloc(&m->v2c_idx, sizeof(int32_t) * (size_t)tot));
+  const dim3 block(256), grid((unsigned)phx_div_up(tot, 256));
+  k_v2c_count<<<grid, block, 0, m->stream>>>(m->nc, nvpc, m->cells, cnt);
+  PHX_CHECK(exclusive_sum<int64_t>(m, (const int64_t *)cnt, m->v2c_ptr, m->nv + 1));
+  PHX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * (size_t)(m->nv + 1), m->stream));
+  k_v2c_fill<<<grid, block, 0, m->stream>>>(m->nc, nvpc, m->cells, m->v2c_ptr, cnt, m->v2c_idx);
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(cnt));
   return PHX_OK;
 }
 
@@ -599,6 +692,7 @@ extern "C" int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab
               PHX_ERR_NOT_IMPLEMENTED, "assembly supports simplices (triangle, tetrahedron) only");
   PHX_REQUIRE(m->have_cell_tags && m->have_facet_tags, PHX_ERR_VALUE,
               "cell and facet tags must be computed before assembly");
+  PHX_CHECK(build_v2c(m));
   const double *dphi, *df, *dud;
   double *o1, *o2, *o3;
   PHX_CHECK(to_device(m, phi_h, loc, m->nv, &dphi, &o1));

@@ -65,6 +65,10 @@ struct phx_mesh {
   // slab of a partitioned box: facets on an ARTIFICIAL end plane are not background-boundary
   // facets; they stay untagged (0) and are left out of the `ds` detection
   uint8_t *facet_exempt = nullptr;  // [nf] or NULL
+  // vertex -> incident cells (CSR), built on first assembly: rows of the stiffness block are
+  // gathered by their owning vertex instead of scattered with atomics
+  int64_t *v2c_ptr = nullptr;  // [nv+1]
+  int32_t *v2c_idx = nullptr;  // [nc*nvpc]
   bool is_box = false;
   int64_t box_plane = 0, box_nlast = 0;
   int8_t *cell_tags = nullptr;   // [nc]

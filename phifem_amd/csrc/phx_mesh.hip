@@ -573,7 +573,7 @@ extern "C" int phx_mesh_destroy(phx_mesh *m) {
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {m->x, m->cells, m->c2f, m->f2c, m->bfacets, m->bfacet_ids, m->cell_tags,
-                  m->facet_tags, m->ent_buf[0], m->ent_buf[1], m->facet_exempt};
+                  m->facet_tags, m->ent_buf[0], m->ent_buf[1], m->facet_exempt, m->v2c_ptr, m->v2c_idx};
   for (void *p : ptrs) (void)hipFree(p);
   free(m->c_map_h); free(m->v_map_h);
   if (m->ev0) (void)hipEventDestroy(m->ev0);

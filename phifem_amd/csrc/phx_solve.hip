@@ -41,12 +41,16 @@ __global__ void k_row_lengths(int64_t n, const int64_t *__restrict__ rowptr,
                               uint32_t *__restrict__ keys, int32_t *__restrict__ rows,
                               unsigned long long *__restrict__ total, int64_t window) {
   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (r >= n) return;
   int len = 0;
-  for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
-    if (val[k] != 0.0 || col[k] == (int32_t)r) ++len;
-  if (len > 255) len = 255;
-  atomicAdd(total, (unsigned long long)len);
+  if (r < n) {
+    for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+      if (val[k] != 0.0 || col[k] == (int32_t)r) ++len;
+    if (len > 255) len = 255;
+  }
+  int wsum = len;
+  for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
+  if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(total, (unsigned long long)wsum);
+  if (r >= n) return;
   // ascending key = (window, 255-len): descending length inside each window
   keys[r] = ((uint32_t)(r / window) << 8) | (uint32_t)(255 - len);
   rows[r] = (int32_t)r;

@@ -227,28 +227,49 @@ k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restri
 // --- a6: (facet, cell) incidences of a one-sided measure -------------------------------------
 // key = 2*facet + position of the cell in the reversed link list (mesh_scripts.py:210-213), so a
 // host-side sort by key reproduces the reference's first-seen order.
-__global__ void k_collect_entities(int64_t nf, int facet_tag, int cell_mask,
-                                   const int32_t *__restrict__ f2c,
+__global__ void k_collect_entities(int64_t nf, const int32_t *__restrict__ f2c,
                                    const int32_t *__restrict__ c2f, int nfpc,
                                    const int8_t *__restrict__ ctags,
-                                   const int8_t *__restrict__ ftags, int64_t cap,
-                                   int64_t *__restrict__ out,
+                                   const int8_t *__restrict__ ftags, int64_t cap0, int64_t cap1,
+                                   int64_t *__restrict__ out0, int64_t *__restrict__ out1,
                                    unsigned long long *__restrict__ count) {
   const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (f >= nf || ftags[f] != facet_tag) return;
-  const int32_t c0 = f2c[2 * f], c1 = f2c[2 * f + 1];
+  const int lane = threadIdx.x & 63;
+  const int ft = f < nf ? ftags[f] : 0;
+  // which 0 -> ds(100): facets tagged 4 seen from cells {1,2}   (mesh_scripts.py:619-622)
+  // which 1 -> ds(101): facets tagged 3 seen from cells {2,3}   (mesh_scripts.py:623-626)
+  const int w = ft == 4 ? 0 : (ft == 3 ? 1 : -1);
+  if (__ballot(w >= 0) == 0ull) return;  // the common case: nothing to emit in this wave
+  const int cell_mask = w == 0 ? ((1 << 1) | (1 << 2)) : ((1 << 2) | (1 << 3));
+  int32_t c0 = -1, c1 = -1;
+  if (w >= 0) { c0 = f2c[2 * f]; c1 = f2c[2 * f + 1]; }
   for (int pos = 0; pos < 2; ++pos) {
-    const int32_t c = c1 >= 0 ? (pos == 0 ? c1 : c0) : (pos == 0 ? c0 : -1);
-    if (c < 0) continue;
-    const int t = ctags[c] & PHX_TAG_MASK;
-    if (t > 30 || !((cell_mask >> t) & 1)) continue;
-    int lf = 0;
-    for (int k = 0; k < nfpc; ++k)
-      if (c2f[(int64_t)c * nfpc + k] == (int32_t)f) lf = k;
-    const unsigned long long slot = atomicAdd(count, 1ull);
-    if ((int64_t)slot < cap) {
-      out[2 * slot] = 2 * f + pos;
-      out[2 * slot + 1] = ((int64_t)c << 8) | lf;
+    int32_t c = -1;
+    if (w >= 0) c = c1 >= 0 ? (pos == 0 ? c1 : c0) : (pos == 0 ? c0 : -1);
+    bool emit = false;
+    if (c >= 0) {
+      const int t = ctags[c] & PHX_TAG_MASK;
+      emit = t <= 30 && ((cell_mask >> t) & 1);
+    }
+    // wave-aggregated append: one atomic per wave and list instead of one per entry
+    for (int ww = 0; ww < 2; ++ww) {
+      const unsigned long long m = __ballot(emit && w == ww);
+      if (m == 0ull) continue;
+      const int leader = __ffsll((long long)m) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(&count[ww], (unsigned long long)__popcll(m));
+      base = __shfl(base, leader);
+      if (emit && w == ww) {
+        const int64_t slot = (int64_t)base + __popcll(m & ((1ull << lane) - 1ull));
+        int lf = 0;
+        for (int k = 0; k < nfpc; ++k)
+          if (c2f[(int64_t)c * nfpc + k] == (int32_t)f) lf = k;
+        int64_t *out = ww == 0 ? out0 : out1;
+        if (slot < (ww == 0 ? cap0 : cap1)) {
+          out[2 * slot] = 2 * f + pos;
+          out[2 * slot + 1] = ((int64_t)c << 8) | lf;
+        }
+      }
     }
   }
 }
@@ -524,26 +545,26 @@ int phx_collect_entities(phx_mesh *m) {
   if (m->have_entities) return PHX_OK;
   PHX_REQUIRE(m->have_cell_tags && m->have_facet_tags, PHX_ERR_VALUE,
               "cell and facet tags must be computed first");
-  // which 0 -> ds(100): facets tagged 4 seen from cells {1,2}   (mesh_scripts.py:619-622)
-  // which 1 -> ds(101): facets tagged 3 seen from cells {2,3}   (mesh_scripts.py:623-626)
   const int ftag[2] = {4, 3};
-  const int cmask[2] = {(1 << 1) | (1 << 2), (1 << 2) | (1 << 3)};
   unsigned long long *dcount = nullptr;
-  PHX_HIP(hipMalloc(&dcount, sizeof(unsigned long long)));
+  PHX_HIP(hipMalloc(&dcount, 2 * sizeof(unsigned long long)));
+  PHX_HIP(hipMemsetAsync(dcount, 0, 2 * sizeof(unsigned long long), m->stream));
+  int64_t cap[2];
   for (int w = 0; w < 2; ++w) {
     if (m->ent_buf[w]) { PHX_HIP(hipFree(m->ent_buf[w])); m->ent_buf[w] = nullptr; }
-    const int64_t cap = 2 * m->ftag_hist[ftag[w]] + 1;
-    PHX_HIP(hipMalloc(&m->ent_buf[w], sizeof(int64_t) * 2 * (size_t)cap));
-    PHX_HIP(hipMemsetAsync(dcount, 0, sizeof(unsigned long long), m->stream));
-    k_collect_entities<<<dim3((unsigned)phx_div_up(m->nf, 256)), dim3(256), 0, m->stream>>>(
-        m->nf, ftag[w], cmask[w], m->f2c, m->c2f, m->ci.nfpc, m->cell_tags, m->facet_tags, cap,
-        m->ent_buf[w], dcount);
-    PHX_HIP(hipGetLastError());
-    unsigned long long cnt = 0;
-    PHX_HIP(hipMemcpyAsync(&cnt, dcount, sizeof(cnt), hipMemcpyDeviceToHost, m->stream));
-    PHX_HIP(hipStreamSynchronize(m->stream));
-    PHX_REQUIRE((int64_t)cnt <= cap, PHX_ERR_HIP, "entity buffer overflow");
-    m->ent_count[w] = (int64_t)cnt;
+    cap[w] = 2 * m->ftag_hist[ftag[w]] + 1;
+    PHX_HIP(hipMalloc(&m->ent_buf[w], sizeof(int64_t) * 2 * (size_t)cap[w]));
+  }
+  k_collect_entities<<<dim3((unsigned)phx_div_up(m->nf, 256)), dim3(256), 0, m->stream>>>(
+      m->nf, m->f2c, m->c2f, m->ci.nfpc, m->cell_tags, m->facet_tags, cap[0], cap[1], m->ent_buf[0],
+      m->ent_buf[1], dcount);
+  PHX_HIP(hipGetLastError());
+  unsigned long long cnt[2] = {0, 0};
+  PHX_HIP(hipMemcpyAsync(cnt, dcount, sizeof(cnt), hipMemcpyDeviceToHost, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  for (int w = 0; w < 2; ++w) {
+    PHX_REQUIRE((int64_t)cnt[w] <= cap[w], PHX_ERR_HIP, "entity buffer overflow");
+    m->ent_count[w] = (int64_t)cnt[w];
   }
   PHX_HIP(hipFree(dcount));
   m->have_entities = true;
