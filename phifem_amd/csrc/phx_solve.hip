@@ -130,11 +130,14 @@ int phx_system_build_sell(phx_system *s) {
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(hipFree(dtotal));
   s->sell_true_nnz = (int64_t)htotal;
+  // only the bits that can differ are sorted: 8 length bits (+ the window index if windowed)
+  int end_bit = 8;
+  for (int64_t w = (n - 1) / g_sell_window; w > 0; w >>= 1) ++end_bit;
   size_t bytes = 0;
-  PHX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys2, rows, s->perm, (int)n, 0, 32, m->stream));
+  PHX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys2, rows, s->perm, (int)n, 0, end_bit, m->stream));
   void *tmp = nullptr;
   PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
-  PHX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys, keys2, rows, s->perm, (int)n, 0, 32, m->stream));
+  PHX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys, keys2, rows, s->perm, (int)n, 0, end_bit, m->stream));
   k_invert_perm<<<grid, block, 0, m->stream>>>(n, s->perm, s->iperm);
   s->nslices = phx_div_up(n, SELL_C);
   int64_t *widths = nullptr;

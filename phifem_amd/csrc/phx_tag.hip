@@ -6,6 +6,7 @@
 // loads, one byte written per entity).  This file is compiled with -ffp-contract=off: the tags
 // hang on exact float compares (mesh_scripts.py:343-347), so every sum is evaluated in the order
 // the oracle spells out and without fused multiply-add.
+#include <hipcub/hipcub.hpp>
 #include <string.h>
 
 #include <algorithm>
@@ -227,51 +228,48 @@ k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restri
 // --- a6: (facet, cell) incidences of a one-sided measure -------------------------------------
 // key = 2*facet + position of the cell in the reversed link list (mesh_scripts.py:210-213), so a
 // host-side sort by key reproduces the reference's first-seen order.
-__global__ void k_collect_entities(int64_t nf, const int32_t *__restrict__ f2c,
-                                   const int32_t *__restrict__ c2f, int nfpc,
-                                   const int8_t *__restrict__ ctags,
-                                   const int8_t *__restrict__ ftags, int64_t cap0, int64_t cap1,
-                                   int64_t *__restrict__ out0, int64_t *__restrict__ out1,
-                                   unsigned long long *__restrict__ count) {
-  const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const int ft = f < nf ? ftags[f] : 0;
-  // which 0 -> ds(100): facets tagged 4 seen from cells {1,2}   (mesh_scripts.py:619-622)
-  // which 1 -> ds(101): facets tagged 3 seen from cells {2,3}   (mesh_scripts.py:623-626)
-  const int w = ft == 4 ? 0 : (ft == 3 ? 1 : -1);
-  if (__ballot(w >= 0) == 0ull) return;  // the common case: nothing to emit in this wave
+// Facets tagged 3 or 4 are compacted first (hipcub select); a count / scan / fill over that short
+// list then places the entries without any contended counter (a single global append counter
+// serialises: the matches are ~1 per wavefront, 4 ms at 2*10^8 facets).
+//   which 0 -> ds(100): facets tagged 4 seen from cells {1,2}   (mesh_scripts.py:619-622)
+//   which 1 -> ds(101): facets tagged 3 seen from cells {2,3}   (mesh_scripts.py:623-626)
+struct SelTag34 {
+  const int8_t *ft;
+  __host__ __device__ bool operator()(const int32_t &f) const { return ft[f] == 3 || ft[f] == 4; }
+};
+
+template <bool FILL>
+__global__ void k_entities(int64_t nlist, const int32_t *__restrict__ list,
+                           const int32_t *__restrict__ f2c, const int32_t *__restrict__ c2f,
+                           int nfpc, const int8_t *__restrict__ ctags,
+                           const int8_t *__restrict__ ftags, int32_t *__restrict__ cnt0,
+                           int32_t *__restrict__ cnt1, const int32_t *__restrict__ off0,
+                           const int32_t *__restrict__ off1, int64_t *__restrict__ out0,
+                           int64_t *__restrict__ out1) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= nlist) return;
+  const int64_t f = list[i];
+  const int w = ftags[f] == 4 ? 0 : 1;
   const int cell_mask = w == 0 ? ((1 << 1) | (1 << 2)) : ((1 << 2) | (1 << 3));
-  int32_t c0 = -1, c1 = -1;
-  if (w >= 0) { c0 = f2c[2 * f]; c1 = f2c[2 * f + 1]; }
+  const int32_t c0 = f2c[2 * f], c1 = f2c[2 * f + 1];
+  int n = 0;
   for (int pos = 0; pos < 2; ++pos) {
-    int32_t c = -1;
-    if (w >= 0) c = c1 >= 0 ? (pos == 0 ? c1 : c0) : (pos == 0 ? c0 : -1);
-    bool emit = false;
-    if (c >= 0) {
-      const int t = ctags[c] & PHX_TAG_MASK;
-      emit = t <= 30 && ((cell_mask >> t) & 1);
+    const int32_t c = c1 >= 0 ? (pos == 0 ? c1 : c0) : (pos == 0 ? c0 : -1);
+    if (c < 0) continue;
+    const int t = ctags[c] & PHX_TAG_MASK;
+    if (t > 30 || !((cell_mask >> t) & 1)) continue;
+    if (FILL) {
+      int lf = 0;
+      for (int k = 0; k < nfpc; ++k)
+        if (c2f[(int64_t)c * nfpc + k] == (int32_t)f) lf = k;
+      int64_t *out = w == 0 ? out0 : out1;
+      const int64_t slot = (w == 0 ? off0[i] : off1[i]) + n;
+      out[2 * slot] = 2 * f + pos;
+      out[2 * slot + 1] = ((int64_t)c << 8) | lf;
     }
-    // wave-aggregated append: one atomic per wave and list instead of one per entry
-    for (int ww = 0; ww < 2; ++ww) {
-      const unsigned long long m = __ballot(emit && w == ww);
-      if (m == 0ull) continue;
-      const int leader = __ffsll((long long)m) - 1;
-      unsigned long long base = 0;
-      if (lane == leader) base = atomicAdd(&count[ww], (unsigned long long)__popcll(m));
-      base = __shfl(base, leader);
-      if (emit && w == ww) {
-        const int64_t slot = (int64_t)base + __popcll(m & ((1ull << lane) - 1ull));
-        int lf = 0;
-        for (int k = 0; k < nfpc; ++k)
-          if (c2f[(int64_t)c * nfpc + k] == (int32_t)f) lf = k;
-        int64_t *out = ww == 0 ? out0 : out1;
-        if (slot < (ww == 0 ? cap0 : cap1)) {
-          out[2 * slot] = 2 * f + pos;
-          out[2 * slot + 1] = ((int64_t)c << 8) | lf;
-        }
-      }
-    }
+    ++n;
   }
+  if (!FILL) { cnt0[i] = w == 0 ? n : 0; cnt1[i] = w == 1 ? n : 0; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -545,28 +543,59 @@ int phx_collect_entities(phx_mesh *m) {
   if (m->have_entities) return PHX_OK;
   PHX_REQUIRE(m->have_cell_tags && m->have_facet_tags, PHX_ERR_VALUE,
               "cell and facet tags must be computed first");
-  const int ftag[2] = {4, 3};
-  unsigned long long *dcount = nullptr;
-  PHX_HIP(hipMalloc(&dcount, 2 * sizeof(unsigned long long)));
-  PHX_HIP(hipMemsetAsync(dcount, 0, 2 * sizeof(unsigned long long), m->stream));
-  int64_t cap[2];
+  hipStream_t st = m->stream;
+  const int64_t nmax = m->ftag_hist[3] + m->ftag_hist[4];
   for (int w = 0; w < 2; ++w) {
     if (m->ent_buf[w]) { PHX_HIP(hipFree(m->ent_buf[w])); m->ent_buf[w] = nullptr; }
-    cap[w] = 2 * m->ftag_hist[ftag[w]] + 1;
-    PHX_HIP(hipMalloc(&m->ent_buf[w], sizeof(int64_t) * 2 * (size_t)cap[w]));
+    m->ent_count[w] = 0;
   }
-  k_collect_entities<<<dim3((unsigned)phx_div_up(m->nf, 256)), dim3(256), 0, m->stream>>>(
-      m->nf, m->f2c, m->c2f, m->ci.nfpc, m->cell_tags, m->facet_tags, cap[0], cap[1], m->ent_buf[0],
-      m->ent_buf[1], dcount);
-  PHX_HIP(hipGetLastError());
-  unsigned long long cnt[2] = {0, 0};
-  PHX_HIP(hipMemcpyAsync(cnt, dcount, sizeof(cnt), hipMemcpyDeviceToHost, m->stream));
-  PHX_HIP(hipStreamSynchronize(m->stream));
+  if (nmax == 0) {
+    for (int w = 0; w < 2; ++w) PHX_HIP(hipMalloc(&m->ent_buf[w], 16));
+    m->have_entities = true;
+    return PHX_OK;
+  }
+  int32_t *list = nullptr, *cnt = nullptr, *off = nullptr;
+  int64_t *dn = nullptr;
+  PHX_HIP(hipMalloc(&list, sizeof(int32_t) * (size_t)nmax));
+  PHX_HIP(hipMalloc(&cnt, sizeof(int32_t) * 2 * (size_t)(nmax + 1)));
+  PHX_HIP(hipMalloc(&off, sizeof(int32_t) * 2 * (size_t)(nmax + 1)));
+  PHX_HIP(hipMalloc(&dn, sizeof(int64_t)));
+  PHX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * 2 * (size_t)(nmax + 1), st));
+  {
+    hipcub::CountingInputIterator<int32_t> it(0);
+    SelTag34 pred{m->facet_tags};
+    size_t bytes = 0;
+    PHX_HIP(hipcub::DeviceSelect::If(nullptr, bytes, it, list, dn, (int)m->nf, pred, st));
+    void *tmp = nullptr;
+    PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+    PHX_HIP(hipcub::DeviceSelect::If(tmp, bytes, it, list, dn, (int)m->nf, pred, st));
+    PHX_HIP(hipStreamSynchronize(st));
+    PHX_HIP(hipFree(tmp));
+  }
+  int32_t *cnt0 = cnt, *cnt1 = cnt + (nmax + 1), *off0 = off, *off1 = off + (nmax + 1);
+  const dim3 grid((unsigned)phx_div_up(nmax, 256)), block(256);
+  k_entities<false><<<grid, block, 0, st>>>(nmax, list, m->f2c, m->c2f, m->ci.nfpc, m->cell_tags,
+                                            m->facet_tags, cnt0, cnt1, nullptr, nullptr, nullptr, nullptr);
   for (int w = 0; w < 2; ++w) {
-    PHX_REQUIRE((int64_t)cnt[w] <= cap[w], PHX_ERR_HIP, "entity buffer overflow");
-    m->ent_count[w] = (int64_t)cnt[w];
+    size_t bytes = 0;
+    int32_t *ci = w == 0 ? cnt0 : cnt1, *oi = w == 0 ? off0 : off1;
+    PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, ci, oi, (int)(nmax + 1), st));
+    void *tmp = nullptr;
+    PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+    PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, ci, oi, (int)(nmax + 1), st));
+    int32_t tot = 0;
+    PHX_HIP(hipMemcpyAsync(&tot, oi + nmax, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PHX_HIP(hipStreamSynchronize(st));
+    PHX_HIP(hipFree(tmp));
+    m->ent_count[w] = tot;
+    PHX_HIP(hipMalloc(&m->ent_buf[w], sizeof(int64_t) * 2 * (size_t)(tot > 0 ? tot : 1)));
   }
-  PHX_HIP(hipFree(dcount));
+  k_entities<true><<<grid, block, 0, st>>>(nmax, list, m->f2c, m->c2f, m->ci.nfpc, m->cell_tags,
+                                           m->facet_tags, nullptr, nullptr, off0, off1,
+                                           m->ent_buf[0], m->ent_buf[1]);
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipStreamSynchronize(st));
+  PHX_HIP(hipFree(list)); PHX_HIP(hipFree(cnt)); PHX_HIP(hipFree(off)); PHX_HIP(hipFree(dn));
   m->have_entities = true;
   return PHX_OK;
 }
