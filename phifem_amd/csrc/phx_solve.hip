@@ -28,6 +28,11 @@ static int64_t g_sell_window = (int64_t)1 << 40;
 // Dot products: every block adds its partial sum to one of NSLOT accumulators (one 64-byte line
 // each, so the memory-side atomics of different blocks do not queue on one address); a one-wave
 // kernel folds the slots into the scalar the next phase reads.
+#ifdef PHX_SPMV_NT
+#define NT_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define NT_LOAD(p) (*(p))
+#endif
 #define NSLOT 64
 #define SLOT_STRIDE 8
 #define P_OFF 16
@@ -198,17 +203,18 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
     const int32_t *c = scol + base + lane;
     const double *v = sval + base + lane;
     int k = 0;
+    // the matrix is streamed once: non-temporal loads keep it from evicting x out of L2 / MALL
     for (; k + 4 <= width; k += 4) {
-      const int32_t c0 = c[(k + 0) * SELL_C], c1 = c[(k + 1) * SELL_C];
-      const int32_t c2 = c[(k + 2) * SELL_C], c3 = c[(k + 3) * SELL_C];
-      const double v0 = v[(k + 0) * SELL_C], v1 = v[(k + 1) * SELL_C];
-      const double v2 = v[(k + 2) * SELL_C], v3 = v[(k + 3) * SELL_C];
+      const int32_t c0 = NT_LOAD(&c[(k + 0) * SELL_C]), c1 = NT_LOAD(&c[(k + 1) * SELL_C]);
+      const int32_t c2 = NT_LOAD(&c[(k + 2) * SELL_C]), c3 = NT_LOAD(&c[(k + 3) * SELL_C]);
+      const double v0 = NT_LOAD(&v[(k + 0) * SELL_C]), v1 = NT_LOAD(&v[(k + 1) * SELL_C]);
+      const double v2 = NT_LOAD(&v[(k + 2) * SELL_C]), v3 = NT_LOAD(&v[(k + 3) * SELL_C]);
       acc += v0 * x[c0];
       acc += v1 * x[c1];
       acc += v2 * x[c2];
       acc += v3 * x[c3];
     }
-    for (; k < width; ++k) acc += v[k * SELL_C] * x[c[k * SELL_C]];
+    for (; k < width; ++k) acc += NT_LOAD(&v[k * SELL_C]) * x[NT_LOAD(&c[k * SELL_C])];
     row = s * SELL_C + lane;
     if (row < n) {
       if (own && !own[row]) acc = 0.0;  // ghost rows stay zero; the halo exchange refreshes them
