@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cubes", type=int, default=256, help="cubes per axis per GPU")
     ap.add_argument("--rtol", type=float, default=1e-8)
-    ap.add_argument("--cpu-n", type=int, default=40, help="box size of the CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=64, help="box size of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 

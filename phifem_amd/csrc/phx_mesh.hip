@@ -649,11 +649,9 @@ extern "C" int phx_mesh_get_array(phx_mesh *m, int which, void *out, int loc) {
       if (loc != PHX_DEVICE) { PHX_HIP(hipMalloc(&tmp, sizeof(int32_t) * (size_t)n)); dst = tmp; }
       k_widen_tags<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, m->stream>>>(
           n, fac ? m->facet_tags : m->cell_tags, dst);
-      if (tmp) {
-        PHX_HIP(hipMemcpyAsync(out, tmp, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
-        PHX_HIP(hipStreamSynchronize(m->stream));
-        PHX_HIP(hipFree(tmp));
-      }
+      if (tmp) PHX_HIP(hipMemcpyAsync(out, tmp, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
+      PHX_HIP(hipStreamSynchronize(m->stream));  // the caller may read `out` from another stream
+      if (tmp) PHX_HIP(hipFree(tmp));
       return PHX_OK;
     }
     default:

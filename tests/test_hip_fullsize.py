@@ -1,0 +1,115 @@
+"""BASELINE configs[1] at FULL size (256^3 Kuhn box, 1.0e8 tetrahedra) on the GPU: the oracle cannot
+run at this size in seconds, so parity is checked through size-independent properties."""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N = 256
+
+
+@pytest.fixture(scope="module")
+def full():
+    import torch
+    import phifem_amd as P
+    from phifem_amd.distributed import SlabProblem
+    assert P._lib.device_count() > 0
+    prob = SlabProblem(N, rtol=1e-9)
+    prob.setup()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = prob.step()
+    return P, prob, res
+
+
+def test_counts_and_tag_partition(full):
+    import ctypes as C
+    P, prob, res = full
+    m = prob.mesh
+    assert (m.nc, m.nv) == (6 * N ** 3, (N + 1) ** 3)          # 100 663 296 tets, 16 974 593 vertices
+    assert m.nf == 12 * N ** 3 + 6 * N ** 2                    # 201 719 808 faces
+    assert m.nbf == 12 * N ** 2
+    hc, hf = (C.c_int64 * 4)(), (C.c_int64 * 7)()
+    P._lib.check(P._lib.lib.phx_mesh_tag_histogram(m._h, hc, hf))
+    assert hc[0] == 0 and sum(hc) == m.nc                      # every cell classified
+    assert hf[0] == 0 and sum(hf) == m.nf                      # tags 1..6 partition the facets
+    assert hf[6] == 0                                          # no direct inside/outside contact
+    # inside + cut volume brackets the unit ball; inside alone is below it
+    h3 = (3.0 / N) ** 3 / 6.0
+    ball = 4.0 / 3.0 * np.pi
+    assert hc[1] * h3 < ball < (hc[1] + hc[2]) * h3
+    assert abs((hc[1] + 0.5 * hc[2]) * h3 - ball) < 0.02 * ball
+    # Gamma_h (tag 4) is a closed triangulated surface: every edge is shared by two of its
+    # triangles, so the triangle count is even; its area brackets the sphere's loosely
+    assert hf[4] % 2 == 0
+
+
+def test_tagging_is_idempotent(full):
+    P, prob, res = full
+    from phifem_amd.mesh_scripts import NodalFunction, _tag_cells, _tag_facets
+    import torch
+    m = prob.mesh
+    dev = prob.phi.device
+    before_c = torch.empty(m.nc, dtype=torch.int32, device=dev)
+    before_f = torch.empty(m.nf, dtype=torch.int32, device=dev)
+    L = P._lib
+    import ctypes as C
+    L.check(L.lib.phx_mesh_get_array(m._h, L.ARR_CELL_TAGS, C.c_void_p(before_c.data_ptr()), L.DEVICE))
+    L.check(L.lib.phx_mesh_get_array(m._h, L.ARR_FACET_TAGS, C.c_void_p(before_f.data_ptr()), L.DEVICE))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        st = _tag_cells(m, NodalFunction(prob.phi), 1, single_layer_cut=True)
+        _tag_facets(m, st, 1)
+    after_c = torch.empty_like(before_c)
+    after_f = torch.empty_like(before_f)
+    L.check(L.lib.phx_mesh_get_array(m._h, L.ARR_CELL_TAGS, C.c_void_p(after_c.data_ptr()), L.DEVICE))
+    L.check(L.lib.phx_mesh_get_array(m._h, L.ARR_FACET_TAGS, C.c_void_p(after_f.data_ptr()), L.DEVICE))
+    assert torch.equal(before_c, after_c) and torch.equal(before_f, after_f)
+
+
+def test_solution_satisfies_the_exported_system(full):
+    """Independent residual: export the CSR, multiply on the host with scipy."""
+    import scipy.sparse as sp
+    P, prob, res = full
+    s = prob.solver
+    rowptr, col, val, rhs, dof = s.export_csr()
+    A = sp.csr_matrix((val, col, rowptr), shape=(rowptr.size - 1,) * 2)
+    w = prob.out.cpu().numpy()
+    r = A @ w[dof] - rhs
+    assert np.linalg.norm(r) <= 5e-9 * np.linalg.norm(rhs)
+    assert res["relres"] <= 1e-9
+    inactive = np.ones(w.size, dtype=bool)
+    inactive[dof] = False
+    assert np.all(w[inactive] == 0.0)
+    # every row has a positive diagonal and the pattern is structurally symmetric
+    assert np.all(A.diagonal() > 0.0)
+    assert (abs(A) > 0).astype(np.int8).sum() <= A.nnz
+    # discretisation error against the manufactured solution at the inside vertices
+    uex = prob.u_ex.cpu().numpy()
+    nv = prob.mesh.nv
+    u_act = dof[dof < nv]
+    err = np.abs(w[u_act] - uex[u_act]).max()
+    assert err < 2e-3
+
+
+def test_linear_patch_test_at_full_size(full):
+    """f = 0, u_D = u linear is reproduced exactly by P1 with p = 0, at any size."""
+    import torch
+    P, prob, res = full
+    m = prob.mesh
+    dev = prob.phi.device
+    import ctypes as C
+    L = P._lib
+    x = torch.empty((m.nv, 3), dtype=torch.float64, device=dev)
+    L.check(L.lib.phx_mesh_get_array(m._h, L.ARR_COORDS, C.c_void_p(x.data_ptr()), L.DEVICE))
+    ulin = x[:, 0] + 2.0 * x[:, 1] + 3.0 * x[:, 2] + 0.5
+    s = P.PhiFEMSolver(m)
+    info = s.assemble(prob.phi, torch.zeros_like(ulin), ulin)
+    out = torch.empty(2 * m.nv, dtype=torch.float64, device=dev)
+    s.solve(rtol=1e-12, max_iter=5000, out=out)
+    rowptr, col, val, rhs, dof = s.export_csr()
+    dof_t = torch.from_numpy(dof).to(dev)
+    u_act = dof_t[dof_t < m.nv]
+    assert float((out[u_act] - ulin[u_act]).abs().max()) < 1e-7
+    assert float(out[m.nv:].abs().max()) < 1e-5

@@ -265,3 +265,46 @@ def test_zero_denominator_warning(P):
     with pytest.warns(RuntimeWarning, match="zero everywhere on a cell"):
         P.compute_tags_measures(m, NodalFunction(np.zeros(m.nv)), 1, box_mode=True)
     assert np.all(m.cell_tag_values() == 2)
+
+
+@pytest.mark.parametrize("mesh_name", ["disk", "square_quad"])
+def test_degree_zero_detection(P, mesh_name):
+    """N = 0: one point at the barycentre (mesh_scripts.py:38-39,63-64,90-91): no cell is cut."""
+    m, topo, x = get_mesh(P, mesh_name)
+    f = MESHTAG_DATA["circle_in_circle"][1]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        oc, of, _, om, _, _ = T.compute_tags_measures(topo.cell_type, x, topo, f, 0, box_mode=True)
+        hc, hf, _, hm, _ = P.compute_tags_measures(m, f, 0, box_mode=True)
+    assert np.array_equal(hc.values, oc.values) and np.array_equal(hf.values, of.values)
+    # a cell is "cut" only when phi vanishes exactly at its barycentre (zero denominator -> 0.5)
+    assert np.count_nonzero(hc.values == 2) <= 4
+    assert np.any(hf.values == 6)          # inside and outside cells touch directly
+
+
+def test_all_inside_and_all_outside(P):
+    """Level-sets of one sign: `len(exterior_cells) == 0` branch (mesh_scripts.py:469-470) and the
+    empty Omega_h."""
+    from phifem_amd.mesh_scripts import NodalFunction
+    m, topo, x = get_mesh(P, "coarse_square")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for sign, ctag in ((-1.0, 1), (1.0, 3)):
+            nod = np.full(m.nv, sign)
+            oc, of, _, om, _, _ = T.compute_tags_measures(topo.cell_type, x, topo, T.NodalP1(nod), 1,
+                                                          box_mode=True)
+            hc, hf, _, hm, _ = P.compute_tags_measures(m, NodalFunction(nod), 1, box_mode=True)
+            assert np.all(hc.values == ctag)
+            assert np.array_equal(hf.values, of.values)
+            assert np.array_equal(hm(100), om(100)) and np.array_equal(hm(101), om(101))
+        # all inside: every background-boundary facet becomes Gamma_h (tag 4)
+        nod = np.full(m.nv, -1.0)
+        hc, hf, _, hm, _ = P.compute_tags_measures(m, NodalFunction(nod), 1, box_mode=True)
+        assert np.count_nonzero(hf.values == 4) == m.nbf and hm(100).size == 2 * m.nbf
+        # all outside: no cell is tagged 1 or 2 -> no sub-mesh, no system
+        nod = np.full(m.nv, 1.0)
+        with pytest.raises(ValueError):
+            P.compute_tags_measures(m, NodalFunction(nod), 1, box_mode=False)
+        P.compute_tags_measures(m, NodalFunction(nod), 1, box_mode=True)
+        with pytest.raises(ValueError):
+            P.PhiFEMSolver(m).assemble(nod, nod, nod)
