@@ -181,6 +181,21 @@ def tag_facets_values(topo, cell_tags, bnd_cell_cut, no_ext=None):
     return tags, count
 
 
+def reshape_map(offsets, array):
+    """mesh_scripts.py:195-214 (a5): ragged adjacency -> dense (n, max) padded with -1, links in
+    reverse order (`array[cumsum - n - 1]`), written as the reference's double loop."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    num = np.diff(offsets)
+    mx = int(num.max())
+    emap = -np.ones((num.size, mx), dtype=np.int64)
+    csum = num.cumsum()
+    for cnt in np.unique(num):
+        rows = np.where(num == cnt)[0]
+        for n in range(cnt):
+            emap[rows, n] = np.asarray(array)[csum[rows] - n - 1]
+    return emap, mx
+
+
 def integration_entities(topo, integration_cells, integration_facets):
     """mesh_scripts.py:137-192: flat int32 [cell, local facet, ...]."""
     integration_facets = np.asarray(integration_facets, dtype=np.int64)

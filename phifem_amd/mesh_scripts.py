@@ -143,6 +143,21 @@ def _evaluate_callable(mesh, f, degree):
     return np.ascontiguousarray(np.concatenate([vc, vf]))
 
 
+def _reshape_map(offsets, array):
+    """mesh_scripts.py:195-214 on a plain adjacency (offsets[n+1], array): dense (n, max_links)
+    table padded with -1, the links of an entity stored in REVERSE order.  The device kernels read
+    the CSR adjacencies directly; this host helper exists for callers of the reference's API."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    array = np.asarray(array)
+    num = np.diff(offsets)
+    width = int(num.max()) if num.size else 0
+    emap = -np.ones((num.size, width), dtype=np.int64)
+    for k in range(width):
+        has = num > k
+        emap[has, k] = array[offsets[1:][has] - k - 1]
+    return emap, width
+
+
 def _tag_cells(mesh, levelset, detection_degree, single_layer_cut=False):
     """mesh_scripts.py:284-390."""
     kind, p, loc, keep = _levelset_args(mesh, levelset, detection_degree)

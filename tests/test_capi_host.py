@@ -93,3 +93,26 @@ def test_device_entry_points_fail_loudly_without_gpu():
     import phifem_amd as P
     with pytest.raises(RuntimeError):
         P.create_box([0, 0], [1, 1], [2, 2])
+
+
+def test_reshape_map_matches_oracle():
+    """a5 (_reshape_map, mesh_scripts.py:195-214): reversed links, -1 padding."""
+    from oracle import tagging as OT
+    from phifem_amd.mesh_scripts import _reshape_map
+    rng = np.random.default_rng(3)
+    num = rng.integers(1, 6, size=40)
+    offsets = np.concatenate([[0], num.cumsum()])
+    array = rng.integers(0, 100, size=offsets[-1])
+    got, w = _reshape_map(offsets, array)
+    ref, w2 = OT.reshape_map(offsets, array)
+    assert w == w2 == num.max() and np.array_equal(got, ref)
+    assert np.array_equal(got[0, :num[0]], array[:num[0]][::-1])
+    # f->c of a real mesh: boundary facets have one link and a -1
+    ctype, x, cells = load_mesh("coarse_square")
+    topo = Topology(ctype, cells, x.shape[0])
+    cnt = (topo.f2c >= 0).sum(axis=1)
+    off = np.concatenate([[0], cnt.cumsum()])
+    arr = topo.f2c[topo.f2c >= 0]
+    got, w = _reshape_map(off, arr)
+    assert w == 2 and np.array_equal(got[cnt == 1][:, 1], -np.ones((cnt == 1).sum(), dtype=np.int64))
+    assert np.array_equal(got[cnt == 2], topo.f2c[cnt == 2][:, ::-1])
