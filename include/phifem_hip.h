@@ -67,8 +67,11 @@ enum phx_array {          /* phx_mesh_get_array selectors */
   PHX_ARR_F2C = 3,        /* i32 [nf*2], ascending cell index, -1 padded  */
   PHX_ARR_CELL_TAGS = 4,  /* i32 [nc]  values 1,2,3 (0 = unclassified)    */
   PHX_ARR_FACET_TAGS = 5, /* i32 [nf]  values 1..6                        */
-  PHX_ARR_BFACETS = 6     /* i32 [nbf*2] (cell, local facet) of the background-boundary facets,
+  PHX_ARR_BFACETS = 6,    /* i32 [nbf*2] (cell, local facet) of the background-boundary facets,
                              ascending facet index                        */
+  PHX_ARR_C2E = 7,        /* i32 [nc*nepc] cell -> edges (P2 DoFs), local edge order of basix:
+                             triangle (1,2),(0,2),(0,1); tetrahedron (2,3),(1,3),(1,2),(0,3),(0,2),(0,1) */
+  PHX_ARR_EDGES = 8       /* i32 [ne*2] vertex pair of every edge, ascending */
 };
 
 /* ------------------------------------------------------------------ misc ------------- */
@@ -109,6 +112,8 @@ int phx_mesh_create_box(int gdim, const double *lo, const double *hi, const int6
  * untagged (0) and take no part in the `ds` detection of mesh_scripts.py:434-461. */
 int phx_mesh_set_slab_faces(phx_mesh *m, int lower_is_cut, int upper_is_cut);
 int phx_mesh_destroy(phx_mesh *m);
+/* Number of edges (builds the edge numbering on first use; needed for P2 spaces). */
+int phx_mesh_edge_count(phx_mesh *m, int64_t *ne);
 /* counts[6] = {gdim, cell_type, nv, nc, nf, nbf} */
 int phx_mesh_counts(const phx_mesh *m, int64_t *counts);
 /* Copy a mesh array out (to host or to a device buffer of the same GPU). */
@@ -169,6 +174,13 @@ int phx_submesh_maps(phx_mesh *sub, int32_t *c_map, int32_t *v_map);
  * are stored. */
 int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab_coef, const double *phi_h,
                             const double *f_h, const double *u_D, int loc, phx_system **out);
+/* The same forms with primal_degree = auxiliary_degree = 2 (BASELINE configs[2]); the
+ * div(grad(.)) terms of main.py:123-128,150 are live.  DoFs per field: vertex v -> v, edge e ->
+ * nv + e (PHX_ARR_EDGES / PHX_ARR_C2E), p block shifted by nv + ne.  f_h, u_D: nodal P2 arrays
+ * [nv + ne]; phi_h: [nv] if phi_degree == 1, [nv + ne] if 2. */
+int phx_assemble_poisson_wd_p2(phx_mesh *m, double pen_coef, double stab_coef, const double *phi_h,
+                               int phi_degree, const double *f_h, const double *u_D, int loc,
+                               phx_system **out);
 int phx_system_destroy(phx_system *s);
 /* info[8] = {n_active, n_active_u, nnz (structural, CSR), n_full (= 2*nv), sell_padded_nnz,
  *            slot_capacity, sell_nnz (explicit zeros dropped), n_slices} */

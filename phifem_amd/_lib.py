@@ -28,7 +28,8 @@ CELL_TYPES = {"triangle": TRIANGLE, "quadrilateral": QUADRILATERAL, "tetrahedron
 CELL_NAMES = {v: k for k, v in CELL_TYPES.items()}
 PHI_NODAL_P1, PHI_POINTS, PHI_QUADRIC = 0, 1, 2
 OPT_PROFILE_SPMV, OPT_HAS_EXTERIOR = 1, 2
-(ARR_COORDS, ARR_CELLS, ARR_C2F, ARR_F2C, ARR_CELL_TAGS, ARR_FACET_TAGS, ARR_BFACETS) = range(7)
+(ARR_COORDS, ARR_CELLS, ARR_C2F, ARR_F2C, ARR_CELL_TAGS, ARR_FACET_TAGS, ARR_BFACETS, ARR_C2E,
+ ARR_EDGES) = range(9)
 
 OK, ERR_VALUE, ERR_NOT_IMPLEMENTED, ERR_HIP, ERR_PARTITION, ERR_CAPACITY, ERR_BREAKDOWN = (
     0, -1, -2, -3, -4, -5, -6)
@@ -49,6 +50,7 @@ SIGNATURES = {
     "phx_mesh_set_slab_faces": ([_vp, _i, _i], _i),
     "phx_mesh_destroy": ([_vp], _i),
     "phx_mesh_counts": ([_vp, _pi64], _i),
+    "phx_mesh_edge_count": ([_vp, _pi64], _i),
     "phx_mesh_get_array": ([_vp, _i, _vp, _i], _i),
     "phx_mesh_stream": ([_vp, C.POINTER(C.c_uint64)], _i),
     "phx_mesh_synchronize": ([_vp], _i),
@@ -68,6 +70,7 @@ SIGNATURES = {
     "phx_submesh_create": ([_vp, C.POINTER(_vp)], _i),
     "phx_submesh_maps": ([_vp, _vp, _vp], _i),
     "phx_assemble_poisson_wd": ([_vp, _d, _d, _vp, _vp, _vp, _i, C.POINTER(_vp)], _i),
+    "phx_assemble_poisson_wd_p2": ([_vp, _d, _d, _vp, _i, _vp, _vp, _i, C.POINTER(_vp)], _i),
     "phx_system_destroy": ([_vp], _i),
     "phx_system_info": ([_vp, _pi64], _i),
     "phx_system_export": ([_vp, _vp, _vp, _vp, _vp, _vp], _i),

@@ -179,6 +179,7 @@ __device__ __forceinline__ double mult4(int i, int j, int k, int l) {
 // Work lists: the element kernels run over COMPACTED lists (inside cells, cut cells, stabilised
 // facets) with one lane per entry of the element tensor, so a wavefront issues 64 independent
 // slot updates instead of one lane walking a whole element matrix.
+struct SelOmega { const int8_t *t; __host__ __device__ bool operator()(const int32_t &c) const { const int v = t[c] & PHX_TAG_MASK; return v == 1 || v == 2; } };
 struct SelCut { const int8_t *t; __host__ __device__ bool operator()(const int32_t &c) const { return (t[c] & PHX_TAG_MASK) == 2; } };
 struct SelGhostFacet {
   const int8_t *ft; const int32_t *f2c;
@@ -446,9 +447,10 @@ __global__ void k_row_counts(int64_t n, int W, const int32_t *__restrict__ cols,
   const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (row >= n) return;
-  const bool used = lane < W && cols[row * W + lane] != -1;
-  const unsigned long long b = __ballot(used);
-  if (lane == 0) counts[row] = __popcll(b);
+  int cnt = 0;
+  for (int k = lane; k < W; k += 64) cnt += cols[row * W + k] != -1;
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0) counts[row] = cnt;
 }
 
 __global__ void k_row_fill(int64_t n, int W, const int32_t *__restrict__ cols,
@@ -478,6 +480,43 @@ __global__ void k_row_fill(int64_t n, int W, const int32_t *__restrict__ cols,
   const int64_t base = rowptr[row];
   const int64_t cnt = rowptr[row + 1] - base;
   if (lane < cnt) { ocol[base + lane] = c; oval[base + lane] = v; }
+}
+
+// rows wider than one wavefront (P2): one block of W threads per row, bitonic sort in LDS
+template <int W>
+__global__ void __launch_bounds__(W)
+k_row_fill_block(int64_t n, const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                 const int64_t *__restrict__ rowptr, int32_t nent, const int32_t *__restrict__ du,
+                 const int32_t *__restrict__ dp, int32_t *__restrict__ ocol,
+                 double *__restrict__ oval, double *__restrict__ diag) {
+  __shared__ int32_t sc[W];
+  __shared__ double sv[W];
+  const int64_t row = blockIdx.x;
+  const int t = threadIdx.x;
+  int32_t c = 0x7fffffff;
+  double v = 0.0;
+  const int32_t cc = cols[row * W + t];
+  if (cc != -1) { c = cc < nent ? du[cc] : dp[cc - nent]; v = vals[row * W + t]; }
+  if (c == (int32_t)row) diag[row] = v;
+  sc[t] = c;
+  sv[t] = v;
+  __syncthreads();
+  for (int k = 2; k <= W; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int p = t ^ j;
+      if (p > t) {
+        const bool up = ((t & k) == 0);
+        const int32_t a = sc[t], b = sc[p];
+        if ((a > b) == up) {
+          sc[t] = b; sc[p] = a;
+          const double x = sv[t]; sv[t] = sv[p]; sv[p] = x;
+        }
+      }
+      __syncthreads();
+    }
+  const int64_t base = rowptr[row];
+  const int64_t cnt = rowptr[row + 1] - base;
+  if (t < cnt) { ocol[base + t] = sc[t]; oval[base + t] = sv[t]; }
 }
 
 template <typename T>
@@ -528,12 +567,63 @@ extern "C" int phx_system_destroy(phx_system *s) {
   return PHX_OK;
 }
 
+// overflow check -> compaction of the slot tables into CSR (sorted columns) -> SELL
+int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
+  phx_mesh *m = s->mesh;
+  const int W = sl.W;
+  const dim3 block(256);
+  int overflow = 0;
+  PHX_HIP(hipMemcpyAsync(&overflow, sl.overflow, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  if (overflow) {
+    PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
+    phx_set_error("row-slot capacity %d exceeded", W);
+    return PHX_ERR_CAPACITY;
+  }
+  int64_t *counts = nullptr;
+  PHX_HIP(hipMalloc(&counts, sizeof(int64_t) * (size_t)(s->n + 1)));
+  PHX_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(s->n + 1), m->stream));
+  PHX_HIP(hipMalloc(&s->rowptr, sizeof(int64_t) * (size_t)(s->n + 1)));
+  const dim3 growave((unsigned)phx_div_up(s->n * 64, 256));
+  k_row_counts<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, counts);
+  PHX_CHECK(exclusive_sum<int64_t>(m, counts, s->rowptr, s->n + 1));
+  int64_t nnz = 0;
+  PHX_HIP(hipMemcpy(&nnz, s->rowptr + s->n, sizeof(int64_t), hipMemcpyDeviceToHost));
+  s->nnz = nnz;
+  PHX_HIP(hipMalloc(&s->col, sizeof(int32_t) * (size_t)nnz));
+  PHX_HIP(hipMalloc(&s->val, sizeof(double) * (size_t)nnz));
+  PHX_HIP(hipMalloc(&s->diag, sizeof(double) * (size_t)s->n));
+  PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
+  if (W <= 64)
+    k_row_fill<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, s->rowptr, nent,
+                                                  s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
+  else if (W == 128)
+    k_row_fill_block<128><<<dim3((unsigned)s->n), dim3(128), 0, m->stream>>>(
+        s->n, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
+  else if (W == 256)
+    k_row_fill_block<256><<<dim3((unsigned)s->n), dim3(256), 0, m->stream>>>(
+        s->n, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
+  else if (W == 512)
+    k_row_fill_block<512><<<dim3((unsigned)s->n), dim3(512), 0, m->stream>>>(
+        s->n, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
+  else {
+    phx_set_error("unsupported slot capacity %d", W);
+    return PHX_ERR_VALUE;
+  }
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(hipFree(counts));
+  PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
+  return phx_system_build_sell(s);
+}
+
 static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef,
                                   const double *dphi, const double *df, const double *dud, int W,
                                   phx_system **out) {
   phx_system *s = new phx_system();
   s->mesh = m;
   s->device = m->device;
+  s->nent = m->nv;
   s->nfull = 2 * m->nv;
   s->slot_cap = W;
   const int D = m->gdim;
@@ -617,38 +707,12 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
     else k_assemble_facets<3><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
   }
   PHX_HIP(hipGetLastError());
-  int overflow = 0;
-  PHX_HIP(hipMemcpyAsync(&overflow, sl.overflow, sizeof(int), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(hipFree(l_cut)); PHX_HIP(hipFree(l_fac));
-  if (overflow) {
-    PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
-    phx_system_destroy(s);
-    phx_set_error("row-slot capacity %d exceeded", W);
-    return PHX_ERR_CAPACITY;
+  {
+    const int rc = phx_finish_system(s, sl, (int32_t)m->nv);
+    if (rc != PHX_OK) { phx_system_destroy(s); return rc; }
   }
-  // ---- compaction to CSR (sorted columns)
-  int64_t *counts = nullptr;
-  PHX_HIP(hipMalloc(&counts, sizeof(int64_t) * (size_t)(s->n + 1)));
-  PHX_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(s->n + 1), m->stream));
-  PHX_HIP(hipMalloc(&s->rowptr, sizeof(int64_t) * (size_t)(s->n + 1)));
-  const dim3 growave((unsigned)phx_div_up(s->n * 64, 256));
-  k_row_counts<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, counts);
-  PHX_CHECK(exclusive_sum<int64_t>(m, counts, s->rowptr, s->n + 1));
-  int64_t nnz = 0;
-  PHX_HIP(hipMemcpy(&nnz, s->rowptr + s->n, sizeof(int64_t), hipMemcpyDeviceToHost));
-  s->nnz = nnz;
-  PHX_HIP(hipMalloc(&s->col, sizeof(int32_t) * (size_t)nnz));
-  PHX_HIP(hipMalloc(&s->val, sizeof(double) * (size_t)nnz));
-  PHX_HIP(hipMalloc(&s->diag, sizeof(double) * (size_t)s->n));
-  PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
-  k_row_fill<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, s->rowptr, (int32_t)m->nv,
-                                                  s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
-  PHX_HIP(hipGetLastError());
-  PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(counts));
-  PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
-  PHX_CHECK(phx_system_build_sell(s));
   *out = s;
   return PHX_OK;
 }
@@ -720,8 +784,8 @@ extern "C" int phx_system_get_perm(phx_system *s, int32_t *perm, int32_t *dof_u,
   PHX_HIP(hipSetDevice(s->mesh->device));
   const hipMemcpyKind k = loc == PHX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   if (perm) PHX_HIP(hipMemcpy(perm, s->perm, sizeof(int32_t) * (size_t)s->n, k));
-  if (dof_u) PHX_HIP(hipMemcpy(dof_u, s->dof_of_vertex_u, sizeof(int32_t) * (size_t)s->mesh->nv, k));
-  if (dof_p) PHX_HIP(hipMemcpy(dof_p, s->dof_of_vertex_p, sizeof(int32_t) * (size_t)s->mesh->nv, k));
+  if (dof_u) PHX_HIP(hipMemcpy(dof_u, s->dof_of_vertex_u, sizeof(int32_t) * (size_t)s->nent, k));
+  if (dof_p) PHX_HIP(hipMemcpy(dof_p, s->dof_of_vertex_p, sizeof(int32_t) * (size_t)s->nent, k));
   return PHX_OK;
 }
 
@@ -735,3 +799,5 @@ extern "C" int phx_system_export(phx_system *s, int64_t *rowptr, int32_t *col, d
   if (dof) PHX_HIP(hipMemcpy(dof, s->full_of_active, sizeof(int64_t) * (size_t)s->n, hipMemcpyDeviceToHost));
   return PHX_OK;
 }
+
+#include "phx_assemble_p2.inc.hip"

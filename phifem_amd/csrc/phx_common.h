@@ -67,6 +67,13 @@ struct phx_mesh {
   uint8_t *facet_exempt = nullptr;  // [nf] or NULL
   // vertex -> incident cells (CSR), built on first assembly: rows of the stiffness block are
   // gathered by their owning vertex instead of scattered with atomics
+  // edges (P2 DoFs): 2-D edges ARE the facets; 3-D boxes use a closed form, others a host sort
+  int64_t ne = 0;
+  int32_t *c2e = nullptr;    // [nc*nepc], local edge k per basix: tri (1,2),(0,2),(0,1);
+                             // tet (2,3),(1,3),(1,2),(0,3),(0,2),(0,1)
+  int32_t *edges = nullptr;  // [ne*2] vertex pairs, ascending
+  bool c2e_is_alias = false;
+  int64_t box_n[3] = {0, 0, 0};
   int64_t *v2c_ptr = nullptr;  // [nv+1]
   int32_t *v2c_idx = nullptr;  // [nc*nvpc]
   bool is_box = false;
@@ -93,6 +100,7 @@ struct phx_system {
   phx_mesh *mesh = nullptr;
   int device = 0;
   int64_t n = 0, nu = 0, nnz = 0, nfull = 0;
+  int64_t nent = 0;  // DoF entities per field: nv (P1) or nv + ne (P2)
   int slot_cap = 0;
   // original active numbering
   int32_t *dof_of_vertex_u = nullptr;  // [nv]  active index or -1
@@ -126,3 +134,4 @@ struct phx_system {
 int phx_mesh_alloc_common(phx_mesh *m);
 int phx_begin_timing(phx_mesh *m);
 int phx_end_timing(phx_mesh *m, int slot);
+int phx_mesh_build_edges(phx_mesh *m);

@@ -514,6 +514,7 @@ extern "C" int phx_mesh_create_box(int gdim, const double *lo, const double *hi,
   m->is_box = true;
   m->box_plane = gdim == 3 ? (b.n[0] + 1) * (b.n[1] + 1) : (b.n[0] + 1);
   m->box_nlast = b.n[gdim - 1];
+  for (int a = 0; a < 3; ++a) m->box_n[a] = a < gdim ? b.n[a] : 1;
   PHX_HIP(hipMalloc(&m->x, sizeof(double) * (size_t)nv * gdim));
   PHX_HIP(hipMalloc(&m->cells, sizeof(int32_t) * (size_t)nc * (gdim + 1)));
   PHX_HIP(hipMalloc(&m->c2f, sizeof(int32_t) * (size_t)nc * (gdim + 1)));
@@ -568,12 +569,134 @@ extern "C" int phx_mesh_set_slab_faces(phx_mesh *m, int lower_is_cut, int upper_
   return PHX_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Edges (the extra DoFs of P2).  Local edge k of a cell follows basix:
+//   triangle (1,2),(0,2),(0,1) -- identical to the local facets, so in 2-D c2e IS c2f;
+//   tetrahedron (2,3),(1,3),(1,2),(0,3),(0,2),(0,1).
+// Kuhn boxes: 7 edge classes per cube, id = base[class] + anchor index inside the class extent:
+//   0,1,2 axis edges x,y,z;  3,4,5 face diagonals (x,y),(x,z),(y,z);  6 body diagonal.
+// ------------------------------------------------------------------------------------------
+__constant__ int c_tet_edge[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+
+struct EdgeDesc {
+  int64_t n[3];
+  int64_t base[8];
+  int64_t ext[7][3];
+};
+
+__global__ void k_box_c2e(EdgeDesc E, int64_t nc, int32_t *__restrict__ c2e) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int t = (int)(c % 6);
+  const int64_t cube = c / 6;
+  int64_t o[3] = {cube % E.n[0], (cube / E.n[0]) % E.n[1], cube / (E.n[0] * E.n[1])};
+  int p[3] = {c_perm3[t][0], c_perm3[t][1], c_perm3[t][2]};
+  // path vertices w0..w3 as offsets from o
+  int w[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int s = 0; s < 3; ++s) {
+    for (int a = 0; a < 3; ++a) w[s + 1][a] = w[s][a];
+    w[s + 1][p[s]] += 1;
+  }
+  for (int k = 0; k < 6; ++k) {
+    const int a = c_tet_edge[k][0], b = c_tet_edge[k][1];  // a < b along the path
+    int dir[3], nd = 0, cls;
+    for (int q = 0; q < 3; ++q) { dir[q] = w[b][q] - w[a][q]; nd += dir[q]; }
+    if (nd == 1) cls = dir[0] ? 0 : (dir[1] ? 1 : 2);
+    else if (nd == 2) cls = !dir[2] ? 3 : (!dir[1] ? 4 : 5);
+    else cls = 6;
+    const int64_t an[3] = {o[0] + w[a][0], o[1] + w[a][1], o[2] + w[a][2]};
+    c2e[c * 6 + k] = (int32_t)(E.base[cls] + an[0] + E.ext[cls][0] * (an[1] + E.ext[cls][1] * an[2]));
+  }
+}
+
+__global__ void k_edge_vertices(int64_t nc, int nvpc, int nepc, int is_tet,
+                                const int32_t *__restrict__ cells,
+                                const int32_t *__restrict__ c2e, int32_t *__restrict__ edges) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  for (int k = 0; k < nepc; ++k) {
+    int a, b;
+    if (is_tet) { a = c_tet_edge[k][0]; b = c_tet_edge[k][1]; }
+    else { a = k == 0 ? 1 : 0; b = k == 2 ? 1 : 2; }
+    const int32_t va = cells[c * nvpc + a], vb = cells[c * nvpc + b];
+    const int64_t e = c2e[c * nepc + k];
+    edges[2 * e] = va < vb ? va : vb;       // every writer of an edge stores the same pair
+    edges[2 * e + 1] = va < vb ? vb : va;
+  }
+}
+
+int phx_mesh_build_edges(phx_mesh *m) {
+  if (m->edges) return PHX_OK;
+  PHX_REQUIRE(m->cell_type == PHX_TRIANGLE || m->cell_type == PHX_TETRAHEDRON,
+              PHX_ERR_NOT_IMPLEMENTED, "edges (P2) are implemented on simplices only");
+  const dim3 block(256), grid((unsigned)phx_div_up(m->nc, 256));
+  if (m->cell_type == PHX_TRIANGLE) {
+    m->ne = m->nf;
+    m->c2e = m->c2f;
+    m->c2e_is_alias = true;
+  } else if (m->is_box) {
+    EdgeDesc E;
+    for (int a = 0; a < 3; ++a) E.n[a] = m->box_n[a];
+    for (int cls = 0; cls < 7; ++cls) {
+      // an edge class spans (n_a) cubes along every axis it moves in, (n_a + 1) otherwise
+      const bool mv[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+      for (int a = 0; a < 3; ++a) E.ext[cls][a] = mv[cls][a] ? E.n[a] : E.n[a] + 1;
+    }
+    E.base[0] = 0;
+    for (int cls = 0; cls < 7; ++cls) E.base[cls + 1] = E.base[cls] + E.ext[cls][0] * E.ext[cls][1] * E.ext[cls][2];
+    m->ne = E.base[7];
+    PHX_REQUIRE(m->ne < INT32_MAX, PHX_ERR_VALUE, "too many edges for 32-bit local ids");
+    PHX_HIP(hipMalloc(&m->c2e, sizeof(int32_t) * (size_t)m->nc * 6));
+    k_box_c2e<<<grid, block, 0, m->stream>>>(E, m->nc, m->c2e);
+  } else {
+    // unstructured tetrahedra: number the edges by the rank of their sorted vertex pair (host)
+    std::vector<int32_t> cells((size_t)m->nc * 4);
+    PHX_HIP(hipMemcpy(cells.data(), m->cells, cells.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    const int te[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+    struct Rec { int32_t a, b; int64_t slot; };
+    std::vector<Rec> recs((size_t)m->nc * 6);
+    for (int64_t c = 0; c < m->nc; ++c)
+      for (int k = 0; k < 6; ++k) {
+        const int32_t va = cells[c * 4 + te[k][0]], vb = cells[c * 4 + te[k][1]];
+        recs[c * 6 + k] = {std::min(va, vb), std::max(va, vb), c * 6 + k};
+      }
+    std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) {
+      return x.a != y.a ? x.a < y.a : (x.b != y.b ? x.b < y.b : x.slot < y.slot);
+    });
+    std::vector<int32_t> c2e((size_t)m->nc * 6);
+    int64_t ne = 0;
+    for (size_t i = 0; i < recs.size(); ++i) {
+      if (i > 0 && (recs[i].a != recs[i - 1].a || recs[i].b != recs[i - 1].b)) ++ne;
+      c2e[recs[i].slot] = (int32_t)ne;
+    }
+    m->ne = recs.empty() ? 0 : ne + 1;
+    PHX_HIP(hipMalloc(&m->c2e, sizeof(int32_t) * c2e.size()));
+    PHX_HIP(hipMemcpy(m->c2e, c2e.data(), sizeof(int32_t) * c2e.size(), hipMemcpyHostToDevice));
+  }
+  PHX_HIP(hipMalloc(&m->edges, sizeof(int32_t) * 2 * (size_t)m->ne));
+  k_edge_vertices<<<grid, block, 0, m->stream>>>(m->nc, m->ci.nvpc, m->cell_type == PHX_TETRAHEDRON ? 6 : 3,
+                                                 m->cell_type == PHX_TETRAHEDRON ? 1 : 0, m->cells,
+                                                 m->c2e, m->edges);
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  return PHX_OK;
+}
+
+extern "C" int phx_mesh_edge_count(phx_mesh *m, int64_t *ne) {
+  PHX_HIP(hipSetDevice(m->device));
+  PHX_CHECK(phx_mesh_build_edges(m));
+  *ne = m->ne;
+  return PHX_OK;
+}
+
 extern "C" int phx_mesh_destroy(phx_mesh *m) {
   if (!m) return PHX_OK;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   void *ptrs[] = {m->x, m->cells, m->c2f, m->f2c, m->bfacets, m->bfacet_ids, m->cell_tags,
-                  m->facet_tags, m->ent_buf[0], m->ent_buf[1], m->facet_exempt, m->v2c_ptr, m->v2c_idx};
+                  m->facet_tags, m->ent_buf[0], m->ent_buf[1], m->facet_exempt, m->v2c_ptr, m->v2c_idx,
+                  m->edges, m->c2e_is_alias ? nullptr : (void *)m->c2e};
   for (void *p : ptrs) (void)hipFree(p);
   free(m->c_map_h); free(m->v_map_h);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -639,6 +762,12 @@ extern "C" int phx_mesh_get_array(phx_mesh *m, int which, void *out, int loc) {
     case PHX_ARR_C2F: src = m->c2f; bytes = sizeof(int32_t) * m->nc * m->ci.nfpc; break;
     case PHX_ARR_F2C: src = m->f2c; bytes = sizeof(int32_t) * m->nf * 2; break;
     case PHX_ARR_BFACETS: src = m->bfacets; bytes = sizeof(int32_t) * m->nbf * 2; break;
+    case PHX_ARR_C2E:
+      PHX_CHECK(phx_mesh_build_edges(m));
+      src = m->c2e; bytes = sizeof(int32_t) * m->nc * (m->cell_type == PHX_TETRAHEDRON ? 6 : 3); break;
+    case PHX_ARR_EDGES:
+      PHX_CHECK(phx_mesh_build_edges(m));
+      src = m->edges; bytes = sizeof(int32_t) * m->ne * 2; break;
     case PHX_ARR_CELL_TAGS:
     case PHX_ARR_FACET_TAGS: {
       const bool fac = which == PHX_ARR_FACET_TAGS;

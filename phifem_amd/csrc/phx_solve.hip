@@ -50,14 +50,14 @@ __global__ void k_row_lengths(int64_t n, const int64_t *__restrict__ rowptr,
   if (r < n) {
     for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
       if (val[k] != 0.0 || col[k] == (int32_t)r) ++len;
-    if (len > 255) len = 255;
+    if (len > 1023) len = 1023;
   }
   int wsum = len;
   for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
   if ((threadIdx.x & 63) == 0 && wsum) atomicAdd(total, (unsigned long long)wsum);
   if (r >= n) return;
-  // ascending key = (window, 255-len): descending length inside each window
-  keys[r] = ((uint32_t)(r / window) << 8) | (uint32_t)(255 - len);
+  // ascending key = (window, 1023-len): descending length inside each window
+  keys[r] = ((uint32_t)(r / window) << 10) | (uint32_t)(1023 - len);
   rows[r] = (int32_t)r;
 }
 
@@ -75,7 +75,7 @@ __global__ void k_slice_widths(int64_t nslices, int64_t n, const uint32_t *__res
   int w = 0;
   for (int r = 0; r < SELL_C; ++r) {
     const int64_t pos = s * SELL_C + r;
-    if (pos < n) w = max(w, 255 - (int)(sorted_keys[pos] & 0xff));
+    if (pos < n) w = max(w, 1023 - (int)(sorted_keys[pos] & 0x3ff));
   }
   widths[s] = (int64_t)w * SELL_C;
 }
@@ -117,7 +117,7 @@ int phx_system_build_sell(phx_system *s) {
   phx_mesh *m = s->mesh;
   const int64_t n = s->n;
   if (const char *e = getenv("PHX_SELL_WINDOW")) g_sell_window = atoll(e) > 0 ? atoll(e) : g_sell_window;
-  PHX_REQUIRE(n / g_sell_window < (1 << 23), PHX_ERR_VALUE, "system too large for the SELL sort key");
+  PHX_REQUIRE(n / g_sell_window < (1 << 21), PHX_ERR_VALUE, "system too large for the SELL sort key");
   uint32_t *keys = nullptr, *keys2 = nullptr;
   int32_t *rows = nullptr;
   PHX_HIP(hipMalloc(&keys, sizeof(uint32_t) * (size_t)n));
@@ -135,8 +135,8 @@ int phx_system_build_sell(phx_system *s) {
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(hipFree(dtotal));
   s->sell_true_nnz = (int64_t)htotal;
-  // only the bits that can differ are sorted: 8 length bits (+ the window index if windowed)
-  int end_bit = 8;
+  // only the bits that can differ are sorted: 10 length bits (+ the window index if windowed)
+  int end_bit = 10;
   for (int64_t w = (n - 1) / g_sell_window; w > 0; w >>= 1) ++end_bit;
   size_t bytes = 0;
   PHX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys2, rows, s->perm, (int)n, 0, end_bit, m->stream));
@@ -343,10 +343,24 @@ k_update_xr(int64_t n, const uint8_t *__restrict__ own, const double *__restrict
   if (blockIdx.x == 0 && threadIdx.x == 0) S[S_OMEGA] = omega;
 }
 
+// Breakdown guard: when (rhat, r) has collapsed relative to (r, r) (or a scalar went non-finite)
+// the iteration is RESTARTED from the current residual: rhat = p = r, rho = (r, r).  Every thread
+// evaluates the same predicate from the same device scalars, so p-update and roll agree.
+__device__ __forceinline__ bool kr_restart(const double *S) {
+  const double rho_new = S[R_OFF + R_RHO], rr = S[R_OFF + R_RR];
+  const double beta = (rho_new / S[S_RHO]) * (S[S_ALPHA] / S[S_OMEGA]);
+  return !(fabs(beta) <= 1.0e300) || !(fabs(rho_new) > 1.0e-14 * rr);
+}
+
 // p = r + beta (p - omega v), beta = (rho_next/rho)(alpha/omega)
 __global__ void __launch_bounds__(256)
 k_update_p(int64_t n, const uint8_t *__restrict__ own, const double *__restrict__ r,
-           const double *__restrict__ v, double *__restrict__ p, const double *__restrict__ S) {
+           const double *__restrict__ v, double *__restrict__ p, double *__restrict__ rhat,
+           const double *__restrict__ S) {
+  if (kr_restart(S)) {
+    GRID_STRIDE(i, n) { const double ri = r[i]; p[i] = ri; rhat[i] = ri; }
+    return;
+  }
   const double beta = (S[R_OFF + R_RHO] / S[S_RHO]) * (S[S_ALPHA] / S[S_OMEGA]);
   const double omega = S[S_OMEGA];
   GRID_STRIDE(i, n) {
@@ -355,10 +369,12 @@ k_update_p(int64_t n, const uint8_t *__restrict__ own, const double *__restrict_
   }
 }
 
-// end of an iteration: roll rho, remember (r,r), clear the reduction slots
+// end of an iteration: roll rho (or (r,r) after a restart), remember (r,r)
 __global__ void k_kr_roll(double *S) {
-  S[S_RHO] = S[R_OFF + R_RHO];
+  const bool restart = kr_restart(S);
+  S[S_RHO] = restart ? S[R_OFF + R_RR] : S[R_OFF + R_RHO];
   S[S_RR] = S[R_OFF + R_RR];
+  if (restart) S[5] += 1.0;  // restart counter
 }
 
 __global__ void k_gather(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ in,
@@ -483,7 +499,7 @@ extern "C" int phx_krylov_phase(phx_system *s, int phase) {
       k_reduce_slots<<<1, 64, 0, st>>>(S, R_RHO, 2);
       break;
     case 6:
-      k_update_p<<<vec_grid(n), block, 0, st>>>(n, s->own, V.r, V.v, V.p, S);
+      k_update_p<<<vec_grid(n), block, 0, st>>>(n, s->own, V.r, V.v, V.p, V.rhat, S);
       k_kr_roll<<<1, 1, 0, st>>>(S);
       break;
     default:
@@ -561,7 +577,8 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
       const double rr = s->scal_h[R_OFF + R_RR], rho = s->scal_h[R_OFF + R_RHO];
       const double omega = s->scal_h[S_OMEGA];
       relres = sqrt(rr / bb);
-      if (!(rr == rr) || !(omega == omega) || rho == 0.0 || omega == 0.0) {
+      (void)rho;
+      if (!(rr == rr) || !(fabs(rr) <= 1.0e300) || !(omega == omega)) {
         phx_set_error("BiCGStab breakdown at iteration %lld (rho=%g omega=%g rr=%g)",
                       (long long)it, rho, omega, rr);
         rc = PHX_ERR_BREAKDOWN;

@@ -88,6 +88,29 @@ class Mesh:
         """(cell, local facet) of the background-boundary facets, ascending facet index."""
         return self._get(L.ARR_BFACETS, (self.nbf, 2), np.int32)
 
+    @property
+    def ne(self):
+        n = C.c_int64(0)
+        L.check(L.lib.phx_mesh_edge_count(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def c2e(self):
+        """cell -> edges (basix local edge order); builds the edge numbering on first use."""
+        nepc = 6 if self.cell_type == "tetrahedron" else 3
+        self.ne
+        return self._get(L.ARR_C2E, (self.nc, nepc), np.int32)
+
+    @property
+    def edges(self):
+        """(ne, 2) vertex pairs, ascending."""
+        return self._get(L.ARR_EDGES, (self.ne, 2), np.int32)
+
+    def p2_dof_points(self):
+        """Coordinates of the P2 nodes: the vertices, then the edge midpoints."""
+        x, e = self.x, self.edges
+        return np.concatenate([x, 0.5 * (x[e[:, 0]] + x[e[:, 1]])], axis=0)
+
     def cell_tag_values(self):
         return self._get(L.ARR_CELL_TAGS, (self.nc,), np.int32)
 

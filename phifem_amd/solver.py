@@ -13,9 +13,17 @@ from . import _lib as L
 
 
 class PhiFEMSolver:
-    def __init__(self, mesh, pen_coef=1.0, stab_coef=1.0):
+    def __init__(self, mesh, pen_coef=1.0, stab_coef=1.0, degree=1, levelset_degree=1):
         """mesh: a tagged `phifem_amd.Mesh` (box mode) or the sub-mesh returned by
-        `compute_tags_measures(..., box_mode=False)`; coefficients as main.py:42-43."""
+        `compute_tags_measures(..., box_mode=False)`; coefficients as main.py:42-43;
+        degree = primal_degree = auxiliary degree (main.py:38, 76-78), levelset_degree as main.py:40.
+        Degree-2 nodal arrays list the vertex values first, then the edge-midpoint values
+        (`mesh.p2_dof_points()`)."""
+        if degree not in (1, 2) or levelset_degree not in (1, 2):
+            raise NotImplementedError("Lagrange degrees 1 and 2 are implemented")
+        if degree == 1 and levelset_degree != 1:
+            raise NotImplementedError("a P2 level-set needs degree = 2")
+        self.degree, self.levelset_degree = degree, levelset_degree
         self.mesh = mesh
         self.pen_coef = float(pen_coef)
         self.stab_coef = float(stab_coef)
@@ -39,23 +47,35 @@ class PhiFEMSolver:
             return a
         a = np.ascontiguousarray(a, dtype=np.float64)
         if a.shape[0] != n:
-            raise ValueError("nodal arrays must have one value per mesh vertex")
+            raise ValueError(f"nodal array has {a.shape[0]} values, the space has {n} DoFs")
         return a
 
     def assemble(self, phi_h, f_h, u_D):
         """Bilinear + linear form of main.py:112-154 (nodal P1 data, numpy or device tensors)."""
         self._free()
-        nv = self.mesh.nv
-        phi_h, f_h, u_D = (self._arr(a, nv) for a in (phi_h, f_h, u_D))
+        nd = self.ndofs
+        nphi = self.mesh.nv if self.levelset_degree == 1 else nd
+        phi_h = self._arr(phi_h, nphi)
+        f_h, u_D = (self._arr(a, nd) for a in (f_h, u_D))
         locs = {L.ptr(a)[1] for a in (phi_h, f_h, u_D)}
         if len(locs) != 1:
             raise ValueError("phi_h, f_h and u_D must all live on the host or all on the device")
         h = C.c_void_p()
-        L.check(L.lib.phx_assemble_poisson_wd(
-            self.mesh._h, self.pen_coef, self.stab_coef, L.ptr(phi_h)[0], L.ptr(f_h)[0],
-            L.ptr(u_D)[0], locs.pop(), C.byref(h)))
+        if self.degree == 1:
+            L.check(L.lib.phx_assemble_poisson_wd(
+                self.mesh._h, self.pen_coef, self.stab_coef, L.ptr(phi_h)[0], L.ptr(f_h)[0],
+                L.ptr(u_D)[0], locs.pop(), C.byref(h)))
+        else:
+            L.check(L.lib.phx_assemble_poisson_wd_p2(
+                self.mesh._h, self.pen_coef, self.stab_coef, L.ptr(phi_h)[0], self.levelset_degree,
+                L.ptr(f_h)[0], L.ptr(u_D)[0], locs.pop(), C.byref(h)))
         self._sys = h
         return self.info()
+
+    @property
+    def ndofs(self):
+        """DoFs per field in the full numbering (vertices, plus edges at degree 2)."""
+        return self.mesh.nv if self.degree == 1 else self.mesh.nv + self.mesh.ne
 
     def info(self):
         i = (C.c_int64 * 8)()
@@ -81,7 +101,7 @@ class PhiFEMSolver:
         """Replaces the KSP/MUMPS block of main.py:162-182.  Returns the mixed solution in the
         full numbering [u (nv), p (nv)] with inactive DoFs at zero; `out` may be a device
         tensor of 2*nv doubles."""
-        nfull = 2 * self.mesh.nv
+        nfull = 2 * self.ndofs
         if out is None:
             out = np.empty(nfull, dtype=np.float64)
         p, loc = L.ptr(out)
@@ -94,8 +114,8 @@ class PhiFEMSolver:
 
     def split(self, w):
         """solution_wh.split() (main.py:185): (u, p) views of the mixed vector."""
-        nv = self.mesh.nv
-        return w[:nv], w[nv:]
+        nd = self.ndofs
+        return w[:nd], w[nd:]
 
     def spmv(self, x):
         y = np.empty_like(x)

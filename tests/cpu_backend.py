@@ -96,9 +96,16 @@ class CpuBackend:
             S[R_OFF + R_RR] = self.r @ self.r
             S[S_OMEGA] = omega
         elif k == 6:
-            beta = (S[R_OFF + R_RHO] / S[S_RHO]) * (S[S_ALPHA] / S[S_OMEGA])
-            self.p[:] = np.where(own, self.r + beta * (self.p - S[S_OMEGA] * self.v), 0.0)
-            S[S_RHO] = S[R_OFF + R_RHO]
+            with np.errstate(all="ignore"):
+                beta = (S[R_OFF + R_RHO] / S[S_RHO]) * (S[S_ALPHA] / S[S_OMEGA])
+            restart = not (abs(beta) <= 1e300) or not (abs(S[R_OFF + R_RHO]) > 1e-14 * S[R_OFF + R_RR])
+            if restart:   # breakdown guard of k_update_p / k_kr_roll
+                self.p[:] = self.r
+                self.rhat[:] = self.r
+                S[S_RHO] = S[R_OFF + R_RR]
+            else:
+                self.p[:] = np.where(own, self.r + beta * (self.p - S[S_OMEGA] * self.v), 0.0)
+                S[S_RHO] = S[R_OFF + R_RHO]
             S[S_RR] = S[R_OFF + R_RR]
 
     def finish(self, out):
