@@ -154,6 +154,7 @@ def main():
                 "rtol": args.rtol, "iterations": res["iterations"], "relres": res["relres"],
                 "stage_ms": {k: 1e3 * v for k, v in res["stage_s"].items()},
                 "parallelism": f"slab{world}",
+                "dist_loop": getattr(getattr(prob, "dk", None), "path", "native-single"),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_spmv_sell (SELL-64 SpMV, f64 values / i32 columns)",

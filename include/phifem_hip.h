@@ -215,6 +215,24 @@ int phx_krylov_profile(phx_system *s, int reset, double *avg_seconds, int64_t *c
 /* perm[n] (solver position -> active row), dof_u[nv] / dof_p[nv] (vertex -> active row or -1). */
 int phx_system_get_perm(phx_system *s, int32_t *perm, int32_t *dof_u, int32_t *dof_p, int loc);
 
+/* --- native multi-GPU solve: RCCL on the solver's stream (bound with dlopen at run time) -------
+ * One communicator per process; the 128-byte id comes from rank 0 (phx_comm_unique_id) and is
+ * broadcast by the host (torch.distributed).  phx_solve_distributed runs the same phase sequence
+ * as phx_solve with a point-to-point halo of p and s (ncclSend/ncclRecv with <= 2 neighbours) and
+ * three all-reduces of 1, 2, 2 doubles per iteration.  Buffers attached with phx_krylov_attach.
+ *   peers[npeers]; counts[2*npeers] = {n_send, n_recv}; idx[2*npeers] = device int64 arrays
+ *   {send positions, recv positions} in solver order. */
+typedef struct phx_comm phx_comm;
+int phx_comm_unique_id(void *out128);
+int phx_comm_create(int nranks, int rank, const void *uid128, int device, phx_comm **out);
+int phx_comm_destroy(phx_comm *c);
+int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, const int *peers,
+                          const int64_t *counts, const int64_t *const *idx, double rtol,
+                          int64_t max_iter, double *x, int loc, double *stats);
+/* One halo exchange of `vec` (solver order) through the solver's own code path: wiring test. */
+int phx_halo_selftest(phx_system *s, phx_comm *c, int npeers, const int *peers,
+                      const int64_t *counts, const int64_t *const *idx, double *vec);
+
 /* y = A x on the active system (solver ordering is internal; x, y are in active numbering).
  * For tests and halo-exchange driven (multi-GPU) solvers. */
 int phx_spmv(phx_system *s, const double *x, double *y, int loc);

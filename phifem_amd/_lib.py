@@ -62,6 +62,11 @@ SIGNATURES = {
     "phx_krylov_finish": ([_vp, _vp, _i], _i),
     "phx_krylov_profile": ([_vp, _i, _pd, _pi64], _i),
     "phx_system_get_perm": ([_vp, _vp, _vp, _vp, _i], _i),
+    "phx_comm_unique_id": ([_vp], _i),
+    "phx_comm_create": ([_i, _i, _vp, _i, C.POINTER(_vp)], _i),
+    "phx_comm_destroy": ([_vp], _i),
+    "phx_solve_distributed": ([_vp, _vp, _i, _vp, _vp, _vp, _d, _i64, _vp, _i, _pd], _i),
+    "phx_halo_selftest": ([_vp, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "phx_tag_cells": ([_vp, _i, _vp, _i, _i, _i, _pi], _i),
     "phx_tag_facets": ([_vp, _i, _vp, _i, _i], _i),
     "phx_overwrite_tags": ([_vp, _i, _i64, _vp, _vp], _i),

@@ -1,0 +1,237 @@
+// Native multi-GPU Krylov loop: RCCL (ncclSend/ncclRecv halo + ncclAllReduce of the batched dot
+// products) on the solver's HIP stream; included by phx_solve.hip.  RCCL is bound at run time with
+// dlopen (the process already holds PyTorch's librccl; a C host may hold /opt/rocm's), so the
+// library itself has no link-time dependency on it.  SURVEY 8(e): slabs talk point-to-point to at
+// most two neighbours over dedicated xGMI links; the scalar all-reduces carry 1, 2 and 2 doubles.
+#include <dlfcn.h>
+
+typedef struct { char internal[128]; } phx_nccl_uid;
+typedef void *phx_nccl_comm;
+struct NcclApi {
+  int (*GetUniqueId)(phx_nccl_uid *);
+  int (*CommInitRank)(phx_nccl_comm *, int, phx_nccl_uid, int);
+  int (*CommDestroy)(phx_nccl_comm);
+  int (*Send)(const void *, size_t, int, int, phx_nccl_comm, hipStream_t);
+  int (*Recv)(void *, size_t, int, int, phx_nccl_comm, hipStream_t);
+  int (*AllReduce)(const void *, void *, size_t, int, int, phx_nccl_comm, hipStream_t);
+  int (*GroupStart)();
+  int (*GroupEnd)();
+  const char *(*GetErrorString)(int);
+  bool ok = false;
+};
+static NcclApi g_nccl;
+enum { PHX_NCCL_FLOAT64 = 8, PHX_NCCL_SUM = 0 };  // ncclDataType_t / ncclRedOp_t values of nccl.h
+
+static int nccl_bind() {
+  if (g_nccl.ok) return PHX_OK;
+  void *h = nullptr;
+  const char *names[] = {"librccl.so.1", "librccl.so", "libnccl.so.2"};
+  for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+  PHX_REQUIRE(h != nullptr, PHX_ERR_HIP, "librccl not found: %s", dlerror());
+#define BIND(field, sym) \
+  *(void **)(&g_nccl.field) = dlsym(h, sym); \
+  PHX_REQUIRE(g_nccl.field != nullptr, PHX_ERR_HIP, "librccl lacks %s", sym)
+  BIND(GetUniqueId, "ncclGetUniqueId");
+  BIND(CommInitRank, "ncclCommInitRank");
+  BIND(CommDestroy, "ncclCommDestroy");
+  BIND(Send, "ncclSend");
+  BIND(Recv, "ncclRecv");
+  BIND(AllReduce, "ncclAllReduce");
+  BIND(GroupStart, "ncclGroupStart");
+  BIND(GroupEnd, "ncclGroupEnd");
+  BIND(GetErrorString, "ncclGetErrorString");
+#undef BIND
+  g_nccl.ok = true;
+  return PHX_OK;
+}
+
+#define PHX_NCCL(expr)                                                                     \
+  do {                                                                                     \
+    int e_ = (expr);                                                                       \
+    if (e_ != 0) {                                                                         \
+      phx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, g_nccl.GetErrorString(e_)); \
+      return PHX_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+struct phx_comm {
+  phx_nccl_comm comm = nullptr;
+  int nranks = 1, rank = 0, device = 0;
+};
+
+extern "C" int phx_comm_unique_id(void *out128) {
+  PHX_CHECK(nccl_bind());
+  phx_nccl_uid id;
+  PHX_NCCL(g_nccl.GetUniqueId(&id));
+  memcpy(out128, &id, sizeof(id));
+  return PHX_OK;
+}
+
+extern "C" int phx_comm_create(int nranks, int rank, const void *uid128, int device, phx_comm **out) {
+  PHX_CHECK(nccl_bind());
+  PHX_HIP(hipSetDevice(device));
+  phx_nccl_uid id;
+  memcpy(&id, uid128, sizeof(id));
+  phx_comm *c = new phx_comm();
+  c->nranks = nranks; c->rank = rank; c->device = device;
+  const int e = g_nccl.CommInitRank(&c->comm, nranks, id, rank);
+  if (e != 0) {
+    phx_set_error("ncclCommInitRank failed: %s", g_nccl.GetErrorString(e));
+    delete c;
+    return PHX_ERR_HIP;
+  }
+  *out = c;
+  return PHX_OK;
+}
+
+extern "C" int phx_comm_destroy(phx_comm *c) {
+  if (!c) return PHX_OK;
+  if (c->comm && g_nccl.ok) g_nccl.CommDestroy(c->comm);
+  delete c;
+  return PHX_OK;
+}
+
+__global__ void k_halo_pack(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ v,
+                            double *__restrict__ buf) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) buf[i] = v[idx[i]];
+}
+__global__ void k_halo_unpack(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ buf,
+                              double *__restrict__ v) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) v[idx[i]] = buf[i];
+}
+
+struct HaloSpec {
+  int npeers;
+  int peer[2];
+  int64_t nsend[2], nrecv[2];
+  const int64_t *send_idx[2], *recv_idx[2];
+  double *sbuf[2], *rbuf[2];
+};
+
+static int halo_exchange(phx_system *s, phx_comm *c, const HaloSpec &H, double *vec) {
+  hipStream_t st = s->mesh->stream;
+  for (int p = 0; p < H.npeers; ++p)
+    if (H.nsend[p] > 0)
+      k_halo_pack<<<dim3((unsigned)phx_div_up(H.nsend[p], 256)), dim3(256), 0, st>>>(
+          H.nsend[p], H.send_idx[p], vec, H.sbuf[p]);
+  PHX_NCCL(g_nccl.GroupStart());
+  for (int p = 0; p < H.npeers; ++p) {
+    if (H.nsend[p] > 0) PHX_NCCL(g_nccl.Send(H.sbuf[p], (size_t)H.nsend[p], PHX_NCCL_FLOAT64, H.peer[p], c->comm, st));
+    if (H.nrecv[p] > 0) PHX_NCCL(g_nccl.Recv(H.rbuf[p], (size_t)H.nrecv[p], PHX_NCCL_FLOAT64, H.peer[p], c->comm, st));
+  }
+  PHX_NCCL(g_nccl.GroupEnd());
+  for (int p = 0; p < H.npeers; ++p)
+    if (H.nrecv[p] > 0)
+      k_halo_unpack<<<dim3((unsigned)phx_div_up(H.nrecv[p], 256)), dim3(256), 0, st>>>(
+          H.nrecv[p], H.recv_idx[p], H.rbuf[p], vec);
+  PHX_HIP(hipGetLastError());
+  return PHX_OK;
+}
+
+static int allreduce_R(phx_system *s, phx_comm *c, int lo, int hi) {
+  if (c->nranks == 1) return PHX_OK;
+  double *R = kr_scal(s) + R_OFF + lo;
+  PHX_NCCL(g_nccl.AllReduce(R, R, (size_t)(hi - lo), PHX_NCCL_FLOAT64, PHX_NCCL_SUM, c->comm, s->mesh->stream));
+  return PHX_OK;
+}
+
+// peers[npeers], counts[2*npeers] = {nsend, nrecv} per peer, idx[2*npeers] device pointers
+// {send_idx, recv_idx} (int64 solver positions), work/scal/own as phx_krylov_attach (already
+// attached).  stats[6] as phx_solve.  Exchange `check` != 0 first verifies the halo wiring by
+// sending each peer the int64 tags in `tags_send[p]` and comparing with `tags_expect[p]`.
+extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, const int *peers,
+                                     const int64_t *counts, const int64_t *const *idx, double rtol,
+                                     int64_t max_iter, double *x_out, int loc, double *stats) {
+  phx_mesh *m = s->mesh;
+  PHX_HIP(hipSetDevice(m->device));
+  PHX_REQUIRE(npeers >= 0 && npeers <= 2, PHX_ERR_VALUE, "a slab has at most two neighbours");
+  hipStream_t st = m->stream;
+  HaloSpec H;
+  memset(&H, 0, sizeof(H));
+  H.npeers = npeers;
+  for (int p = 0; p < npeers; ++p) {
+    H.peer[p] = peers[p];
+    H.nsend[p] = counts[2 * p]; H.nrecv[p] = counts[2 * p + 1];
+    H.send_idx[p] = idx[2 * p]; H.recv_idx[p] = idx[2 * p + 1];
+    PHX_HIP(hipMalloc(&H.sbuf[p], sizeof(double) * (size_t)(H.nsend[p] > 0 ? H.nsend[p] : 1)));
+    PHX_HIP(hipMalloc(&H.rbuf[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)));
+  }
+  const KrVecs V = kr_vecs(s);
+  double *S = kr_scal(s);
+  const int check_every = 8;
+  int rc = PHX_OK;
+  auto body = [&]() -> int {
+    PHX_CHECK(prof_reset(s));
+    PHX_CHECK(phx_begin_timing(m));
+    PHX_CHECK(phx_krylov_phase(s, 0));
+    PHX_CHECK(allreduce_R(s, c, R_RHO, R_RHO + 1));
+    PHX_CHECK(phx_krylov_phase(s, 1));
+    PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+    PHX_HIP(hipStreamSynchronize(st));
+    const double bb = s->scal_h[S_BB];
+    int64_t it = 0;
+    double relres = bb == 0.0 ? 0.0 : 1.0;
+    while (bb != 0.0 && it < max_iter) {
+      PHX_CHECK(halo_exchange(s, c, H, V.p));
+      PHX_CHECK(phx_krylov_phase(s, 2));
+      PHX_CHECK(allreduce_R(s, c, R_RV, R_RV + 1));
+      PHX_CHECK(phx_krylov_phase(s, 3));
+      PHX_CHECK(halo_exchange(s, c, H, V.sv));
+      PHX_CHECK(phx_krylov_phase(s, 4));
+      PHX_CHECK(allreduce_R(s, c, R_TS, R_TT + 1));
+      PHX_CHECK(phx_krylov_phase(s, 5));
+      PHX_CHECK(allreduce_R(s, c, R_RHO, R_RR + 1));
+      ++it;
+      if ((it % check_every == 0) || it == max_iter) {
+        PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+        PHX_HIP(hipStreamSynchronize(st));
+        const double rr = s->scal_h[R_OFF + R_RR];
+        relres = sqrt(rr / bb);
+        if (!(rr == rr) || !(fabs(rr) <= 1.0e300)) {
+          phx_set_error("BiCGStab breakdown at iteration %lld (rr=%g)", (long long)it, rr);
+          return PHX_ERR_BREAKDOWN;
+        }
+        if (relres <= rtol) break;
+      }
+      PHX_CHECK(phx_krylov_phase(s, 6));
+    }
+    PHX_CHECK(phx_krylov_finish(s, x_out, loc));
+    PHX_CHECK(phx_end_timing(m, 3));
+    double pavg = 0.0;
+    int pcount = 0;
+    PHX_CHECK(prof_collect(s, &pavg, &pcount));
+    if (stats) {
+      stats[0] = (double)it; stats[1] = relres; stats[2] = m->timings[3];
+      stats[3] = (double)(2 * it); stats[4] = pavg; stats[5] = (double)pcount;
+    }
+    return PHX_OK;
+  };
+  rc = body();
+  (void)hipStreamSynchronize(st);
+  for (int p = 0; p < npeers; ++p) { (void)hipFree(H.sbuf[p]); (void)hipFree(H.rbuf[p]); }
+  return rc;
+}
+
+// Wiring self-test: every rank sends each peer `tags` gathered at its send positions and receives
+// into its recv positions; used by the host to prove both sides enumerate the same DoFs through
+// the SAME code path the solver uses (ncclSend/ncclRecv + pack/unpack kernels).
+extern "C" int phx_halo_selftest(phx_system *s, phx_comm *c, int npeers, const int *peers,
+                                 const int64_t *counts, const int64_t *const *idx, double *vec) {
+  PHX_HIP(hipSetDevice(s->mesh->device));
+  HaloSpec H;
+  memset(&H, 0, sizeof(H));
+  H.npeers = npeers;
+  for (int p = 0; p < npeers; ++p) {
+    H.peer[p] = peers[p];
+    H.nsend[p] = counts[2 * p]; H.nrecv[p] = counts[2 * p + 1];
+    H.send_idx[p] = idx[2 * p]; H.recv_idx[p] = idx[2 * p + 1];
+    PHX_HIP(hipMalloc(&H.sbuf[p], sizeof(double) * (size_t)(H.nsend[p] > 0 ? H.nsend[p] : 1)));
+    PHX_HIP(hipMalloc(&H.rbuf[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)));
+  }
+  const int rc = halo_exchange(s, c, H, vec);
+  (void)hipStreamSynchronize(s->mesh->stream);
+  for (int p = 0; p < npeers; ++p) { (void)hipFree(H.sbuf[p]); (void)hipFree(H.rbuf[p]); }
+  return rc;
+}

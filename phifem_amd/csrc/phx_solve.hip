@@ -605,6 +605,8 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
   return rc;
 }
 
+#include "phx_dist.inc.hip"
+
 // y = A x in ORIGINAL active numbering (for tests and externally driven iterations)
 __global__ void k_scatter_perm(int64_t n, const int32_t *__restrict__ perm,
                                const double *__restrict__ in, double *__restrict__ out) {

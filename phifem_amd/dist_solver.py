@@ -229,13 +229,22 @@ class DistributedSolver:
 
 
 class DistributedKrylov:
-    """Glue between `SlabProblem` (phifem_amd/distributed.py) and `DistributedSolver`."""
+    """Glue between `SlabProblem` (phifem_amd/distributed.py) and the solver loops.
+
+    With the nccl backend the loop runs NATIVELY in the library (`phx_solve_distributed`: RCCL
+    send/recv + all-reduce on the solver's stream, no Python in the iteration).  The Python-driven
+    `DistributedSolver` is the reference implementation of the same protocol: it is what the gloo
+    tests exercise, and the fallback whenever the native path cannot be set up or its halo
+    self-test disagrees (decided collectively, so all ranks take the same path)."""
 
     def __init__(self, prob):
         import torch
         import torch.distributed as dist
         self.prob, self.torch, self.dist = prob, torch, dist
         self.dev = torch.device("cuda", prob.device)
+        self.comm = None
+        self.native = None   # None: not tried yet, True/False afterwards
+        self.path = "python"
 
     def agree_on_exterior(self):
         """`len(exterior_cells) == 0` (mesh_scripts.py:469) must be decided over ALL slabs."""
@@ -245,6 +254,74 @@ class DistributedKrylov:
         flag = self.torch.tensor([1 if hist[3] > 0 else 0], dtype=self.torch.int32, device=self.dev)
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
         L.check(L.lib.phx_set_option(self.prob.mesh._h, L.OPT_HAS_EXTERIOR, int(flag.item())))
+
+    def _all_ok(self, ok):
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def _init_native(self):
+        """RCCL communicator of the library: id from rank 0, broadcast with torch.distributed."""
+        from . import _lib as L
+        torch, dist = self.torch, self.dist
+        if dist.get_backend() != "nccl":
+            self.native = False
+            return
+        ok = True
+        uid = torch.zeros(128, dtype=torch.uint8, device=self.dev)
+        try:
+            if self.prob.rank == 0:
+                buf = (C.c_ubyte * 128)()
+                L.check(L.lib.phx_comm_unique_id(buf))
+                uid.copy_(torch.tensor(list(buf), dtype=torch.uint8))
+        except Exception:
+            ok = False
+        if not self._all_ok(ok):
+            self.native = False
+            return
+        dist.broadcast(uid, src=0)
+        host = (C.c_ubyte * 128)(*uid.cpu().tolist())
+        h = C.c_void_p()
+        rc = L.lib.phx_comm_create(self.prob.world, self.prob.rank, host, self.prob.device, C.byref(h))
+        ok = rc == 0
+        if ok:
+            self.comm = h
+        self.native = self._all_ok(ok)
+
+    def _halo_arrays(self, ds):
+        torch = self.torch
+        np_ = len(ds.halos)
+        peers = (C.c_int * max(np_, 1))(*[h["peer"] for h in ds.halos])
+        counts = (C.c_int64 * max(2 * np_, 1))()
+        idx = (C.c_void_p * max(2 * np_, 1))()
+        keep = []
+        for p, h in enumerate(ds.halos):
+            sp, rp = h["send"][0].contiguous(), h["recv"][0].contiguous()
+            for t in (sp, rp):  # the kernels index the work vectors with these: never out of range
+                if t.numel() and (int(t.min()) < 0 or int(t.max()) >= ds.b.n):
+                    raise RuntimeError("halo position out of range")
+            keep += [sp, rp]
+            counts[2 * p], counts[2 * p + 1] = sp.numel(), rp.numel()
+            idx[2 * p], idx[2 * p + 1] = sp.data_ptr(), rp.data_ptr()
+        return np_, peers, counts, idx, keep
+
+    def _selftest(self, backend, ds, arrays):
+        """Send the global DoF ids through ncclSend/ncclRecv + the pack/unpack kernels and compare
+        with the ids this rank expects: proves the native wiring before any solve uses it."""
+        from . import _lib as L
+        torch = self.torch
+        np_, peers, counts, idx, keep = arrays
+        vec = torch.full((backend.n,), -1.0, dtype=torch.float64, device=self.dev)
+        for h in ds.halos:
+            vec[h["send"][0]] = h["send"][1].to(torch.float64)
+        torch.cuda.synchronize(self.dev)
+        rc = L.lib.phx_halo_selftest(backend.sys, self.comm, np_, peers, counts, idx,
+                                     C.c_void_p(vec.data_ptr()))
+        ok = rc == 0
+        if ok:
+            for h in ds.halos:
+                ok = ok and bool(torch.equal(vec[h["recv"][0]], h["recv"][1].to(torch.float64)))
+        return ok
 
     def solve(self, out, profile_spmv=False):
         from . import _lib as L
@@ -257,4 +334,21 @@ class DistributedKrylov:
         ds = DistributedSolver(backend, self.dist, self.torch, prob.rank, prob.world, plane,
                                lay["k0"], lay["P0"], lay["P1"], lay["k1"] - lay["k0"] + 1,
                                rtol=prob.rtol, max_iter=prob.max_iter)
-        return ds.solve(out, profile_spmv=profile_spmv)
+        if self.native is None:
+            self._init_native()
+            if self.native:
+                self.native = self._all_ok(self._selftest(backend, ds, self._halo_arrays(ds)))
+        if not self.native:
+            self.path = "python"
+            return ds.solve(out, profile_spmv=profile_spmv)
+        self.path = "native"
+        np_, peers, counts, idx, keep = self._halo_arrays(ds)
+        st = (C.c_double * 6)()
+        self.torch.cuda.synchronize(self.dev)
+        t0 = time.perf_counter()
+        L.check(L.lib.phx_solve_distributed(backend.sys, self.comm, np_, peers, counts, idx,
+                                            float(prob.rtol), int(prob.max_iter),
+                                            C.c_void_p(out.data_ptr()), L.DEVICE, st))
+        self.torch.cuda.synchronize(self.dev)
+        return {"iterations": int(st[0]), "relres": st[1], "seconds": time.perf_counter() - t0,
+                "n_owned": ds.n_owned, "spmv_avg_s": st[4], "spmv_timed": int(st[5])}

@@ -215,3 +215,53 @@ def test_config0_flower_2d(P):
     wo = OA.solve_direct(A, b, act)
     assert np.abs(w - wo).max() <= SOL_TOL * np.abs(wo).max()
     assert w[:mesh.nv].max() > 0.0 and np.all(w[~act] == 0.0)
+
+
+def test_native_rccl_loop_world1(P):
+    """phx_solve_distributed with a one-rank RCCL communicator (no halo; the all-reduces are
+    skipped for one rank) reproduces the native single-GPU solve: binds librccl at run time."""
+    import ctypes as C
+    import torch
+    from phifem_amd import _lib as L
+    from phifem_amd.dist_solver import DistributedSolver, HipBackend
+    from phifem_amd.distributed import SlabProblem
+    prob = SlabProblem(16, rank=0, world=1, device=0, rtol=1e-10)
+    prob.setup()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = prob.step()
+    native = prob.out.clone()
+    uid = (C.c_ubyte * 128)()
+    L.check(L.lib.phx_comm_unique_id(uid))
+    comm = C.c_void_p()
+    L.check(L.lib.phx_comm_create(1, 0, uid, 0, C.byref(comm)))
+    dev = torch.device("cuda", 0)
+    be = HipBackend(prob.solver, dev)
+    be.use_current_stream()
+    lay = prob.lay
+    ds = DistributedSolver(be, None, torch, 0, 1, (prob.n + 1) ** 2, lay["k0"], lay["P0"], lay["P1"],
+                           lay["k1"] - lay["k0"] + 1, rtol=1e-10)
+    out = torch.zeros_like(native)
+    st = (C.c_double * 6)()
+    peers, counts, idx = (C.c_int * 1)(), (C.c_int64 * 1)(), (C.c_void_p * 1)()
+    L.check(L.lib.phx_solve_distributed(be.sys, comm, 0, peers, counts, idx, 1e-10, 20000,
+                                        C.c_void_p(out.data_ptr()), L.DEVICE, st))
+    torch.cuda.synchronize()
+    assert int(st[0]) == res["iterations"]
+    assert torch.allclose(out, native, rtol=0, atol=1e-9 * float(native.abs().max()))
+    # halo code path (pack kernel -> ncclSend/ncclRecv -> unpack kernel) with the rank as its own
+    # neighbour: entries at `recv` positions must come back as the entries at `send` positions
+    n = be.n
+    vec = torch.arange(n, dtype=torch.float64, device=dev)
+    k = n // 4
+    assert 3 * k + 2 < n
+    send = torch.arange(0, k, dtype=torch.int64, device=dev) * 3 + 1
+    recv = torch.arange(0, k, dtype=torch.int64, device=dev) * 3 + 2
+    peers[0] = 0
+    counts2 = (C.c_int64 * 2)(k, k)
+    idx2 = (C.c_void_p * 2)(send.data_ptr(), recv.data_ptr())
+    L.check(L.lib.phx_halo_selftest(be.sys, comm, 1, peers, counts2, idx2, C.c_void_p(vec.data_ptr())))
+    torch.cuda.synchronize()
+    assert torch.equal(vec[recv], send.to(torch.float64))
+    assert torch.equal(vec[send], send.to(torch.float64))
+    L.check(L.lib.phx_comm_destroy(comm))
