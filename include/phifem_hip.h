@@ -204,7 +204,7 @@ int phx_solve(phx_system *s, int method, double rtol, int64_t max_iter, double *
  * The driver owns the loop, does the halo exchange of p / s before phases 2 / 4 and all-reduces
  * the 8 reduction scalars (scal[8..15]) after phases 0, 2, 4 and 5.  Vectors are in SOLVER order
  * (row i of the solver = active row perm[i]).
- *   work: 8 vectors of n doubles {r, rhat, p, v, s, t, y, b};  scal: 4112 doubles (16 scalars + 8 x 64 dot-product slots of 64 B)
+ *   work: 8 vectors of n doubles {r, rhat, p, v, s, t, y, b};  scal: 8208 doubles (16 scalars + 2 x 8 x 64 dot-product slots of 64 B)
  *   own : n bytes in solver order, 1 = this rank owns the row (NULL = all)                     */
 int phx_krylov_attach(phx_system *s, double *work, double *scal, const uint8_t *own);
 /* phase 0 begin, 1 begin2, 2 v=Ap, 3 s-update, 4 t=As, 5 x/r-update, 6 p-update + roll */

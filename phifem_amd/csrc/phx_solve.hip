@@ -36,7 +36,7 @@ static int64_t g_sell_window = (int64_t)1 << 40;
 #define NSLOT 64
 #define SLOT_STRIDE 8
 #define P_OFF 16
-#define PHX_SCAL_DOUBLES (P_OFF + 8 * NSLOT * SLOT_STRIDE)
+#define PHX_SCAL_DOUBLES (P_OFF + 2 * 8 * NSLOT * SLOT_STRIDE)  // two parity sets of slots
 
 // ---------------------------------------------------------------------------------------------
 // SELL construction
@@ -251,9 +251,18 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
 // launch sequence with no host round trip.  `own` (nullable) masks the rows this rank owns:
 // ghost rows are kept at zero and refreshed by the halo exchange of the driver.
 // ---------------------------------------------------------------------------------------------
-enum { S_RHO = 0, S_ALPHA = 1, S_OMEGA = 2, S_BB = 3, S_RR = 4 };
+enum { S_RHO = 0, S_ALPHA = 1, S_OMEGA = 2, S_BB = 3, S_RR = 4, S_RESTARTS = 5, S_RHO_NEXT = 6,
+       S_MODE = 7 };
 enum { R_RV = 0, R_TS = 1, R_TT = 2, R_SS = 3, R_RHO = 4, R_RR = 5 };
 #define R_OFF 8
+// S_MODE = 1: every dot product is folded into R by k_reduce_slots (and all-reduced by a
+// multi-GPU driver) before its consumer runs.  S_MODE = 0 (native single-GPU loop): consumers
+// fold the 64 slots themselves -- no reduce / roll launches; the slot sets alternate with the
+// iteration parity so that a set is cleared while nobody reads it.
+
+__host__ __device__ __forceinline__ double *slot_base(double *S, int par, int q) {
+  return S + P_OFF + ((par * 8 + q) * NSLOT) * SLOT_STRIDE;
+}
 
 __device__ __forceinline__ void block_atomic_sum(double v, double *out) {
   __shared__ double red[4];
@@ -265,15 +274,23 @@ __device__ __forceinline__ void block_atomic_sum(double v, double *out) {
   __syncthreads();
 }
 
-__host__ __device__ __forceinline__ double *slot_base(double *S, int q) { return S + P_OFF + q * NSLOT * SLOT_STRIDE; }
+// value of dot product q of the running iteration
+__device__ __forceinline__ double dotv(const double *S, int par, int q) {
+  if (S[S_MODE] != 0.0) return S[R_OFF + q];
+  const double *p = S + P_OFF + ((par * 8 + q) * NSLOT) * SLOT_STRIDE;
+  double v = 0.0;
+#pragma unroll 8
+  for (int k = 0; k < NSLOT; ++k) v += p[k * SLOT_STRIDE];
+  return v;
+}
 
-// fold the slots of quantities q0..q0+nq-1 into R and clear them (one wave)
-__global__ void k_reduce_slots(double *S, int q0, int nq) {
+// fold the slots of quantities q0..q0+nq-1 into R; `clear` also zeroes them (one wave)
+__global__ void k_reduce_slots(double *S, int par, int q0, int nq, int clear) {
   const int lane = threadIdx.x;
   for (int q = q0; q < q0 + nq; ++q) {
-    double *p = slot_base(S, q) + lane * SLOT_STRIDE;
+    double *p = slot_base(S, par, q) + lane * SLOT_STRIDE;
     double v = *p;
-    *p = 0.0;
+    if (clear) *p = 0.0;
     v = wave_sum(v);
     if (lane == 0) S[R_OFF + q] = v;
   }
@@ -295,36 +312,39 @@ k_kr_begin(int64_t n, const int32_t *__restrict__ perm, const double *__restrict
     b[i] = bi; r[i] = bi; rhat[i] = bi; p[i] = bi; y[i] = 0.0;
     acc += bi * bi;
   }
-  block_atomic_sum(acc, slot_base(S, R_RHO));
+  block_atomic_sum(acc, slot_base(S, 0, R_RHO));
 }
 
-// after the (optional) all-reduce of R: rho = bb = R_RHO; clear R
-__global__ void k_kr_begin2(double *S) {
+// after the (optional) all-reduce of R: rho = bb = R_RHO
+__global__ void k_kr_begin2(double *S, int mode) {
+  S[S_MODE] = mode ? 1.0 : 0.0;
   S[S_RHO] = S[R_OFF + R_RHO];
+  S[S_RHO_NEXT] = S[R_OFF + R_RHO];
   S[S_BB] = S[R_OFF + R_RHO];
   S[S_RR] = S[R_OFF + R_RHO];
 }
 
 // s = r - alpha v, alpha = rho/(rhat,v)
 __global__ void __launch_bounds__(256)
-k_update_s(int64_t n, const uint8_t *__restrict__ own, const double *__restrict__ r,
+k_update_s(int64_t n, int par, const uint8_t *__restrict__ own, const double *__restrict__ r,
            const double *__restrict__ v, double *__restrict__ sv, double *__restrict__ S) {
-  const double alpha = S[S_RHO] / S[R_OFF + R_RV];
+  const double rho = S[S_RHO_NEXT];
+  const double alpha = rho / dotv(S, par, R_RV);
   GRID_STRIDE(i, n) {
     const bool mine = !own || own[i];
     sv[i] = mine ? r[i] - alpha * v[i] : 0.0;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) S[S_ALPHA] = alpha;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { S[S_ALPHA] = alpha; S[S_RHO] = rho; }
 }
 
 // x += alpha p + omega s;  r = s - omega t;  accumulates rho_next = (rhat,r) and (r,r)
 __global__ void __launch_bounds__(256)
-k_update_xr(int64_t n, const uint8_t *__restrict__ own, const double *__restrict__ p,
+k_update_xr(int64_t n, int par, const uint8_t *__restrict__ own, const double *__restrict__ p,
             const double *__restrict__ sv, const double *__restrict__ t,
             const double *__restrict__ rhat, double *__restrict__ x, double *__restrict__ r,
             double *__restrict__ S) {
   const double alpha = S[S_ALPHA];
-  const double omega = S[R_OFF + R_TS] / S[R_OFF + R_TT];
+  const double omega = dotv(S, par, R_TS) / dotv(S, par, R_TT);
   double a0 = 0.0, a1 = 0.0;
   GRID_STRIDE(i, n) {
     const bool mine = !own || own[i];
@@ -338,43 +358,46 @@ k_update_xr(int64_t n, const uint8_t *__restrict__ own, const double *__restrict
     a0 += rhat[i] * ri;
     a1 += ri * ri;
   }
-  block_atomic_sum(a0, slot_base(S, R_RHO));
-  block_atomic_sum(a1, slot_base(S, R_RR));
+  block_atomic_sum(a0, slot_base(S, par, R_RHO));
+  block_atomic_sum(a1, slot_base(S, par, R_RR));
   if (blockIdx.x == 0 && threadIdx.x == 0) S[S_OMEGA] = omega;
 }
 
 // Breakdown guard: when (rhat, r) has collapsed relative to (r, r) (or a scalar went non-finite)
 // the iteration is RESTARTED from the current residual: rhat = p = r, rho = (r, r).  Every thread
-// evaluates the same predicate from the same device scalars, so p-update and roll agree.
-__device__ __forceinline__ bool kr_restart(const double *S) {
-  const double rho_new = S[R_OFF + R_RHO], rr = S[R_OFF + R_RR];
+// evaluates the same predicate from the same device scalars.
+__device__ __forceinline__ bool kr_restart(const double *S, double rho_new, double rr) {
   const double beta = (rho_new / S[S_RHO]) * (S[S_ALPHA] / S[S_OMEGA]);
   return !(fabs(beta) <= 1.0e300) || !(fabs(rho_new) > 1.0e-14 * rr);
 }
 
-// p = r + beta (p - omega v), beta = (rho_next/rho)(alpha/omega)
+// p = r + beta (p - omega v), beta = (rho_next/rho)(alpha/omega); rolls rho for the next
+// iteration and clears the slot set the next iteration accumulates into
 __global__ void __launch_bounds__(256)
-k_update_p(int64_t n, const uint8_t *__restrict__ own, const double *__restrict__ r,
+k_update_p(int64_t n, int par, const uint8_t *__restrict__ own, const double *__restrict__ r,
            const double *__restrict__ v, double *__restrict__ p, double *__restrict__ rhat,
-           const double *__restrict__ S) {
-  if (kr_restart(S)) {
+           double *__restrict__ S) {
+  const double rho_new = dotv(S, par, R_RHO), rr = dotv(S, par, R_RR);
+  const bool restart = kr_restart(S, rho_new, rr);
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      S[S_RHO_NEXT] = restart ? rr : rho_new;
+      S[S_RR] = rr;
+      if (restart) S[S_RESTARTS] += 1.0;
+    }
+    double *nxt = S + P_OFF + ((par ^ 1) * 8 * NSLOT) * SLOT_STRIDE;
+    for (int k = threadIdx.x; k < 8 * NSLOT; k += blockDim.x) nxt[k * SLOT_STRIDE] = 0.0;
+  }
+  if (restart) {
     GRID_STRIDE(i, n) { const double ri = r[i]; p[i] = ri; rhat[i] = ri; }
     return;
   }
-  const double beta = (S[R_OFF + R_RHO] / S[S_RHO]) * (S[S_ALPHA] / S[S_OMEGA]);
+  const double beta = (rho_new / S[S_RHO]) * (S[S_ALPHA] / S[S_OMEGA]);
   const double omega = S[S_OMEGA];
   GRID_STRIDE(i, n) {
     const bool mine = !own || own[i];
     p[i] = mine ? r[i] + beta * (p[i] - omega * v[i]) : 0.0;
   }
-}
-
-// end of an iteration: roll rho (or (r,r) after a restart), remember (r,r)
-__global__ void k_kr_roll(double *S) {
-  const bool restart = kr_restart(S);
-  S[S_RHO] = restart ? S[R_OFF + R_RR] : S[R_OFF + R_RHO];
-  S[S_RR] = S[R_OFF + R_RR];
-  if (restart) S[5] += 1.0;  // restart counter
 }
 
 __global__ void k_gather(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ in,
@@ -461,10 +484,11 @@ static int prof_collect(phx_system *s, double *avg_s, int *count) {
 }
 
 // phases: 0 begin (local (b,b) -> R_RHO), 1 begin2 (after all-reduce), 2 v = A p (+R_RV),
-// 3 s-update, 4 t = A s (+R_TS, R_TT), 5 x/r-update (+R_RHO, R_RR), 6 p-update + roll
-extern "C" int phx_krylov_phase(phx_system *s, int phase) {
+// 3 s-update, 4 t = A s (+R_TS, R_TT), 5 x/r-update (+R_RHO, R_RR), 6 p-update + roll.
+// mode 1 (phase API, multi-GPU): every dot product is folded into R right after its producer so
+// the driver can all-reduce it; mode 0 (native loop): consumers fold the slots, `par` alternates.
+static int kr_phase(phx_system *s, int phase, int mode, int par) {
   phx_mesh *m = s->mesh;
-  PHX_HIP(hipSetDevice(m->device));
   const int64_t n = s->n;
   hipStream_t st = m->stream;
   const KrVecs V = kr_vecs(s);
@@ -474,33 +498,32 @@ extern "C" int phx_krylov_phase(phx_system *s, int phase) {
     case 0:
       PHX_HIP(hipMemsetAsync(S, 0, sizeof(double) * PHX_SCAL_DOUBLES, st));
       k_kr_begin<<<vec_grid(n), block, 0, st>>>(n, s->perm, s->rhs, s->own, V.b, V.r, V.rhat, V.p, V.y, S);
-      k_reduce_slots<<<1, 64, 0, st>>>(S, R_RHO, 1);
+      k_reduce_slots<<<1, 64, 0, st>>>(S, 0, R_RHO, 1, 1);
       break;
     case 1:
-      k_kr_begin2<<<1, 1, 0, st>>>(S);
+      k_kr_begin2<<<1, 1, 0, st>>>(S, mode);
       break;
     case 2:
       PHX_CHECK(prof_begin(s));
-      PHX_CHECK(launch_spmv(s, s->sell_val, V.p, V.v, 1, V.rhat, slot_base(S, R_RV), nullptr));
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.p, V.v, 1, V.rhat, slot_base(S, par, R_RV), nullptr));
       PHX_CHECK(prof_end(s));
-      k_reduce_slots<<<1, 64, 0, st>>>(S, R_RV, 1);
+      if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_RV, 1, 1);
       break;
     case 3:
-      k_update_s<<<vec_grid(n), block, 0, st>>>(n, s->own, V.r, V.v, V.sv, S);
+      k_update_s<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.r, V.v, V.sv, S);
       break;
     case 4:
       PHX_CHECK(prof_begin(s));
-      PHX_CHECK(launch_spmv(s, s->sell_val, V.sv, V.t, 2, V.sv, slot_base(S, R_TS), slot_base(S, R_TT)));
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.sv, V.t, 2, V.sv, slot_base(S, par, R_TS), slot_base(S, par, R_TT)));
       PHX_CHECK(prof_end(s));
-      k_reduce_slots<<<1, 64, 0, st>>>(S, R_TS, 2);
+      if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_TS, 2, 1);
       break;
     case 5:
-      k_update_xr<<<vec_grid(n), block, 0, st>>>(n, s->own, V.p, V.sv, V.t, V.rhat, V.y, V.r, S);
-      k_reduce_slots<<<1, 64, 0, st>>>(S, R_RHO, 2);
+      k_update_xr<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.p, V.sv, V.t, V.rhat, V.y, V.r, S);
+      if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_RHO, 2, 1);
       break;
     case 6:
-      k_update_p<<<vec_grid(n), block, 0, st>>>(n, s->own, V.r, V.v, V.p, V.rhat, S);
-      k_kr_roll<<<1, 1, 0, st>>>(S);
+      k_update_p<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.r, V.v, V.p, V.rhat, S);
       break;
     default:
       phx_set_error("unknown Krylov phase %d", phase);
@@ -508,6 +531,11 @@ extern "C" int phx_krylov_phase(phx_system *s, int phase) {
   }
   PHX_HIP(hipGetLastError());
   return PHX_OK;
+}
+
+extern "C" int phx_krylov_phase(phx_system *s, int phase) {
+  PHX_HIP(hipSetDevice(s->mesh->device));
+  return kr_phase(s, phase, 1, 0);
 }
 
 // x = D^-1 y scattered to FULL numbering, inactive (and non-owned) DoFs = 0
@@ -559,8 +587,8 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
   const int check_every = 8;
   PHX_CHECK(prof_reset(s));
   PHX_CHECK(phx_begin_timing(m));
-  PHX_CHECK(phx_krylov_phase(s, 0));
-  PHX_CHECK(phx_krylov_phase(s, 1));
+  PHX_CHECK(kr_phase(s, 0, 0, 0));
+  PHX_CHECK(kr_phase(s, 1, 0, 0));
   PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
   PHX_HIP(hipStreamSynchronize(st));
   const double bb = s->scal_h[S_BB];
@@ -568,25 +596,26 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
   double relres = bb == 0.0 ? 0.0 : 1.0;
   int rc = PHX_OK;
   while (bb != 0.0 && it < max_iter) {
-    for (int ph = 2; ph <= 5; ++ph) PHX_CHECK(phx_krylov_phase(s, ph));
+    const int par = (int)(it & 1);
+    for (int ph = 2; ph <= 5; ++ph) PHX_CHECK(kr_phase(s, ph, 0, par));
     spmvs += 2;
     ++it;
     if ((it % check_every == 0) || it == max_iter) {
+      // fold (r,r) and (rhat,r) of this iteration for the host, without clearing the slots
+      k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_RHO, 2, 0);
       PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
       PHX_HIP(hipStreamSynchronize(st));
-      const double rr = s->scal_h[R_OFF + R_RR], rho = s->scal_h[R_OFF + R_RHO];
+      const double rr = s->scal_h[R_OFF + R_RR];
       const double omega = s->scal_h[S_OMEGA];
       relres = sqrt(rr / bb);
-      (void)rho;
       if (!(rr == rr) || !(fabs(rr) <= 1.0e300) || !(omega == omega)) {
-        phx_set_error("BiCGStab breakdown at iteration %lld (rho=%g omega=%g rr=%g)",
-                      (long long)it, rho, omega, rr);
+        phx_set_error("BiCGStab breakdown at iteration %lld (omega=%g rr=%g)", (long long)it, omega, rr);
         rc = PHX_ERR_BREAKDOWN;
         break;
       }
       if (relres <= rtol) break;
     }
-    PHX_CHECK(phx_krylov_phase(s, 6));
+    PHX_CHECK(kr_phase(s, 6, 0, par));
   }
   // back to full numbering, x = D^-1 y, inactive DoFs = 0 (MUMPS ICNTL(24)=1 semantics)
   PHX_CHECK(phx_krylov_finish(s, x_out, loc));

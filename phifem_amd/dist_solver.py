@@ -18,7 +18,7 @@ import time
 import numpy as np
 
 HALO_PLANES = 2   # a row reaches vertices two planes away (facet macro-elements, main.py:129-134)
-SCAL_DOUBLES = 16 + 8 * 64 * 8
+SCAL_DOUBLES = 16 + 2 * 8 * 64 * 8
 R_OFF = 8
 R_RV, R_TS, R_TT, R_RHO, R_RR = 0, 1, 2, 4, 5
 S_BB = 3
