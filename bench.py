@@ -31,41 +31,28 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cubes", type=int, default=256, help="cubes per axis per GPU")
     ap.add_argument("--rtol", type=float, default=1e-8)
-    ap.add_argument("--cpu-n", type=int, default=64, help="box size of the CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=160, help="box size of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
 def cpu_baseline(n, rtol):
-    """The numpy/scipy oracle ("port", 1 core) on a bounded sample of the same workload:
-    the same sphere problem on an n^3 box; tag + assemble + Jacobi-BiCGStab (scipy)."""
-    import numpy as np
-    import scipy.sparse as sp
-    import scipy.sparse.linalg as spla
-    from oracle import assembly as OA, meshgen, tagging as OT
-    from oracle.topology import Topology
-    x, cells = meshgen.create_box([-1.5] * 3, [1.5] * 3, [n] * 3)
-    topo = Topology("tetrahedron", cells, x.shape[0])  # mesh/topology setup: untimed, as on the GPU
-    phi = (x ** 2).sum(axis=1) - 1.0
-    uex = np.prod(np.sin(x), axis=1)
-    t0 = time.perf_counter()
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        ct, ft, _, meas, _, _ = OT.compute_tags_measures("tetrahedron", x, topo, OT.NodalP1(phi), 1,
-                                                         box_mode=True, single_layer_cut=True)
-    cv = np.zeros(topo.nc, dtype=np.int64)
-    cv[ct.indices] = ct.values
-    A, b, act = OA.assemble_poisson_wd(topo, x, cv, ft.values, meas(100), phi, 3.0 * uex, uex)
-    idx = np.flatnonzero(act)
-    Aa = A[idx][:, idx].tocsr()
-    d = Aa.diagonal()
-    its = [0]
-    xs, info = spla.bicgstab(Aa, b[idx], M=sp.diags(1.0 / d), rtol=rtol, maxiter=20000,
-                             callback=lambda _: its.__setitem__(0, its[0] + 1))
-    dt = time.perf_counter() - t0
-    return {"value": idx.size / dt, "unit": "DoF/s", "cores": 1, "kind": "port",
-            "sample": f"numpy/scipy oracle, same sphere problem on a {n}^3 box: {idx.size} active "
-                      f"DoFs, tag+assemble+Jacobi-BiCGStab ({its[0]} it, rtol {rtol:g}) in {dt:.1f} s"}
+    """The C/OpenMP restatement of the same pipeline (oracle/phifem_oracle.c, "port": a CPU
+    restatement, NOT dolfinx/PETSc -- those are not installed here or on the GPU box) on a bounded
+    sample of the same workload: the same sphere problem on an n^3 box, all host cores.
+    Mesh generation is untimed, as on the GPU."""
+    from oracle import c_oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    r = c_oracle.poisson_sphere(n, threads=cores, rtol=rtol)
+    dt = r["t_tag"] + r["t_assemble"] + r["t_solve"]
+    r1 = c_oracle.poisson_sphere(max(n // 2, 8), threads=1, rtol=rtol)
+    dt1 = r1["t_tag"] + r1["t_assemble"] + r1["t_solve"]
+    return {"value": r["n_active"] / dt, "unit": "DoF/s", "cores": int(r["threads"]), "kind": "port",
+            "sample": f"C/OpenMP restatement (oracle/phifem_oracle.c), same sphere problem on a {n}^3 "
+                      f"box: {int(r['n_active'])} active DoFs, tag {r['t_tag']:.2f} s + assemble "
+                      f"{r['t_assemble']:.2f} s + Jacobi-BiCGStab {r['t_solve']:.2f} s "
+                      f"({int(r['iterations'])} it, rtol {rtol:g}); single core on {max(n // 2, 8)}^3: "
+                      f"{r1['n_active'] / dt1:.0f} DoF/s"}
 
 
 def spmv_traffic(cubes):
