@@ -24,8 +24,14 @@ class NodalFunction:
     `dolfinx.fem.Function` in a first-order Lagrange space).  `values` may be a numpy array or
     a torch tensor living on the mesh's GPU."""
 
-    def __init__(self, values):
+    def __init__(self, values, degree=1):
+        """degree 1: one value per vertex.  degree 2: vertex values then edge-midpoint values
+        (`mesh.p2_dof_points()`); evaluated at the detection points by P2 tabulation on the host
+        and classified on the device (PHX_PHI_POINTS)."""
+        if degree not in (1, 2):
+            raise NotImplementedError("level-set functions of degree 1 and 2 are implemented")
         self.values = values
+        self.degree = degree
 
 
 class Quadric:
@@ -68,6 +74,10 @@ class BoundaryMeasure:
 
 def _levelset_args(mesh, levelset, degree):
     """-> (phi_kind, pointer, loc, keepalive)."""
+    if isinstance(levelset, NodalFunction) and levelset.degree == 2:
+        vals = _evaluate_p2(mesh, np.asarray(levelset.values, dtype=np.float64), degree)
+        p, loc = L.ptr(vals)
+        return L.PHI_POINTS, p, loc, vals
     if isinstance(levelset, NodalFunction):
         v = levelset.values
         if not hasattr(v, "data_ptr"):
@@ -124,6 +134,50 @@ def _push(N, xv):
     for i in range(1, N.shape[1]):
         acc = acc + N[None, :, i, None] * xv[:, None, i, :]
     return acc  # (n, npts, gdim)
+
+
+_EDGE_VERTS = {
+    "triangle": np.array([[1, 2], [0, 2], [0, 1]]),
+    "tetrahedron": np.array([[2, 3], [1, 3], [1, 2], [0, 3], [0, 2], [0, 1]]),
+}
+
+
+def _p2_tab(cell_type, lam):
+    """P2 basis at barycentric points lam (npts, n): vertex functions then edge functions."""
+    n = lam.shape[1]
+    ev = _EDGE_VERTS[cell_type]
+    N = np.empty((lam.shape[0], n + ev.shape[0]))
+    for i in range(n):
+        N[:, i] = lam[:, i] * (2.0 * lam[:, i] - 1.0)
+    for k, (a, b) in enumerate(ev):
+        N[:, n + k] = 4.0 * lam[:, a] * lam[:, b]
+    return N
+
+
+def _evaluate_p2(mesh, nodal, degree):
+    """phi_h in P2 (vertex + edge values) at the cell detection points and at the facet detection
+    points of the background-boundary facets (layout of PHX_PHI_POINTS)."""
+    if mesh.cell_type not in _EDGE_VERTS:
+        raise NotImplementedError("P2 level-sets are implemented on simplices")
+    cells, c2e = mesh.cells, mesh.c2e
+    if nodal.shape[0] != mesh.nv + mesh.ne:
+        raise ValueError("a P2 level-set has one value per vertex and per edge")
+    cell_dofs = np.concatenate([cells, mesh.nv + c2e], axis=1)
+    lam_c = _shape(mesh.cell_type, _ref_points(mesh.cell_type, degree, 0))      # P1 shape = barycentric
+    vc = nodal[cell_dofs] @ _p2_tab(mesh.cell_type, lam_c).T                      # (nc, npts)
+    bf = mesh.boundary_facets
+    ftype = "interval" if mesh.tdim == 2 else "triangle"
+    mu = _shape(ftype, _ref_points(mesh.cell_type, degree, 1))                   # (nq, nvpf)
+    fv = _FACET_VERTS[mesh.cell_type]
+    vf = np.empty((bf.shape[0], mu.shape[0]))
+    for lf in range(fv.shape[0]):
+        sel = np.flatnonzero(bf[:, 1] == lf)
+        if sel.size == 0:
+            continue
+        lam = np.zeros((mu.shape[0], cells.shape[1]))
+        lam[:, fv[lf]] = mu
+        vf[sel] = nodal[cell_dofs[bf[sel, 0]]] @ _p2_tab(mesh.cell_type, lam).T
+    return np.ascontiguousarray(np.concatenate([vc.reshape(-1), vf.reshape(-1)]))
 
 
 def _evaluate_callable(mesh, f, degree):

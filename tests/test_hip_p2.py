@@ -158,3 +158,29 @@ def test_p2_solve_vs_direct_2d(P):
     assert np.abs(w - wo).max() <= 1e-6 * np.abs(wo).max()
     inside = np.unique(V.cell_dofs[work.cell_tag_values() == 1])
     assert np.abs(w[:V.ndofs][inside] - uex[inside]).max() < 5e-2
+
+
+@pytest.mark.parametrize("mesh_name,data", [("disk", "circle_in_circle"), ("square_tri", "nasty_smooth")])
+@pytest.mark.parametrize("deg", [1, 2, 3])
+def test_tagging_with_p2_levelset(P, mesh_name, data, deg):
+    """A level-set given as a P2 function (a2: "P_k nodal values"): for a quadratic phi the P2
+    interpolant IS phi, so the tags must equal those of the closed form, at every detection
+    degree."""
+    from datasets import MESHTAG_DATA
+    from phifem_amd.mesh_scripts import NodalFunction
+    ctype, x, cells = load_mesh(mesh_name)
+    m = P.Mesh.from_arrays(ctype, x, cells)
+    if data == "circle_in_circle":
+        f = MESHTAG_DATA[data][1]
+    else:
+        def f(xx):
+            return 0.7 * xx[0] ** 2 - 0.4 * xx[0] * xx[1] + 1.3 * xx[1] ** 2 + 0.2 * xx[0] - 0.9
+    pts = m.p2_dof_points()
+    nod = f(pts.T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c2, f2 = P.compute_tags_measures(m, NodalFunction(nod, degree=2), deg, box_mode=True)[:2]
+        c1, f1 = P.compute_tags_measures(m, f, deg, box_mode=True)[:2]
+    # identical up to exact-compare degeneracies of round-off (none on these data)
+    assert np.array_equal(c2.values, c1.values)
+    assert np.array_equal(f2.values, f1.values)
