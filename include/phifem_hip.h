@@ -181,6 +181,18 @@ int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab_coef, cons
 int phx_assemble_poisson_wd_p2(phx_mesh *m, double pen_coef, double stab_coef, const double *phi_h,
                                int phi_degree, const double *f_h, const double *u_D, int loc,
                                phx_system **out);
+/* Interface linear elasticity, 5-field mixed phi-FEM (u_in, u_out, y_in, y_out, p), all P1:
+ * demo/interface-elasticity/main.py:179-235 (bilinear form) + assemble_matrix(bcs) :237-239, linear
+ * form :255-269 + apply_lifting / bc.set :271-277, material law data.py:5-36, on the tags held by
+ * the mesh (box mode: dx((1,2)), dx((2,3)), dx(2), dS(3), dS(4), d_bdry(100), d_bdry(101)).
+ *   params[6] = {E_in, nu_in, E_out, nu_out, penalization_coefficient, stabilization_coefficient}
+ *   phi_h[nv]; f_h, u_D: [d*nv] component-major nodal vector fields; bc_vertices[nbc]: vertices
+ *   where u_in = u_D is imposed (main.py:158-177).
+ * DoF layout: component-major blocks of nv: u_in[a] -> a, u_out[a] -> d+a, y_in[a][b] -> 2d+a d+b,
+ * y_out[a][b] -> 2d+d^2+a d+b, p[a] -> 2d+2d^2+a; phx_solve returns x[(2d+2d^2+d)*nv]. */
+int phx_assemble_elasticity_if(phx_mesh *m, const double *params, const double *phi_h,
+                               const double *f_h, const double *u_D, const int32_t *bc_vertices,
+                               int64_t nbc, int loc, phx_system **out);
 int phx_system_destroy(phx_system *s);
 /* info[8] = {n_active, n_active_u, nnz (structural, CSR), n_full (= 2*nv), sell_padded_nnz,
  *            slot_capacity, sell_nnz (explicit zeros dropped), n_slices} */

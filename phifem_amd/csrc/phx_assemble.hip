@@ -606,6 +606,9 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   else if (W == 512)
     k_row_fill_block<512><<<dim3((unsigned)s->n), dim3(512), 0, m->stream>>>(
         s->n, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
+  else if (W == 1024)
+    k_row_fill_block<1024><<<dim3((unsigned)s->n), dim3(1024), 0, m->stream>>>(
+        s->n, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
   else {
     phx_set_error("unsupported slot capacity %d", W);
     return PHX_ERR_VALUE;
@@ -801,3 +804,4 @@ extern "C" int phx_system_export(phx_system *s, int64_t *rowptr, int32_t *col, d
 }
 
 #include "phx_assemble_p2.inc.hip"
+#include "phx_assemble_el.inc.hip"

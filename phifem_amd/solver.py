@@ -101,7 +101,7 @@ class PhiFEMSolver:
         """Replaces the KSP/MUMPS block of main.py:162-182.  Returns the mixed solution in the
         full numbering [u (nv), p (nv)] with inactive DoFs at zero; `out` may be a device
         tensor of 2*nv doubles."""
-        nfull = 2 * self.ndofs
+        nfull = self.info()["n_full"]
         if out is None:
             out = np.empty(nfull, dtype=np.float64)
         p, loc = L.ptr(out)
@@ -127,3 +127,50 @@ class PhiFEMSolver:
         o = (C.c_double * 3)()
         L.check(L.lib.phx_spmv_bench(self._sys, int(reps), o))
         return {"ms": o[0], "algorithmic_bytes": o[1], "padded_bytes": o[2]}
+
+
+class InterfaceElasticitySolver(PhiFEMSolver):
+    """Two-material linear elasticity with a level-set interface, 5-field mixed phi-FEM
+    (u_in, u_out, y_in, y_out, p), all first-order Lagrange: the assemble -> solve sequence of
+    demo/interface-elasticity/main.py:145-289 over the C ABI (`phx_assemble_elasticity_if`).
+
+    The mesh must be tagged in box mode (main.py:115-117).  Solution layout: component-major
+    blocks of nv entries, see `blocks()`."""
+
+    def __init__(self, mesh, E_in=1.0, nu_in=0.3, E_out=1.0e-3, nu_out=0.3,
+                 penalization_coefficient=1.0, stabilization_coefficient=1.0):
+        # material parameters demo/interface-elasticity/data.py:14-22, coefficients param1.yaml:16-17
+        super().__init__(mesh)
+        self.params = np.array([E_in, nu_in, E_out, nu_out, penalization_coefficient,
+                                stabilization_coefficient], dtype=np.float64)
+
+    def assemble(self, phi_h, f_h, u_D, bc_vertices):
+        """phi_h: (nv,) nodal level-set; f_h, u_D: (nv, d) nodal vector fields; bc_vertices:
+        vertices where u_in = u_D is imposed (the box boundary in the demo, main.py:158-177)."""
+        self._free()
+        m = self.mesh
+        d = m.gdim
+        phi_h = np.ascontiguousarray(phi_h, dtype=np.float64)
+        f_cm = np.ascontiguousarray(np.asarray(f_h, dtype=np.float64).T)   # component-major
+        u_cm = np.ascontiguousarray(np.asarray(u_D, dtype=np.float64).T)
+        bcv = np.ascontiguousarray(bc_vertices, dtype=np.int32)
+        if phi_h.shape[0] != m.nv or f_cm.shape != (d, m.nv) or u_cm.shape != (d, m.nv):
+            raise ValueError("phi_h must be (nv,), f_h and u_D (nv, d)")
+        if bcv.size and (bcv.min() < 0 or bcv.max() >= m.nv):
+            raise ValueError("bc_vertices out of range")
+        h = C.c_void_p()
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        L.check(L.lib.phx_assemble_elasticity_if(m._h, vp(self.params), vp(phi_h), vp(f_cm), vp(u_cm),
+                                                 vp(bcv), bcv.size, L.HOST, C.byref(h)))
+        self._sys = h
+        return self.info()
+
+    def blocks(self, w):
+        """Split the solution: dict of (nv, d) / (nv, d, d) arrays (solution_wh.split(), main.py:291)."""
+        m = self.mesh
+        d, nv = m.gdim, m.nv
+        w = np.asarray(w).reshape(-1, nv)
+        return {"u_in": w[0:d].T, "u_out": w[d:2 * d].T,
+                "y_in": w[2 * d:2 * d + d * d].T.reshape(nv, d, d),
+                "y_out": w[2 * d + d * d:2 * d + 2 * d * d].T.reshape(nv, d, d),
+                "p": w[2 * d + 2 * d * d:].T}
