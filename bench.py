@@ -31,9 +31,32 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cubes", type=int, default=256, help="cubes per axis per GPU")
     ap.add_argument("--rtol", type=float, default=1e-8)
-    ap.add_argument("--cpu-n", type=int, default=160, help="box size of the CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=0,
+                    help="box size of the CPU-baseline sample (0: the full 256^3 workload when the host "
+                         "grants >= 12 cores, else 160^3; ~10-30 s of CPU work either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
+
+
+def host_cores(cap=16):
+    """Threads for the CPU baseline: the CPU share of this process (affinity mask, cgroup quota),
+    never more than `cap` -- a GPU box exposes every core of the host (256) but grants one GPU's
+    share (16); oversubscribing OpenMP there turns seconds into minutes."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, cap))
 
 
 def cpu_baseline(n, rtol):
@@ -42,7 +65,7 @@ def cpu_baseline(n, rtol):
     sample of the same workload: the same sphere problem on an n^3 box, all host cores.
     Mesh generation is untimed, as on the GPU."""
     from oracle import c_oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     r = c_oracle.poisson_sphere(n, threads=cores, rtol=rtol)
     dt = r["t_tag"] + r["t_assemble"] + r["t_solve"]
     r1 = c_oracle.poisson_sphere(max(n // 2, 8), threads=1, rtol=rtol)
@@ -153,7 +176,8 @@ def main():
             },
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, args.rtol)
+            cpu_n = args.cpu_n or (256 if host_cores() >= 12 else 160)
+            out["cpu_baseline"] = cpu_baseline(cpu_n, args.rtol)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -194,7 +194,17 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
             const uint8_t *__restrict__ own, const double *__restrict__ d0,
             double *__restrict__ out0, double *__restrict__ out1) {
   const int lane = threadIdx.x & 63;
-  const int64_t s = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  // XCD-aware block -> slice-group map: blocks b and b+8 share an XCD (and its 4 MiB L2), so XCD k
+  // is given the k-th CONTIGUOUS eighth of the slices; the x entries its rows gather then live in
+  // one L2 instead of being pulled into all eight (speed only; any placement is correct).
+  int64_t bid = blockIdx.x;
+#ifdef PHX_SPMV_XCD
+  {
+    const int64_t nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+#endif
+  const int64_t s = bid * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   double acc = 0.0;
   int64_t row = -1;
   if (s < nslices) {
