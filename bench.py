@@ -35,6 +35,9 @@ def parse():
                     help="box size of the CPU-baseline sample (0: the full 256^3 workload when the host "
                          "grants >= 12 cores, else 160^3; ~10-30 s of CPU work either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE configs[4]: 1024 x 1024 x 128 cubes per GPU (805 306 368 tets), unit "
+                         "sphere, 1024^3 box at 8 GPUs; not the default workload")
     return ap.parse_args()
 
 
@@ -116,8 +119,9 @@ def main():
     import phifem_amd as P
     from phifem_amd import distributed as D
 
-    n = args.cubes
-    prob = D.SlabProblem(n_per_rank=n, rank=rank, world=world, device=local_rank, rtol=args.rtol)
+    n = 128 if args.config5 else args.cubes
+    prob = D.SlabProblem(n_per_rank=n, rank=rank, world=world, device=local_rank, rtol=args.rtol,
+                         nxy=1024 if args.config5 else None)
     prob.setup()  # mesh generation + nodal data on the device: inputs resident before timing
 
     def barrier():
@@ -157,9 +161,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"3D weak-Dirichlet Poisson phi-FEM, P1xP1, spherical level-set, "
-                            f"{n}^3 Kuhn box per GPU ({6 * n ** 3} tets), box mode, "
-                            f"single-layer cut, gamma=sigma=1",
+                "workload": (f"3D weak-Dirichlet Poisson phi-FEM, P1xP1, spherical level-set, "
+                             f"{n}^3 Kuhn box per GPU ({6 * n ** 3} tets), box mode, "
+                             f"single-layer cut, gamma=sigma=1") if not args.config5 else
+                            ("3D weak-Dirichlet Poisson phi-FEM, P1xP1, unit sphere, 1024x1024x128 Kuhn "
+                             "slab per GPU (805306368 tets), box mode, single-layer cut, gamma=sigma=1"),
                 "active_dofs": n_active, "krylov": "BiCGStab + Jacobi (right)",
                 "rtol": args.rtol, "iterations": res["iterations"], "relres": res["relres"],
                 "stage_ms": {k: 1e3 * v for k, v in res["stage_s"].items()},

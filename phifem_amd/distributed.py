@@ -32,29 +32,37 @@ class SlabProblem:
     """BASELINE configs[1] per GPU, weak-scaled: n^3 cubes per rank of an n x n x (n*world) box
     on [-1.5,1.5]^2 x [-1.5*world, 1.5*world] around x^2 + y^2 + (z/world)^2 = 1."""
 
-    def __init__(self, n_per_rank, rank=0, world=1, device=0, rtol=1e-8, max_iter=20000):
+    def __init__(self, n_per_rank, rank=0, world=1, device=0, rtol=1e-8, max_iter=20000, nxy=None):
+        """nxy = None: BASELINE configs[1] weak-scaled (n^3 cubes per rank, ellipsoid).
+        nxy = 1024, n_per_rank = 128: BASELINE configs[4] -- the 1024^3 box of [-1.5,1.5]^3 cut into
+        eight 1024 x 1024 x 128 slabs; with `world` < 8 ranks the z-range shrinks to [-1.5 world/8, 1.5 world/8], around the UNIT SPHERE (same h)."""
         self.n, self.rank, self.world, self.device = n_per_rank, rank, world, device
+        self.nxy = nxy or n_per_rank
+        self.config5 = nxy is not None
         self.rtol, self.max_iter = rtol, max_iter
         self.lay = slab_layout(n_per_rank, rank, world)
 
     def setup(self):
         import torch
         n, w, lay = self.n, self.world, self.lay
-        lo = [-1.5, -1.5, -1.5 * w]
-        hi = [1.5, 1.5, 1.5 * w]
-        self.mesh = create_box(lo, hi, [n, n, lay["k1"] - lay["k0"]], device=self.device,
-                               offset=[0, 0, lay["k0"]], n_global=[n, n, lay["nz"]])
+        nxy = self.nxy
+        zext = 1.5 * w * n / nxy if self.config5 else 1.5 * w   # same h in z as in x and y
+        lo = [-1.5, -1.5, -zext]
+        hi = [1.5, 1.5, zext]
+        self.mesh = create_box(lo, hi, [nxy, nxy, lay["k1"] - lay["k0"]], device=self.device,
+                               offset=[0, 0, lay["k0"]], n_global=[nxy, nxy, lay["nz"]])
         # the slab's end planes inside the global box are cuts, not background boundary
         L.check(L.lib.phx_mesh_set_slab_faces(self.mesh._h, 1 if lay["k0"] > 0 else 0,
                                               1 if lay["k1"] < lay["nz"] else 0))
         dev = torch.device("cuda", self.device)
         x = torch.empty((self.mesh.nv, 3), dtype=torch.float64, device=dev)
         L.check(L.lib.phx_mesh_get_array(self.mesh._h, L.ARR_COORDS, C.c_void_p(x.data_ptr()), L.DEVICE))
-        zs = x[:, 2] / float(w)
+        zs = x[:, 2] if self.config5 else x[:, 2] / float(w)
+        zscale = 1.0 if self.config5 else float(w)
         self.phi = x[:, 0] ** 2 + x[:, 1] ** 2 + zs ** 2 - 1.0
-        # manufactured solution u = sin x sin y sin(z/w):  -Laplace(u) = (2 + 1/w^2) u
+        # manufactured solution u = sin x sin y sin(z/s):  -Laplace(u) = (2 + 1/s^2) u
         self.u_ex = torch.sin(x[:, 0]) * torch.sin(x[:, 1]) * torch.sin(zs)
-        self.f = (2.0 + 1.0 / float(w * w)) * self.u_ex
+        self.f = (2.0 + 1.0 / (zscale * zscale)) * self.u_ex
         self.out = torch.empty(2 * self.mesh.nv, dtype=torch.float64, device=dev)
         del x
         torch.cuda.synchronize()
