@@ -78,6 +78,8 @@ enum phx_array {          /* phx_mesh_get_array selectors */
 int phx_version(void);                     /* [host] ABI version (1) */
 const char *phx_last_error(void);          /* [host] */
 int phx_device_count(int *n);              /* [host] 0 GPUs is not an error here */
+/* Return the device memory cached by the library's allocator to the driver. */
+int phx_pool_release(void);
 
 /* [host] Detection points on the reference cell / reference facet: restates
  * _reference_{segment,triangle_boundary,square_boundary}_points (mesh_scripts.py:28-92) and

@@ -43,6 +43,7 @@ SIGNATURES = {
     "phx_version": ([], _i),
     "phx_last_error": ([], C.c_char_p),
     "phx_device_count": ([_pi], _i),
+    "phx_pool_release": ([], _i),
     "phx_detection_points": ([_i, _i, _i, _vp, _pi64], _i),
     "phx_topology_build_host": ([_i, _i64, _i64, _vp, _vp, _vp, _pi64], _i),
     "phx_mesh_create": ([_i, _i, _i64, _vp, _i64, _vp, _i, C.POINTER(_vp)], _i),

@@ -424,18 +424,18 @@ __global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const in
 template <typename Pred>
 static int build_list(phx_mesh *m, int64_t n, Pred pred, int32_t **list, int64_t *count) {
   int64_t *dcount = nullptr;
-  PHX_HIP(hipMalloc(list, sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
-  PHX_HIP(hipMalloc(&dcount, sizeof(int64_t)));
+  PHX_HIP(phx_malloc(list, sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
+  PHX_HIP(phx_malloc(&dcount, sizeof(int64_t)));
   hipcub::CountingInputIterator<int32_t> it(0);
   size_t bytes = 0;
   PHX_HIP(hipcub::DeviceSelect::If(nullptr, bytes, it, *list, dcount, (int)n, pred, m->stream));
   void *tmp = nullptr;
-  PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
   PHX_HIP(hipcub::DeviceSelect::If(tmp, bytes, it, *list, dcount, (int)n, pred, m->stream));
   PHX_HIP(hipMemcpyAsync(count, dcount, sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(tmp));
-  PHX_HIP(hipFree(dcount));
+  PHX_HIP(phx_free(tmp));
+  PHX_HIP(phx_free(dcount));
   return PHX_OK;
 }
 
@@ -524,10 +524,10 @@ static int exclusive_sum(phx_mesh *m, const T *in, T *out, int64_t n) {
   size_t bytes = 0;
   PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, m->stream));
   void *tmp = nullptr;
-  PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
   PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(tmp));
+  PHX_HIP(phx_free(tmp));
   return PHX_OK;
 }
 
@@ -540,14 +540,14 @@ static int scan_flags(phx_mesh *m, const uint8_t *flags, int32_t *out, int64_t n
   size_t bytes = 0;
   PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, (int)n, m->stream));
   void *tmp = nullptr;
-  PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
   PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, out, (int)n, m->stream));
   int32_t last = 0;
   uint8_t lastf = 0;
   PHX_HIP(hipMemcpyAsync(&last, out + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipMemcpyAsync(&lastf, flags + (n - 1), 1, hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(tmp));
+  PHX_HIP(phx_free(tmp));
   *total = last + (int32_t)lastf;
   return PHX_OK;
 }
@@ -560,7 +560,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
   void *ptrs[] = {s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active, s->rowptr, s->col,
                   s->val, s->rhs, s->diag, s->slice_ptr, s->sell_col, s->sell_val,
                   s->sell_val_raw, s->perm, s->iperm, s->work, s->scal};
-  for (void *p : ptrs) (void)hipFree(p);
+  for (void *p : ptrs) (void)phx_free(p);
   if (s->scal_h) (void)hipHostFree(s->scal_h);
   for (auto &e : s->prof_ev) (void)hipEventDestroy(e);
   delete s;
@@ -576,23 +576,23 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(hipMemcpyAsync(&overflow, sl.overflow, sizeof(int), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
   if (overflow) {
-    PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
+    PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow));
     phx_set_error("row-slot capacity %d exceeded", W);
     return PHX_ERR_CAPACITY;
   }
   int64_t *counts = nullptr;
-  PHX_HIP(hipMalloc(&counts, sizeof(int64_t) * (size_t)(s->n + 1)));
+  PHX_HIP(phx_malloc(&counts, sizeof(int64_t) * (size_t)(s->n + 1)));
   PHX_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(s->n + 1), m->stream));
-  PHX_HIP(hipMalloc(&s->rowptr, sizeof(int64_t) * (size_t)(s->n + 1)));
+  PHX_HIP(phx_malloc(&s->rowptr, sizeof(int64_t) * (size_t)(s->n + 1)));
   const dim3 growave((unsigned)phx_div_up(s->n * 64, 256));
   k_row_counts<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, counts);
   PHX_CHECK(exclusive_sum<int64_t>(m, counts, s->rowptr, s->n + 1));
   int64_t nnz = 0;
   PHX_HIP(hipMemcpy(&nnz, s->rowptr + s->n, sizeof(int64_t), hipMemcpyDeviceToHost));
   s->nnz = nnz;
-  PHX_HIP(hipMalloc(&s->col, sizeof(int32_t) * (size_t)nnz));
-  PHX_HIP(hipMalloc(&s->val, sizeof(double) * (size_t)nnz));
-  PHX_HIP(hipMalloc(&s->diag, sizeof(double) * (size_t)s->n));
+  PHX_HIP(phx_malloc(&s->col, sizeof(int32_t) * (size_t)nnz));
+  PHX_HIP(phx_malloc(&s->val, sizeof(double) * (size_t)nnz));
+  PHX_HIP(phx_malloc(&s->diag, sizeof(double) * (size_t)s->n));
   PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
   if (W <= 64)
     k_row_fill<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, s->rowptr, nent,
@@ -615,8 +615,8 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   }
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(counts));
-  PHX_HIP(hipFree(sl.cols)); PHX_HIP(hipFree(sl.vals)); PHX_HIP(hipFree(sl.overflow));
+  PHX_HIP(phx_free(counts));
+  PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow));
   return phx_system_build_sell(s);
 }
 
@@ -634,10 +634,10 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   // ---- active numbering
   uint8_t *fu = nullptr, *fp = nullptr;
   int32_t *su = nullptr, *sp = nullptr;
-  PHX_HIP(hipMalloc(&fu, (size_t)m->nv));
-  PHX_HIP(hipMalloc(&fp, (size_t)m->nv));
-  PHX_HIP(hipMalloc(&su, sizeof(int32_t) * (size_t)m->nv));
-  PHX_HIP(hipMalloc(&sp, sizeof(int32_t) * (size_t)m->nv));
+  PHX_HIP(phx_malloc(&fu, (size_t)m->nv));
+  PHX_HIP(phx_malloc(&fp, (size_t)m->nv));
+  PHX_HIP(phx_malloc(&su, sizeof(int32_t) * (size_t)m->nv));
+  PHX_HIP(phx_malloc(&sp, sizeof(int32_t) * (size_t)m->nv));
   PHX_HIP(hipMemsetAsync(fu, 0, (size_t)m->nv, m->stream));
   PHX_HIP(hipMemsetAsync(fp, 0, (size_t)m->nv, m->stream));
   const dim3 gcells((unsigned)phx_div_up(m->nc, 256));
@@ -649,23 +649,23 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   s->nu = nu;
   s->n = (int64_t)nu + np;
   PHX_REQUIRE(s->n > 0, PHX_ERR_VALUE, "no active DoF: no cell is tagged 1 or 2");
-  PHX_HIP(hipMalloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)m->nv));
-  PHX_HIP(hipMalloc(&s->dof_of_vertex_p, sizeof(int32_t) * (size_t)m->nv));
-  PHX_HIP(hipMalloc(&s->full_of_active, sizeof(int64_t) * (size_t)s->n));
+  PHX_HIP(phx_malloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)m->nv));
+  PHX_HIP(phx_malloc(&s->dof_of_vertex_p, sizeof(int32_t) * (size_t)m->nv));
+  PHX_HIP(phx_malloc(&s->full_of_active, sizeof(int64_t) * (size_t)s->n));
   k_finish_numbering<<<dim3((unsigned)phx_div_up(m->nv, 256)), block, 0, m->stream>>>(
       m->nv, fu, fp, su, sp, nu, s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active);
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(fu)); PHX_HIP(hipFree(fp)); PHX_HIP(hipFree(su)); PHX_HIP(hipFree(sp));
+  PHX_HIP(phx_free(fu)); PHX_HIP(phx_free(fp)); PHX_HIP(phx_free(su)); PHX_HIP(phx_free(sp));
   // ---- slots
   Slots sl;
   sl.W = W;
-  PHX_HIP(hipMalloc(&sl.cols, sizeof(int32_t) * (size_t)s->n * W));
-  PHX_HIP(hipMalloc(&sl.vals, sizeof(double) * (size_t)s->n * W));
-  PHX_HIP(hipMalloc(&sl.overflow, sizeof(int)));
+  PHX_HIP(phx_malloc(&sl.cols, sizeof(int32_t) * (size_t)s->n * W));
+  PHX_HIP(phx_malloc(&sl.vals, sizeof(double) * (size_t)s->n * W));
+  PHX_HIP(phx_malloc(&sl.overflow, sizeof(int)));
   PHX_HIP(hipMemsetAsync(sl.cols, 0xff, sizeof(int32_t) * (size_t)s->n * W, m->stream));
   PHX_HIP(hipMemsetAsync(sl.vals, 0, sizeof(double) * (size_t)s->n * W, m->stream));
   PHX_HIP(hipMemsetAsync(sl.overflow, 0, sizeof(int), m->stream));
-  PHX_HIP(hipMalloc(&s->rhs, sizeof(double) * (size_t)s->n));
+  PHX_HIP(phx_malloc(&s->rhs, sizeof(double) * (size_t)s->n));
   PHX_HIP(hipMemsetAsync(s->rhs, 0, sizeof(double) * (size_t)s->n, m->stream));
   AsmArgs A;
   A.cells = m->cells; A.x = m->x; A.ctags = m->cell_tags; A.ftags = m->facet_tags;
@@ -711,7 +711,7 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   }
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(l_cut)); PHX_HIP(hipFree(l_fac));
+  PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_fac));
   {
     const int rc = phx_finish_system(s, sl, (int32_t)m->nv);
     if (rc != PHX_OK) { phx_system_destroy(s); return rc; }
@@ -725,10 +725,10 @@ static int build_v2c(phx_mesh *m) {
   const int nvpc = m->ci.nvpc;
   const int64_t tot = m->nc * nvpc;
   unsigned long long *cnt = nullptr;
-  PHX_HIP(hipMalloc(&cnt, sizeof(unsigned long long) * (size_t)(m->nv + 1)));
+  PHX_HIP(phx_malloc(&cnt, sizeof(unsigned long long) * (size_t)(m->nv + 1)));
   PHX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long) * (size_t)(m->nv + 1), m->stream));
-  PHX_HIP(hipMalloc(&m->v2c_ptr, sizeof(int64_t) * (size_t)(m->nv + 1)));
-  PHX_HIP(hipMalloc(&m->v2c_idx, sizeof(int32_t) * (size_t)tot));
+  PHX_HIP(phx_malloc(&m->v2c_ptr, sizeof(int64_t) * (size_t)(m->nv + 1)));
+  PHX_HIP(phx_malloc(&m->v2c_idx, sizeof(int32_t) * (size_t)tot));
   const dim3 block(256), grid((unsigned)phx_div_up(tot, 256));
   k_v2c_count<<<grid, block, 0, m->stream>>>(m->nc, nvpc, m->cells, cnt);
   PHX_CHECK(exclusive_sum<int64_t>(m, (const int64_t *)cnt, m->v2c_ptr, m->nv + 1));
@@ -736,7 +736,7 @@ static int build_v2c(phx_mesh *m) {
   k_v2c_fill<<<grid, block, 0, m->stream>>>(m->nc, nvpc, m->cells, m->v2c_ptr, cnt, m->v2c_idx);
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(cnt));
+  PHX_HIP(phx_free(cnt));
   return PHX_OK;
 }
 
@@ -745,7 +745,7 @@ static int to_device(phx_mesh *m, const double *p, int loc, int64_t n, const dou
   *owned = nullptr;
   PHX_REQUIRE(p != nullptr, PHX_ERR_VALUE, "NULL nodal array");
   if (loc == PHX_DEVICE) { *dev = p; return PHX_OK; }
-  PHX_HIP(hipMalloc(owned, sizeof(double) * (size_t)n));
+  PHX_HIP(phx_malloc(owned, sizeof(double) * (size_t)n));
   PHX_HIP(hipMemcpyAsync(*owned, p, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, m->stream));
   *dev = *owned;
   return PHX_OK;
@@ -770,9 +770,9 @@ extern "C" int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab
   int rc = assemble_with_capacity(m, pen_coef, stab_coef, dphi, df, dud, W, out);
   if (rc == PHX_ERR_CAPACITY && W < 64) rc = assemble_with_capacity(m, pen_coef, stab_coef, dphi, df, dud, 64, out);
   if (rc == PHX_OK) rc = phx_end_timing(m, 2);
-  if (o1) (void)hipFree(o1);
-  if (o2) (void)hipFree(o2);
-  if (o3) (void)hipFree(o3);
+  if (o1) (void)phx_free(o1);
+  if (o2) (void)phx_free(o2);
+  if (o3) (void)phx_free(o3);
   return rc;
 }
 

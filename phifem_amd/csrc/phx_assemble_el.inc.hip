@@ -331,8 +331,8 @@ static int assemble_el_with_capacity(phx_mesh *m, const double *params, const do
   A.gamma = params[4]; A.sigma = params[5];
   uint8_t *flags = nullptr, *bc = nullptr;
   int32_t *scan = nullptr;
-  PHX_HIP(hipMalloc(&flags, (size_t)nent)); PHX_HIP(hipMalloc(&bc, (size_t)m->nv));
-  PHX_HIP(hipMalloc(&scan, sizeof(int32_t) * (size_t)nent));
+  PHX_HIP(phx_malloc(&flags, (size_t)nent)); PHX_HIP(phx_malloc(&bc, (size_t)m->nv));
+  PHX_HIP(phx_malloc(&scan, sizeof(int32_t) * (size_t)nent));
   PHX_HIP(hipMemsetAsync(flags, 0, (size_t)nent, m->stream));
   PHX_HIP(hipMemsetAsync(bc, 0, (size_t)m->nv, m->stream));
   A.bc = bc;
@@ -344,22 +344,22 @@ static int assemble_el_with_capacity(phx_mesh *m, const double *params, const do
   PHX_CHECK(scan_flags(m, flags, scan, nent, &n));
   s->n = n; s->nu = n;
   PHX_REQUIRE(n > 0, PHX_ERR_VALUE, "no active DoF");
-  PHX_HIP(hipMalloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)nent));
-  PHX_HIP(hipMalloc(&s->dof_of_vertex_p, sizeof(int32_t) * 4));
-  PHX_HIP(hipMalloc(&s->full_of_active, sizeof(int64_t) * (size_t)n));
+  PHX_HIP(phx_malloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)nent));
+  PHX_HIP(phx_malloc(&s->dof_of_vertex_p, sizeof(int32_t) * 4));
+  PHX_HIP(phx_malloc(&s->full_of_active, sizeof(int64_t) * (size_t)n));
   k_el_numbering<<<dim3((unsigned)phx_div_up(nent, 256)), block, 0, m->stream>>>(nent, flags, scan, s->dof_of_vertex_u, s->full_of_active);
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(flags)); PHX_HIP(hipFree(scan));
+  PHX_HIP(phx_free(flags)); PHX_HIP(phx_free(scan));
   A.dofmap = s->dof_of_vertex_u;
   Slots sl;
   sl.W = W;
-  PHX_HIP(hipMalloc(&sl.cols, sizeof(int32_t) * (size_t)n * W));
-  PHX_HIP(hipMalloc(&sl.vals, sizeof(double) * (size_t)n * W));
-  PHX_HIP(hipMalloc(&sl.overflow, sizeof(int)));
+  PHX_HIP(phx_malloc(&sl.cols, sizeof(int32_t) * (size_t)n * W));
+  PHX_HIP(phx_malloc(&sl.vals, sizeof(double) * (size_t)n * W));
+  PHX_HIP(phx_malloc(&sl.overflow, sizeof(int)));
   PHX_HIP(hipMemsetAsync(sl.cols, 0xff, sizeof(int32_t) * (size_t)n * W, m->stream));
   PHX_HIP(hipMemsetAsync(sl.vals, 0, sizeof(double) * (size_t)n * W, m->stream));
   PHX_HIP(hipMemsetAsync(sl.overflow, 0, sizeof(int), m->stream));
-  PHX_HIP(hipMalloc(&s->rhs, sizeof(double) * (size_t)n));
+  PHX_HIP(phx_malloc(&s->rhs, sizeof(double) * (size_t)n));
   PHX_HIP(hipMemsetAsync(s->rhs, 0, sizeof(double) * (size_t)n, m->stream));
   A.rhs = s->rhs; A.slots = sl;
   int32_t *l_cut = nullptr, *l_f3 = nullptr, *l_f4 = nullptr;
@@ -387,7 +387,7 @@ static int assemble_el_with_capacity(phx_mesh *m, const double *params, const do
   if (nbc > 0) k_el_bc_rows<<<dim3((unsigned)phx_div_up(nbc * D, 256)), block, 0, m->stream>>>(nbc, D, A, dbcv);
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(l_cut)); PHX_HIP(hipFree(l_f3)); PHX_HIP(hipFree(l_f4)); PHX_HIP(hipFree(bc));
+  PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_f3)); PHX_HIP(phx_free(l_f4)); PHX_HIP(phx_free(bc));
   const int rc = phx_finish_system(s, sl, (int32_t)nent);
   if (rc != PHX_OK) { phx_system_destroy(s); return rc; }
   *out = s;
@@ -414,7 +414,7 @@ extern "C" int phx_assemble_elasticity_if(phx_mesh *m, const double *params, con
   if (nbc > 0) {
     if (loc == PHX_DEVICE) dbcv = (int32_t *)bc_vertices;
     else {
-      PHX_HIP(hipMalloc(&dbcv, sizeof(int32_t) * (size_t)nbc));
+      PHX_HIP(phx_malloc(&dbcv, sizeof(int32_t) * (size_t)nbc));
       PHX_HIP(hipMemcpyAsync(dbcv, bc_vertices, sizeof(int32_t) * (size_t)nbc, hipMemcpyHostToDevice, m->stream));
     }
   }
@@ -423,9 +423,9 @@ extern "C" int phx_assemble_elasticity_if(phx_mesh *m, const double *params, con
   int rc = assemble_el_with_capacity(m, params, dphi, df, dud, dbcv, nbc, W, out);
   if (rc == PHX_ERR_CAPACITY && W < 1024) rc = assemble_el_with_capacity(m, params, dphi, df, dud, dbcv, nbc, 2 * W, out);
   if (rc == PHX_OK) rc = phx_end_timing(m, 2);
-  if (o1) (void)hipFree(o1);
-  if (o2) (void)hipFree(o2);
-  if (o3) (void)hipFree(o3);
-  if (dbcv && loc != PHX_DEVICE) (void)hipFree(dbcv);
+  if (o1) (void)phx_free(o1);
+  if (o2) (void)phx_free(o2);
+  if (o3) (void)phx_free(o3);
+  if (dbcv && loc != PHX_DEVICE) (void)phx_free(dbcv);
   return rc;
 }

@@ -98,8 +98,8 @@ static int upload_rule(phx_mesh *m, int d, int degree, DevRule *r, std::vector<v
   std::vector<double> lam, w;
   conical_rule(d, degree, lam, w);
   double *dl = nullptr, *dw = nullptr;
-  PHX_HIP(hipMalloc(&dl, sizeof(double) * lam.size()));
-  PHX_HIP(hipMalloc(&dw, sizeof(double) * w.size()));
+  PHX_HIP(phx_malloc(&dl, sizeof(double) * lam.size()));
+  PHX_HIP(phx_malloc(&dw, sizeof(double) * w.size()));
   PHX_HIP(hipMemcpyAsync(dl, lam.data(), sizeof(double) * lam.size(), hipMemcpyHostToDevice, m->stream));
   PHX_HIP(hipMemcpyAsync(dw, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
@@ -427,8 +427,8 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
   // facet rules carry D barycentric coordinates per point
   uint8_t *fu = nullptr, *fp = nullptr;
   int32_t *su = nullptr, *sp = nullptr;
-  PHX_HIP(hipMalloc(&fu, (size_t)nent)); PHX_HIP(hipMalloc(&fp, (size_t)nent));
-  PHX_HIP(hipMalloc(&su, sizeof(int32_t) * (size_t)nent)); PHX_HIP(hipMalloc(&sp, sizeof(int32_t) * (size_t)nent));
+  PHX_HIP(phx_malloc(&fu, (size_t)nent)); PHX_HIP(phx_malloc(&fp, (size_t)nent));
+  PHX_HIP(phx_malloc(&su, sizeof(int32_t) * (size_t)nent)); PHX_HIP(phx_malloc(&sp, sizeof(int32_t) * (size_t)nent));
   PHX_HIP(hipMemsetAsync(fu, 0, (size_t)nent, m->stream));
   PHX_HIP(hipMemsetAsync(fp, 0, (size_t)nent, m->stream));
   P.A.cells = m->cells; P.A.x = m->x; P.A.ctags = m->cell_tags; P.A.ftags = m->facet_tags;
@@ -443,22 +443,22 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
   PHX_CHECK(scan_flags(m, fp, sp, nent, &np));
   s->nu = nu; s->n = (int64_t)nu + np;
   PHX_REQUIRE(s->n > 0, PHX_ERR_VALUE, "no active DoF: no cell is tagged 1 or 2");
-  PHX_HIP(hipMalloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)nent));
-  PHX_HIP(hipMalloc(&s->dof_of_vertex_p, sizeof(int32_t) * (size_t)nent));
-  PHX_HIP(hipMalloc(&s->full_of_active, sizeof(int64_t) * (size_t)s->n));
+  PHX_HIP(phx_malloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)nent));
+  PHX_HIP(phx_malloc(&s->dof_of_vertex_p, sizeof(int32_t) * (size_t)nent));
+  PHX_HIP(phx_malloc(&s->full_of_active, sizeof(int64_t) * (size_t)s->n));
   k_finish_numbering<<<dim3((unsigned)phx_div_up(nent, 256)), block, 0, m->stream>>>(
       nent, fu, fp, su, sp, nu, s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active);
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(fu)); PHX_HIP(hipFree(fp)); PHX_HIP(hipFree(su)); PHX_HIP(hipFree(sp));
+  PHX_HIP(phx_free(fu)); PHX_HIP(phx_free(fp)); PHX_HIP(phx_free(su)); PHX_HIP(phx_free(sp));
   Slots sl;
   sl.W = W;
-  PHX_HIP(hipMalloc(&sl.cols, sizeof(int32_t) * (size_t)s->n * W));
-  PHX_HIP(hipMalloc(&sl.vals, sizeof(double) * (size_t)s->n * W));
-  PHX_HIP(hipMalloc(&sl.overflow, sizeof(int)));
+  PHX_HIP(phx_malloc(&sl.cols, sizeof(int32_t) * (size_t)s->n * W));
+  PHX_HIP(phx_malloc(&sl.vals, sizeof(double) * (size_t)s->n * W));
+  PHX_HIP(phx_malloc(&sl.overflow, sizeof(int)));
   PHX_HIP(hipMemsetAsync(sl.cols, 0xff, sizeof(int32_t) * (size_t)s->n * W, m->stream));
   PHX_HIP(hipMemsetAsync(sl.vals, 0, sizeof(double) * (size_t)s->n * W, m->stream));
   PHX_HIP(hipMemsetAsync(sl.overflow, 0, sizeof(int), m->stream));
-  PHX_HIP(hipMalloc(&s->rhs, sizeof(double) * (size_t)s->n));
+  PHX_HIP(phx_malloc(&s->rhs, sizeof(double) * (size_t)s->n));
   PHX_HIP(hipMemsetAsync(s->rhs, 0, sizeof(double) * (size_t)s->n, m->stream));
   P.A.du = s->dof_of_vertex_u; P.A.dp = s->dof_of_vertex_p; P.A.rhs = s->rhs; P.A.slots = sl;
   int32_t *l_om = nullptr, *l_cut = nullptr, *l_fac = nullptr;
@@ -489,8 +489,8 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
   }
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(l_om)); PHX_HIP(hipFree(l_cut)); PHX_HIP(hipFree(l_fac));
-  for (void *p : keep) PHX_HIP(hipFree(p));
+  PHX_HIP(phx_free(l_om)); PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_fac));
+  for (void *p : keep) PHX_HIP(phx_free(p));
   const int rc = phx_finish_system(s, sl, (int32_t)nent);
   if (rc != PHX_OK) { phx_system_destroy(s); return rc; }
   *out = s;
@@ -518,8 +518,8 @@ extern "C" int phx_assemble_poisson_wd_p2(phx_mesh *m, double pen_coef, double s
   int rc = assemble_p2_with_capacity(m, pen_coef, stab_coef, phi_degree, dphi, df, dud, W, out);
   if (rc == PHX_ERR_CAPACITY) rc = assemble_p2_with_capacity(m, pen_coef, stab_coef, phi_degree, dphi, df, dud, 2 * W, out);
   if (rc == PHX_OK) rc = phx_end_timing(m, 2);
-  if (o1) (void)hipFree(o1);
-  if (o2) (void)hipFree(o2);
-  if (o3) (void)hipFree(o3);
+  if (o1) (void)phx_free(o1);
+  if (o2) (void)phx_free(o2);
+  if (o3) (void)phx_free(o3);
   return rc;
 }

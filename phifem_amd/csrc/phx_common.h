@@ -13,6 +13,18 @@
 
 void phx_set_error(const char *fmt, ...);
 
+// Caching device allocator: assembly and solve allocate and release the same multi-GB transient
+// buffers on every pass; hipMalloc/hipFree of such blocks costs hundreds of milliseconds at
+// BASELINE scale (0.8 s per pass on the 1024x1024x128 slab).  Released blocks are kept per device and
+// handed back on an exact-size match; everything cached is returned to the driver when a real
+// allocation fails or the cache exceeds PHX_POOL_LIMIT_GB (default 96).
+hipError_t phx_pool_malloc(void **p, size_t bytes);
+hipError_t phx_pool_free(void *p);
+void phx_pool_trim(void);
+template <typename T>
+static inline hipError_t phx_malloc(T **p, size_t bytes) { return phx_pool_malloc((void **)p, bytes); }
+static inline hipError_t phx_free(void *p) { return phx_pool_free(p); }
+
 #define PHX_HIP(expr)                                                                       \
   do {                                                                                      \
     hipError_t e_ = (expr);                                                                 \

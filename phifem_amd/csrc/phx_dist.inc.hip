@@ -155,8 +155,8 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     H.peer[p] = peers[p];
     H.nsend[p] = counts[2 * p]; H.nrecv[p] = counts[2 * p + 1];
     H.send_idx[p] = idx[2 * p]; H.recv_idx[p] = idx[2 * p + 1];
-    PHX_HIP(hipMalloc(&H.sbuf[p], sizeof(double) * (size_t)(H.nsend[p] > 0 ? H.nsend[p] : 1)));
-    PHX_HIP(hipMalloc(&H.rbuf[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)));
+    PHX_HIP(phx_malloc(&H.sbuf[p], sizeof(double) * (size_t)(H.nsend[p] > 0 ? H.nsend[p] : 1)));
+    PHX_HIP(phx_malloc(&H.rbuf[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)));
   }
   const KrVecs V = kr_vecs(s);
   double *S = kr_scal(s);
@@ -210,7 +210,7 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
   };
   rc = body();
   (void)hipStreamSynchronize(st);
-  for (int p = 0; p < npeers; ++p) { (void)hipFree(H.sbuf[p]); (void)hipFree(H.rbuf[p]); }
+  for (int p = 0; p < npeers; ++p) { (void)phx_free(H.sbuf[p]); (void)phx_free(H.rbuf[p]); }
   return rc;
 }
 
@@ -227,11 +227,11 @@ extern "C" int phx_halo_selftest(phx_system *s, phx_comm *c, int npeers, const i
     H.peer[p] = peers[p];
     H.nsend[p] = counts[2 * p]; H.nrecv[p] = counts[2 * p + 1];
     H.send_idx[p] = idx[2 * p]; H.recv_idx[p] = idx[2 * p + 1];
-    PHX_HIP(hipMalloc(&H.sbuf[p], sizeof(double) * (size_t)(H.nsend[p] > 0 ? H.nsend[p] : 1)));
-    PHX_HIP(hipMalloc(&H.rbuf[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)));
+    PHX_HIP(phx_malloc(&H.sbuf[p], sizeof(double) * (size_t)(H.nsend[p] > 0 ? H.nsend[p] : 1)));
+    PHX_HIP(phx_malloc(&H.rbuf[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)));
   }
   const int rc = halo_exchange(s, c, H, vec);
   (void)hipStreamSynchronize(s->mesh->stream);
-  for (int p = 0; p < npeers; ++p) { (void)hipFree(H.sbuf[p]); (void)hipFree(H.rbuf[p]); }
+  for (int p = 0; p < npeers; ++p) { (void)phx_free(H.sbuf[p]); (void)phx_free(H.rbuf[p]); }
   return rc;
 }

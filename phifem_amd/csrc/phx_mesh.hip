@@ -20,6 +20,79 @@ void phx_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
+#include <map>
+#include <mutex>
+#include <unordered_map>
+namespace {
+struct Pool {
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, void *> free_blocks;   // (device, bytes) -> ptr
+  std::unordered_map<void *, std::pair<int, size_t>> live;      // ptr -> (device, bytes)
+  size_t cached = 0;
+};
+Pool &pool() { static Pool p; return p; }
+size_t pool_limit() {
+  static size_t lim = [] {
+    const char *e = getenv("PHX_POOL_LIMIT_GB");
+    return (size_t)((e ? atof(e) : 96.0) * (double)(1ull << 30));
+  }();
+  return lim;
+}
+void trim_locked(Pool &P) {
+  for (auto &kv : P.free_blocks) (void)hipFree(kv.second);
+  P.free_blocks.clear();
+  P.cached = 0;
+}
+}  // namespace
+
+hipError_t phx_pool_malloc(void **p, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  Pool &P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  auto it = P.free_blocks.find({dev, bytes});
+  if (it != P.free_blocks.end()) {
+    *p = it->second;
+    P.free_blocks.erase(it);
+    P.cached -= bytes;
+    P.live[*p] = {dev, bytes};
+    return hipSuccess;
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {  // give the cache back and retry once
+    (void)hipGetLastError();
+    trim_locked(P);
+    e = hipMalloc(p, bytes);
+  }
+  if (e == hipSuccess) P.live[*p] = {dev, bytes};
+  return e;
+}
+
+hipError_t phx_pool_free(void *p) {
+  if (!p) return hipSuccess;
+  Pool &P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  auto it = P.live.find(p);
+  if (it == P.live.end()) return hipFree(p);  // not ours (allocated before the pool existed)
+  const auto key = it->second;
+  P.live.erase(it);
+  if (key.second < (1u << 20) || P.cached + key.second > pool_limit()) return hipFree(p);
+  // hipFree would have synchronised the device; a cached block may be handed to another stream
+  (void)hipDeviceSynchronize();
+  P.free_blocks.insert({key, p});
+  P.cached += key.second;
+  return hipSuccess;
+}
+
+void phx_pool_trim(void) {
+  Pool &P = pool();
+  std::lock_guard<std::mutex> lk(P.mu);
+  trim_locked(P);
+}
+
+extern "C" int phx_pool_release(void) { phx_pool_trim(); return PHX_OK; }
+
 extern "C" int phx_version(void) { return 1; }
 extern "C" const char *phx_last_error(void) { return g_err; }
 extern "C" int phx_device_count(int *n) {
@@ -245,8 +318,8 @@ static int mesh_init_device(phx_mesh *m, int device) {
 }
 
 int phx_mesh_alloc_common(phx_mesh *m) {
-  PHX_HIP(hipMalloc(&m->cell_tags, (size_t)m->nc));
-  PHX_HIP(hipMalloc(&m->facet_tags, (size_t)m->nf));
+  PHX_HIP(phx_malloc(&m->cell_tags, (size_t)m->nc));
+  PHX_HIP(phx_malloc(&m->facet_tags, (size_t)m->nf));
   PHX_HIP(hipMemsetAsync(m->cell_tags, 0, (size_t)m->nc, m->stream));
   PHX_HIP(hipMemsetAsync(m->facet_tags, 0, (size_t)m->nf, m->stream));
   return PHX_OK;
@@ -275,30 +348,30 @@ __global__ void k_bfacet_pairs(int64_t nbf, const int32_t *__restrict__ bf,
 static int build_boundary_list(phx_mesh *m) {
   int32_t *sel = nullptr;
   int64_t *dcount = nullptr;
-  PHX_HIP(hipMalloc(&sel, sizeof(int32_t) * (size_t)m->nf));
-  PHX_HIP(hipMalloc(&dcount, sizeof(int64_t)));
+  PHX_HIP(phx_malloc(&sel, sizeof(int32_t) * (size_t)m->nf));
+  PHX_HIP(phx_malloc(&dcount, sizeof(int64_t)));
   hipcub::CountingInputIterator<int32_t> it(0);
   IsBoundary pred{m->f2c};
   size_t tmp_bytes = 0;
   PHX_HIP(hipcub::DeviceSelect::If(nullptr, tmp_bytes, it, sel, dcount, (int)m->nf, pred, m->stream));
   void *tmp = nullptr;
-  PHX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  PHX_HIP(phx_malloc(&tmp, tmp_bytes ? tmp_bytes : 16));
   PHX_HIP(hipcub::DeviceSelect::If(tmp, tmp_bytes, it, sel, dcount, (int)m->nf, pred, m->stream));
   int64_t nbf = 0;
   PHX_HIP(hipMemcpyAsync(&nbf, dcount, sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
   m->nbf = nbf;
-  PHX_HIP(hipMalloc(&m->bfacets, sizeof(int32_t) * 2 * (size_t)(nbf > 0 ? nbf : 1)));
+  PHX_HIP(phx_malloc(&m->bfacets, sizeof(int32_t) * 2 * (size_t)(nbf > 0 ? nbf : 1)));
   if (nbf > 0)
     k_bfacet_pairs<<<dim3((unsigned)phx_div_up(nbf, 256)), dim3(256), 0, m->stream>>>(
         nbf, sel, m->f2c, m->c2f, m->ci.nfpc, m->bfacets);
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(tmp));
-  PHX_HIP(hipMalloc(&m->bfacet_ids, sizeof(int32_t) * (size_t)(nbf > 0 ? nbf : 1)));
+  PHX_HIP(phx_free(tmp));
+  PHX_HIP(phx_malloc(&m->bfacet_ids, sizeof(int32_t) * (size_t)(nbf > 0 ? nbf : 1)));
   if (nbf > 0)
     PHX_HIP(hipMemcpy(m->bfacet_ids, sel, sizeof(int32_t) * (size_t)nbf, hipMemcpyDeviceToDevice));
-  PHX_HIP(hipFree(sel));
-  PHX_HIP(hipFree(dcount));
+  PHX_HIP(phx_free(sel));
+  PHX_HIP(phx_free(dcount));
   return PHX_OK;
 }
 
@@ -316,10 +389,10 @@ extern "C" int phx_mesh_create(int gdim, int cell_type, int64_t nv, const double
   if (rc != PHX_OK) { delete m; return rc; }
   m->gdim = gdim; m->cell_type = cell_type; m->ci = ci;
   m->nv = nv; m->nc = nc; m->nf = nf;
-  PHX_HIP(hipMalloc(&m->x, sizeof(double) * (size_t)nv * gdim));
-  PHX_HIP(hipMalloc(&m->cells, sizeof(int32_t) * (size_t)nc * ci.nvpc));
-  PHX_HIP(hipMalloc(&m->c2f, sizeof(int32_t) * (size_t)nc * ci.nfpc));
-  PHX_HIP(hipMalloc(&m->f2c, sizeof(int32_t) * (size_t)nf * 2));
+  PHX_HIP(phx_malloc(&m->x, sizeof(double) * (size_t)nv * gdim));
+  PHX_HIP(phx_malloc(&m->cells, sizeof(int32_t) * (size_t)nc * ci.nvpc));
+  PHX_HIP(phx_malloc(&m->c2f, sizeof(int32_t) * (size_t)nc * ci.nfpc));
+  PHX_HIP(phx_malloc(&m->f2c, sizeof(int32_t) * (size_t)nf * 2));
   PHX_HIP(hipMemcpy(m->x, coords, sizeof(double) * (size_t)nv * gdim, hipMemcpyHostToDevice));
   PHX_HIP(hipMemcpy(m->cells, cells, sizeof(int32_t) * (size_t)nc * ci.nvpc, hipMemcpyHostToDevice));
   PHX_HIP(hipMemcpy(m->c2f, c2f.data(), sizeof(int32_t) * (size_t)nc * ci.nfpc, hipMemcpyHostToDevice));
@@ -515,10 +588,10 @@ extern "C" int phx_mesh_create_box(int gdim, const double *lo, const double *hi,
   m->box_plane = gdim == 3 ? (b.n[0] + 1) * (b.n[1] + 1) : (b.n[0] + 1);
   m->box_nlast = b.n[gdim - 1];
   for (int a = 0; a < 3; ++a) m->box_n[a] = a < gdim ? b.n[a] : 1;
-  PHX_HIP(hipMalloc(&m->x, sizeof(double) * (size_t)nv * gdim));
-  PHX_HIP(hipMalloc(&m->cells, sizeof(int32_t) * (size_t)nc * (gdim + 1)));
-  PHX_HIP(hipMalloc(&m->c2f, sizeof(int32_t) * (size_t)nc * (gdim + 1)));
-  PHX_HIP(hipMalloc(&m->f2c, sizeof(int32_t) * (size_t)nf * 2));
+  PHX_HIP(phx_malloc(&m->x, sizeof(double) * (size_t)nv * gdim));
+  PHX_HIP(phx_malloc(&m->cells, sizeof(int32_t) * (size_t)nc * (gdim + 1)));
+  PHX_HIP(phx_malloc(&m->c2f, sizeof(int32_t) * (size_t)nc * (gdim + 1)));
+  PHX_HIP(phx_malloc(&m->f2c, sizeof(int32_t) * (size_t)nf * 2));
   const int T = 256;
   k_box_coords<<<dim3((unsigned)phx_div_up(nv, T)), dim3(T), 0, m->stream>>>(b, nv, m->x);
   k_box_cells<<<dim3((unsigned)phx_div_up(nc, T)), dim3(T), 0, m->stream>>>(b, nc, m->cells, m->c2f);
@@ -556,7 +629,7 @@ __global__ void k_mark_exempt(int64_t nbf, const int32_t *__restrict__ bfacets,
 extern "C" int phx_mesh_set_slab_faces(phx_mesh *m, int lower_is_cut, int upper_is_cut) {
   PHX_HIP(hipSetDevice(m->device));
   PHX_REQUIRE(m->is_box, PHX_ERR_VALUE, "slab faces exist on device-generated boxes only");
-  if (!m->facet_exempt) PHX_HIP(hipMalloc(&m->facet_exempt, (size_t)m->nf));
+  if (!m->facet_exempt) PHX_HIP(phx_malloc(&m->facet_exempt, (size_t)m->nf));
   PHX_HIP(hipMemsetAsync(m->facet_exempt, 0, (size_t)m->nf, m->stream));
   if ((lower_is_cut || upper_is_cut) && m->nbf > 0)
     k_mark_exempt<<<dim3((unsigned)phx_div_up(m->nbf, 256)), dim3(256), 0, m->stream>>>(
@@ -647,7 +720,7 @@ int phx_mesh_build_edges(phx_mesh *m) {
     for (int cls = 0; cls < 7; ++cls) E.base[cls + 1] = E.base[cls] + E.ext[cls][0] * E.ext[cls][1] * E.ext[cls][2];
     m->ne = E.base[7];
     PHX_REQUIRE(m->ne < INT32_MAX, PHX_ERR_VALUE, "too many edges for 32-bit local ids");
-    PHX_HIP(hipMalloc(&m->c2e, sizeof(int32_t) * (size_t)m->nc * 6));
+    PHX_HIP(phx_malloc(&m->c2e, sizeof(int32_t) * (size_t)m->nc * 6));
     k_box_c2e<<<grid, block, 0, m->stream>>>(E, m->nc, m->c2e);
   } else {
     // unstructured tetrahedra: number the edges by the rank of their sorted vertex pair (host)
@@ -671,10 +744,10 @@ int phx_mesh_build_edges(phx_mesh *m) {
       c2e[recs[i].slot] = (int32_t)ne;
     }
     m->ne = recs.empty() ? 0 : ne + 1;
-    PHX_HIP(hipMalloc(&m->c2e, sizeof(int32_t) * c2e.size()));
+    PHX_HIP(phx_malloc(&m->c2e, sizeof(int32_t) * c2e.size()));
     PHX_HIP(hipMemcpy(m->c2e, c2e.data(), sizeof(int32_t) * c2e.size(), hipMemcpyHostToDevice));
   }
-  PHX_HIP(hipMalloc(&m->edges, sizeof(int32_t) * 2 * (size_t)m->ne));
+  PHX_HIP(phx_malloc(&m->edges, sizeof(int32_t) * 2 * (size_t)m->ne));
   k_edge_vertices<<<grid, block, 0, m->stream>>>(m->nc, m->ci.nvpc, m->cell_type == PHX_TETRAHEDRON ? 6 : 3,
                                                  m->cell_type == PHX_TETRAHEDRON ? 1 : 0, m->cells,
                                                  m->c2e, m->edges);
@@ -697,7 +770,7 @@ extern "C" int phx_mesh_destroy(phx_mesh *m) {
   void *ptrs[] = {m->x, m->cells, m->c2f, m->f2c, m->bfacets, m->bfacet_ids, m->cell_tags,
                   m->facet_tags, m->ent_buf[0], m->ent_buf[1], m->facet_exempt, m->v2c_ptr, m->v2c_idx,
                   m->edges, m->c2e_is_alias ? nullptr : (void *)m->c2e};
-  for (void *p : ptrs) (void)hipFree(p);
+  for (void *p : ptrs) (void)phx_free(p);
   free(m->c_map_h); free(m->v_map_h);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
@@ -775,12 +848,12 @@ extern "C" int phx_mesh_get_array(phx_mesh *m, int which, void *out, int loc) {
       const int64_t n = fac ? m->nf : m->nc;
       int32_t *dst = (int32_t *)out;
       int32_t *tmp = nullptr;
-      if (loc != PHX_DEVICE) { PHX_HIP(hipMalloc(&tmp, sizeof(int32_t) * (size_t)n)); dst = tmp; }
+      if (loc != PHX_DEVICE) { PHX_HIP(phx_malloc(&tmp, sizeof(int32_t) * (size_t)n)); dst = tmp; }
       k_widen_tags<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, m->stream>>>(
           n, fac ? m->facet_tags : m->cell_tags, dst);
       if (tmp) PHX_HIP(hipMemcpyAsync(out, tmp, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, m->stream));
       PHX_HIP(hipStreamSynchronize(m->stream));  // the caller may read `out` from another stream
-      if (tmp) PHX_HIP(hipFree(tmp));
+      if (tmp) PHX_HIP(phx_free(tmp));
       return PHX_OK;
     }
     default:

@@ -120,20 +120,20 @@ int phx_system_build_sell(phx_system *s) {
   PHX_REQUIRE(n / g_sell_window < (1 << 21), PHX_ERR_VALUE, "system too large for the SELL sort key");
   uint32_t *keys = nullptr, *keys2 = nullptr;
   int32_t *rows = nullptr;
-  PHX_HIP(hipMalloc(&keys, sizeof(uint32_t) * (size_t)n));
-  PHX_HIP(hipMalloc(&keys2, sizeof(uint32_t) * (size_t)n));
-  PHX_HIP(hipMalloc(&rows, sizeof(int32_t) * (size_t)n));
-  PHX_HIP(hipMalloc(&s->perm, sizeof(int32_t) * (size_t)n));
-  PHX_HIP(hipMalloc(&s->iperm, sizeof(int32_t) * (size_t)n));
+  PHX_HIP(phx_malloc(&keys, sizeof(uint32_t) * (size_t)n));
+  PHX_HIP(phx_malloc(&keys2, sizeof(uint32_t) * (size_t)n));
+  PHX_HIP(phx_malloc(&rows, sizeof(int32_t) * (size_t)n));
+  PHX_HIP(phx_malloc(&s->perm, sizeof(int32_t) * (size_t)n));
+  PHX_HIP(phx_malloc(&s->iperm, sizeof(int32_t) * (size_t)n));
   const dim3 block(256), grid((unsigned)phx_div_up(n, 256));
   unsigned long long *dtotal = nullptr;
-  PHX_HIP(hipMalloc(&dtotal, sizeof(unsigned long long)));
+  PHX_HIP(phx_malloc(&dtotal, sizeof(unsigned long long)));
   PHX_HIP(hipMemsetAsync(dtotal, 0, sizeof(unsigned long long), m->stream));
   k_row_lengths<<<grid, block, 0, m->stream>>>(n, s->rowptr, s->col, s->val, keys, rows, dtotal, g_sell_window);
   unsigned long long htotal = 0;
   PHX_HIP(hipMemcpyAsync(&htotal, dtotal, sizeof(htotal), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(dtotal));
+  PHX_HIP(phx_free(dtotal));
   s->sell_true_nnz = (int64_t)htotal;
   // only the bits that can differ are sorted: 10 length bits (+ the window index if windowed)
   int end_bit = 10;
@@ -141,38 +141,38 @@ int phx_system_build_sell(phx_system *s) {
   size_t bytes = 0;
   PHX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys2, rows, s->perm, (int)n, 0, end_bit, m->stream));
   void *tmp = nullptr;
-  PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
   PHX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys, keys2, rows, s->perm, (int)n, 0, end_bit, m->stream));
   k_invert_perm<<<grid, block, 0, m->stream>>>(n, s->perm, s->iperm);
   s->nslices = phx_div_up(n, SELL_C);
   int64_t *widths = nullptr;
-  PHX_HIP(hipMalloc(&widths, sizeof(int64_t) * (size_t)(s->nslices + 1)));
-  PHX_HIP(hipMalloc(&s->slice_ptr, sizeof(int64_t) * (size_t)(s->nslices + 1)));
+  PHX_HIP(phx_malloc(&widths, sizeof(int64_t) * (size_t)(s->nslices + 1)));
+  PHX_HIP(phx_malloc(&s->slice_ptr, sizeof(int64_t) * (size_t)(s->nslices + 1)));
   k_slice_widths<<<dim3((unsigned)phx_div_up(s->nslices + 1, 256)), block, 0, m->stream>>>(
       s->nslices, n, keys2, widths);
   {
     size_t b2 = 0;
     PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, widths, s->slice_ptr, (int)(s->nslices + 1), m->stream));
     void *t2 = nullptr;
-    PHX_HIP(hipMalloc(&t2, b2 ? b2 : 16));
+    PHX_HIP(phx_malloc(&t2, b2 ? b2 : 16));
     PHX_HIP(hipcub::DeviceScan::ExclusiveSum(t2, b2, widths, s->slice_ptr, (int)(s->nslices + 1), m->stream));
     PHX_HIP(hipStreamSynchronize(m->stream));
-    PHX_HIP(hipFree(t2));
+    PHX_HIP(phx_free(t2));
   }
   PHX_HIP(hipMemcpy(&s->sell_nnz, s->slice_ptr + s->nslices, sizeof(int64_t), hipMemcpyDeviceToHost));
-  PHX_HIP(hipMalloc(&s->sell_col, sizeof(int32_t) * (size_t)s->sell_nnz));
-  PHX_HIP(hipMalloc(&s->sell_val, sizeof(double) * (size_t)s->sell_nnz));
-  PHX_HIP(hipMalloc(&s->sell_val_raw, sizeof(double) * (size_t)s->sell_nnz));
+  PHX_HIP(phx_malloc(&s->sell_col, sizeof(int32_t) * (size_t)s->sell_nnz));
+  PHX_HIP(phx_malloc(&s->sell_val, sizeof(double) * (size_t)s->sell_nnz));
+  PHX_HIP(phx_malloc(&s->sell_val_raw, sizeof(double) * (size_t)s->sell_nnz));
   k_sell_fill<<<dim3((unsigned)phx_div_up(s->nslices * SELL_C, 256)), block, 0, m->stream>>>(
       n, s->rowptr, s->col, s->val, s->diag, s->perm, s->iperm, s->slice_ptr, s->sell_col,
       s->sell_val, s->sell_val_raw);
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(tmp)); PHX_HIP(hipFree(keys)); PHX_HIP(hipFree(keys2)); PHX_HIP(hipFree(rows));
-  PHX_HIP(hipFree(widths));
+  PHX_HIP(phx_free(tmp)); PHX_HIP(phx_free(keys)); PHX_HIP(phx_free(keys2)); PHX_HIP(phx_free(rows));
+  PHX_HIP(phx_free(widths));
   // solver workspace: 9 vectors + scalars
-  PHX_HIP(hipMalloc(&s->work, sizeof(double) * (size_t)n * 9));
-  PHX_HIP(hipMalloc(&s->scal, sizeof(double) * PHX_SCAL_DOUBLES));
+  PHX_HIP(phx_malloc(&s->work, sizeof(double) * (size_t)n * 9));
+  PHX_HIP(phx_malloc(&s->scal, sizeof(double) * PHX_SCAL_DOUBLES));
   PHX_HIP(hipHostMalloc(&s->scal_h, sizeof(double) * 16));
   return PHX_OK;
 }
@@ -557,7 +557,7 @@ extern "C" int phx_krylov_finish(phx_system *s, double *x_out, int loc) {
   const KrVecs V = kr_vecs(s);
   double *xfull = x_out;
   double *owned = nullptr;
-  if (loc != PHX_DEVICE) { PHX_HIP(hipMalloc(&owned, sizeof(double) * (size_t)s->nfull)); xfull = owned; }
+  if (loc != PHX_DEVICE) { PHX_HIP(phx_malloc(&owned, sizeof(double) * (size_t)s->nfull)); xfull = owned; }
   PHX_HIP(hipMemsetAsync(xfull, 0, sizeof(double) * (size_t)s->nfull, st));
   k_scatter_solution<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, st>>>(
       n, s->perm, s->full_of_active, s->diag, V.y, xfull);
@@ -565,7 +565,7 @@ extern "C" int phx_krylov_finish(phx_system *s, double *x_out, int loc) {
   PHX_HIP(hipStreamSynchronize(st));
   if (owned) {
     PHX_HIP(hipMemcpy(x_out, owned, sizeof(double) * (size_t)s->nfull, hipMemcpyDeviceToHost));
-    PHX_HIP(hipFree(owned));
+    PHX_HIP(phx_free(owned));
   }
   return PHX_OK;
 }

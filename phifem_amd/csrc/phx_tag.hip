@@ -300,7 +300,7 @@ static int stage_phi(phx_mesh *m, int phi_kind, const double *phi, int loc, int6
     return PHX_OK;
   }
   if (loc == PHX_DEVICE) { *dev = phi; return PHX_OK; }
-  PHX_HIP(hipMalloc(owned, sizeof(double) * (size_t)(count > 0 ? count : 1)));
+  PHX_HIP(phx_malloc(owned, sizeof(double) * (size_t)(count > 0 ? count : 1)));
   PHX_HIP(hipMemcpyAsync(*owned, phi, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, m->stream));
   *dev = *owned;
   return PHX_OK;
@@ -314,14 +314,14 @@ static int64_t cell_points_count(const phx_mesh *m, int degree) {
 
 static int read_hist(phx_mesh *m, const int8_t *tags, int64_t n, int nbins, int64_t *out) {
   unsigned long long *d = nullptr;
-  PHX_HIP(hipMalloc(&d, sizeof(unsigned long long) * 8));
+  PHX_HIP(phx_malloc(&d, sizeof(unsigned long long) * 8));
   PHX_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long) * 8, m->stream));
   const int blocks = (int)std::min<int64_t>(phx_div_up(n, 256), 2048);
   k_tag_hist<<<dim3(blocks), dim3(256), 0, m->stream>>>(n, tags, nbins, d);
   unsigned long long h[8];
   PHX_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(d));
+  PHX_HIP(phx_free(d));
   for (int i = 0; i < nbins; ++i) out[i] = (int64_t)h[i];
   return PHX_OK;
 }
@@ -353,7 +353,7 @@ extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int l
   const int64_t count = phi_kind == PHX_PHI_NODAL_P1 ? m->nv : m->nc * (int64_t)tab.npts;
   PHX_CHECK(stage_phi(m, phi_kind, phi, loc, count, &dphi, &owned, &quad));
   int *dwarn = nullptr;
-  PHX_HIP(hipMalloc(&dwarn, sizeof(int)));
+  PHX_HIP(phx_malloc(&dwarn, sizeof(int)));
   PHX_HIP(hipMemsetAsync(dwarn, 0, sizeof(int), m->stream));
   PHX_CHECK(phx_begin_timing(m));
   if (phi_kind == PHX_PHI_NODAL_P1) PHX_CHECK(launch_tag_cells<PHX_PHI_NODAL_P1>(m, tab, dphi, quad, dwarn));
@@ -361,7 +361,7 @@ extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int l
   else PHX_CHECK(launch_tag_cells<PHX_PHI_QUADRIC>(m, tab, dphi, quad, dwarn));
   if (single_layer_cut) {
     uint8_t *touched = nullptr;
-    PHX_HIP(hipMalloc(&touched, (size_t)m->nv));
+    PHX_HIP(phx_malloc(&touched, (size_t)m->nv));
     PHX_HIP(hipMemsetAsync(touched, 0, (size_t)m->nv, m->stream));
     const dim3 grid((unsigned)phx_div_up(m->nc, 256)), block(256);
     if (m->ci.nvpc == 3) {
@@ -373,14 +373,14 @@ extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int l
     }
     PHX_HIP(hipGetLastError());
     PHX_CHECK(phx_end_timing(m, 0));
-    PHX_HIP(hipFree(touched));
+    PHX_HIP(phx_free(touched));
   } else {
     PHX_CHECK(phx_end_timing(m, 0));
   }
   int hwarn = 0;
   PHX_HIP(hipMemcpy(&hwarn, dwarn, sizeof(int), hipMemcpyDeviceToHost));
-  PHX_HIP(hipFree(dwarn));
-  if (owned) PHX_HIP(hipFree(owned));
+  PHX_HIP(phx_free(dwarn));
+  if (owned) PHX_HIP(phx_free(owned));
   if (warn_zero_denominator) *warn_zero_denominator = hwarn;
   PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist));
   m->have_cell_tags = true;
@@ -409,7 +409,7 @@ __global__ void k_clear_bcut(int64_t n, int8_t *tags) {
 
 static int run_facet_rule(phx_mesh *m) {
   unsigned long long *dbad = nullptr;
-  PHX_HIP(hipMalloc(&dbad, sizeof(unsigned long long)));
+  PHX_HIP(phx_malloc(&dbad, sizeof(unsigned long long)));
   PHX_HIP(hipMemsetAsync(dbad, 0, sizeof(unsigned long long), m->stream));
   k_tag_facets<<<dim3((unsigned)phx_div_up(m->nf, 256)), dim3(256), 0, m->stream>>>(
       m->nf, m->f2c, m->cell_tags,
@@ -419,7 +419,7 @@ static int run_facet_rule(phx_mesh *m) {
   PHX_CHECK(phx_end_timing(m, 1));
   unsigned long long bad = 0;
   PHX_HIP(hipMemcpy(&bad, dbad, sizeof(bad), hipMemcpyDeviceToHost));
-  PHX_HIP(hipFree(dbad));
+  PHX_HIP(phx_free(dbad));
   PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist));
   m->have_facet_tags = true;
   m->have_entities = false;
@@ -458,7 +458,7 @@ extern "C" int phx_tag_facets(phx_mesh *m, int phi_kind, const double *phi, int 
   else if (phi_kind == PHX_PHI_POINTS) PHX_CHECK(launch_bcut<PHX_PHI_POINTS>(m, tab, fvs, dphi, quad));
   else PHX_CHECK(launch_bcut<PHX_PHI_QUADRIC>(m, tab, fvs, dphi, quad));
   const int rc = run_facet_rule(m);
-  if (owned) PHX_HIP(hipFree(owned));
+  if (owned) PHX_HIP(phx_free(owned));
   return rc;
 }
 
@@ -492,15 +492,15 @@ extern "C" int phx_overwrite_tags(phx_mesh *m, int entity_is_facet, int64_t n,
   }
   if (n == 0) return PHX_OK;
   int32_t *di = nullptr, *dv = nullptr;
-  PHX_HIP(hipMalloc(&di, sizeof(int32_t) * (size_t)n));
-  PHX_HIP(hipMalloc(&dv, sizeof(int32_t) * (size_t)n));
+  PHX_HIP(phx_malloc(&di, sizeof(int32_t) * (size_t)n));
+  PHX_HIP(phx_malloc(&dv, sizeof(int32_t) * (size_t)n));
   PHX_HIP(hipMemcpyAsync(di, indices, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, m->stream));
   PHX_HIP(hipMemcpyAsync(dv, values, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, m->stream));
   k_scatter_tags<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, m->stream>>>(
       n, di, dv, entity_is_facet ? m->facet_tags : m->cell_tags, entity_is_facet ? 0 : PHX_BCUT_BIT);
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(hipFree(di));
-  PHX_HIP(hipFree(dv));
+  PHX_HIP(phx_free(di));
+  PHX_HIP(phx_free(dv));
   if (entity_is_facet) PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist));
   else PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist));
   m->have_entities = false;
@@ -518,14 +518,14 @@ extern "C" int phx_set_tags(phx_mesh *m, int entity_is_facet, const int32_t *val
   const int32_t *src = values;
   int32_t *tmp = nullptr;
   if (loc != PHX_DEVICE) {
-    PHX_HIP(hipMalloc(&tmp, sizeof(int32_t) * (size_t)n));
+    PHX_HIP(phx_malloc(&tmp, sizeof(int32_t) * (size_t)n));
     PHX_HIP(hipMemcpyAsync(tmp, values, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, m->stream));
     src = tmp;
   }
   k_narrow_tags<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, m->stream>>>(
       n, src, entity_is_facet ? m->facet_tags : m->cell_tags);
   PHX_HIP(hipStreamSynchronize(m->stream));
-  if (tmp) PHX_HIP(hipFree(tmp));
+  if (tmp) PHX_HIP(phx_free(tmp));
   if (entity_is_facet) {
     PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist));
     m->have_facet_tags = true;
@@ -546,20 +546,20 @@ int phx_collect_entities(phx_mesh *m) {
   hipStream_t st = m->stream;
   const int64_t nmax = m->ftag_hist[3] + m->ftag_hist[4];
   for (int w = 0; w < 2; ++w) {
-    if (m->ent_buf[w]) { PHX_HIP(hipFree(m->ent_buf[w])); m->ent_buf[w] = nullptr; }
+    if (m->ent_buf[w]) { PHX_HIP(phx_free(m->ent_buf[w])); m->ent_buf[w] = nullptr; }
     m->ent_count[w] = 0;
   }
   if (nmax == 0) {
-    for (int w = 0; w < 2; ++w) PHX_HIP(hipMalloc(&m->ent_buf[w], 16));
+    for (int w = 0; w < 2; ++w) PHX_HIP(phx_malloc(&m->ent_buf[w], 16));
     m->have_entities = true;
     return PHX_OK;
   }
   int32_t *list = nullptr, *cnt = nullptr, *off = nullptr;
   int64_t *dn = nullptr;
-  PHX_HIP(hipMalloc(&list, sizeof(int32_t) * (size_t)nmax));
-  PHX_HIP(hipMalloc(&cnt, sizeof(int32_t) * 2 * (size_t)(nmax + 1)));
-  PHX_HIP(hipMalloc(&off, sizeof(int32_t) * 2 * (size_t)(nmax + 1)));
-  PHX_HIP(hipMalloc(&dn, sizeof(int64_t)));
+  PHX_HIP(phx_malloc(&list, sizeof(int32_t) * (size_t)nmax));
+  PHX_HIP(phx_malloc(&cnt, sizeof(int32_t) * 2 * (size_t)(nmax + 1)));
+  PHX_HIP(phx_malloc(&off, sizeof(int32_t) * 2 * (size_t)(nmax + 1)));
+  PHX_HIP(phx_malloc(&dn, sizeof(int64_t)));
   PHX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * 2 * (size_t)(nmax + 1), st));
   {
     hipcub::CountingInputIterator<int32_t> it(0);
@@ -567,10 +567,10 @@ int phx_collect_entities(phx_mesh *m) {
     size_t bytes = 0;
     PHX_HIP(hipcub::DeviceSelect::If(nullptr, bytes, it, list, dn, (int)m->nf, pred, st));
     void *tmp = nullptr;
-    PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+    PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
     PHX_HIP(hipcub::DeviceSelect::If(tmp, bytes, it, list, dn, (int)m->nf, pred, st));
     PHX_HIP(hipStreamSynchronize(st));
-    PHX_HIP(hipFree(tmp));
+    PHX_HIP(phx_free(tmp));
   }
   int32_t *cnt0 = cnt, *cnt1 = cnt + (nmax + 1), *off0 = off, *off1 = off + (nmax + 1);
   const dim3 grid((unsigned)phx_div_up(nmax, 256)), block(256);
@@ -581,21 +581,21 @@ int phx_collect_entities(phx_mesh *m) {
     int32_t *ci = w == 0 ? cnt0 : cnt1, *oi = w == 0 ? off0 : off1;
     PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, ci, oi, (int)(nmax + 1), st));
     void *tmp = nullptr;
-    PHX_HIP(hipMalloc(&tmp, bytes ? bytes : 16));
+    PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
     PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, ci, oi, (int)(nmax + 1), st));
     int32_t tot = 0;
     PHX_HIP(hipMemcpyAsync(&tot, oi + nmax, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     PHX_HIP(hipStreamSynchronize(st));
-    PHX_HIP(hipFree(tmp));
+    PHX_HIP(phx_free(tmp));
     m->ent_count[w] = tot;
-    PHX_HIP(hipMalloc(&m->ent_buf[w], sizeof(int64_t) * 2 * (size_t)(tot > 0 ? tot : 1)));
+    PHX_HIP(phx_malloc(&m->ent_buf[w], sizeof(int64_t) * 2 * (size_t)(tot > 0 ? tot : 1)));
   }
   k_entities<true><<<grid, block, 0, st>>>(nmax, list, m->f2c, m->c2f, m->ci.nfpc, m->cell_tags,
                                            m->facet_tags, nullptr, nullptr, off0, off1,
                                            m->ent_buf[0], m->ent_buf[1]);
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(st));
-  PHX_HIP(hipFree(list)); PHX_HIP(hipFree(cnt)); PHX_HIP(hipFree(off)); PHX_HIP(hipFree(dn));
+  PHX_HIP(phx_free(list)); PHX_HIP(phx_free(cnt)); PHX_HIP(phx_free(off)); PHX_HIP(phx_free(dn));
   m->have_entities = true;
   return PHX_OK;
 }
