@@ -35,6 +35,10 @@ def parse():
                     help="box size of the CPU-baseline sample (0: the full 256^3 workload when the host "
                          "grants >= 12 cores, else 160^3; ~10-30 s of CPU work either way)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE configs[3]: 3-D interface elasticity (5-field mixed, 27 components per "
+                         "vertex) on a --cubes^3 box (256 in the config) split into z-slabs over the GPUs "
+                         "(strong scaling); not the default workload")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE configs[4]: 1024 x 1024 x 128 cubes per GPU (805 306 368 tets), unit "
                          "sphere, 1024^3 box at 8 GPUs; not the default workload")
@@ -120,8 +124,14 @@ def main():
     from phifem_amd import distributed as D
 
     n = 128 if args.config5 else args.cubes
-    prob = D.SlabProblem(n_per_rank=n, rank=rank, world=world, device=local_rank, rtol=args.rtol,
-                         nxy=1024 if args.config5 else None)
+    if args.config4:
+        if n % world:
+            raise SystemExit("--config4 needs --cubes divisible by the number of GPUs")
+        prob = D.ElasticitySlabProblem(n, n // world, rank=rank, world=world, device=local_rank,
+                                       rtol=args.rtol)
+    else:
+        prob = D.SlabProblem(n_per_rank=n, rank=rank, world=world, device=local_rank, rtol=args.rtol,
+                             nxy=1024 if args.config5 else None)
     prob.setup()  # mesh generation + nodal data on the device: inputs resident before timing
 
     def barrier():
@@ -158,14 +168,18 @@ def main():
             "metric": "assembled+solved DoF/s, 3D Poisson phi-FEM (tag+assemble+solve)",
             "value": value, "unit": "DoF/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong" if args.config4 else "weak",
+            "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": (f"3D weak-Dirichlet Poisson phi-FEM, P1xP1, spherical level-set, "
                              f"{n}^3 Kuhn box per GPU ({6 * n ** 3} tets), box mode, "
                              f"single-layer cut, gamma=sigma=1") if not args.config5 else
                             ("3D weak-Dirichlet Poisson phi-FEM, P1xP1, unit sphere, 1024x1024x128 Kuhn "
-                             "slab per GPU (805306368 tets), box mode, single-layer cut, gamma=sigma=1"),
+                             "slab per GPU (805306368 tets), box mode, single-layer cut, gamma=sigma=1")
+                            if not args.config4 else
+                            (f"3D interface elasticity phi-FEM, 5-field mixed P1 (27 comps/vertex), "
+                             f"E_in=1, E_out=1e-3, nu=0.3, {n}^3 Kuhn box in {world} z-slab(s), box mode"),
                 "active_dofs": n_active, "krylov": "BiCGStab + Jacobi (right)",
                 "rtol": args.rtol, "iterations": res["iterations"], "relres": res["relres"],
                 "stage_ms": {k: 1e3 * v for k, v in res["stage_s"].items()},

@@ -27,7 +27,7 @@ S_BB = 3
 class HipBackend:
     """The assembled local system of a `PhiFEMSolver` seen through the phase API."""
 
-    def __init__(self, solver, torch_device):
+    def __init__(self, solver, torch_device, blocks=None):
         import torch
         from . import _lib as L
         self.L, self.torch = L, torch
@@ -36,13 +36,19 @@ class HipBackend:
         info = solver.info()
         self.n, self.nv = info["n_active"], solver.mesh.nv
         self.dev = torch_device
+        nent = info["n_full"] // 2 if blocks is None else info["n_full"]
         perm = torch.empty(self.n, dtype=torch.int32, device=self.dev)
-        dof_u = torch.empty(self.nv, dtype=torch.int32, device=self.dev)
-        dof_p = torch.empty(self.nv, dtype=torch.int32, device=self.dev)
+        dof_u = torch.empty(nent, dtype=torch.int32, device=self.dev)
         L.check(L.lib.phx_system_get_perm(self.sys, C.c_void_p(perm.data_ptr()),
-                                          C.c_void_p(dof_u.data_ptr()), C.c_void_p(dof_p.data_ptr()),
-                                          L.DEVICE))
-        self.perm, self.dof_u, self.dof_p = perm.long(), dof_u.long(), dof_p.long()
+                                          C.c_void_p(dof_u.data_ptr()), None, L.DEVICE))
+        self.perm = perm.long()
+        if blocks is None:      # (u, p) mixed scalar system: two blocks over the vertices
+            dof_p = torch.empty(nent, dtype=torch.int32, device=self.dev)
+            L.check(L.lib.phx_system_get_perm(self.sys, None, None, C.c_void_p(dof_p.data_ptr()), L.DEVICE))
+            self.dof_blocks = [dof_u.long(), dof_p.long()]
+        else:                   # component-major blocks of nv entries in ONE map (elasticity)
+            full = dof_u.long()
+            self.dof_blocks = [full[b * self.nv:(b + 1) * self.nv] for b in range(blocks)]
 
     def use_current_stream(self):
         st = self.torch.cuda.current_stream(self.dev).cuda_stream
@@ -84,7 +90,8 @@ def ownership_and_halos(torch, backend, plane_size, k0, P0, P1, rank, world, n_p
     plane = torch.arange(nv, device=dev) // plane_size + k0
     owned_v = (plane >= P0) & (plane < P1)
     owned_a = torch.zeros(n, dtype=torch.bool, device=dev)
-    for dof in (backend.dof_u, backend.dof_p):
+    nblk = len(backend.dof_blocks)
+    for dof in backend.dof_blocks:
         act = dof >= 0
         owned_a[dof[act]] = owned_v[act]
     iperm = torch.empty(n, dtype=torch.long, device=dev)
@@ -95,10 +102,10 @@ def ownership_and_halos(torch, backend, plane_size, k0, P0, P1, rank, world, n_p
         """solver positions + global ids of the active DoFs on global planes [lo, hi)."""
         sel = (plane >= lo) & (plane < hi)
         pos, gid = [], []
-        for kind, dof in enumerate((backend.dof_u, backend.dof_p)):
+        for kind, dof in enumerate(backend.dof_blocks):
             v = torch.nonzero(sel & (dof >= 0)).flatten()
             pos.append(iperm[dof[v]])
-            gid.append((v + k0 * plane_size) * 2 + kind)
+            gid.append((v + k0 * plane_size) * nblk + kind)
         return torch.cat(pos), torch.cat(gid)
 
     halos = []
@@ -327,7 +334,7 @@ class DistributedKrylov:
         from . import _lib as L
         prob = self.prob
         lay = prob.lay
-        backend = HipBackend(prob.solver, self.dev)
+        backend = HipBackend(prob.solver, self.dev, blocks=getattr(prob, "n_blocks", None))
         backend.use_current_stream()
         L.check(L.lib.phx_set_option(prob.mesh._h, L.OPT_PROFILE_SPMV, 1 if profile_spmv else 0))
         plane = (prob.nxy + 1) * (prob.nxy + 1)

@@ -95,3 +95,68 @@ class SlabProblem:
             "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),
             "spmv_algorithmic_bytes": 12.0 * info["sell_nnz"] + 20.0 * info["n_active"],
         }
+
+
+class ElasticitySlabProblem(SlabProblem):
+    """BASELINE configs[3]: 3-D interface elasticity (5-field mixed phi-FEM, P1 vector fields,
+    E_in = 1, E_out = 1e-3, nu = 0.3, phi = 1 - r^2: demo/interface-elasticity/data.py:14-22,39-40)
+    on an n x n x (nz_per_rank * world) Kuhn box of [-1.5,1.5]^3, slab-partitioned.  Tags without the
+    single-layer rule and u_in = u_D on the box boundary, as in the demo (main.py:115-117,158-177)."""
+
+    def __init__(self, nxy, nz_per_rank, rank=0, world=1, device=0, rtol=1e-8, max_iter=200000):
+        super().__init__(nz_per_rank, rank=rank, world=world, device=device, rtol=rtol,
+                         max_iter=max_iter, nxy=nxy)
+        self.n_blocks = 27
+
+    def setup(self):
+        import torch
+        from .solver import InterfaceElasticitySolver
+        lay, nxy = self.lay, self.nxy
+        nzl = lay["k1"] - lay["k0"]
+        self.mesh = create_box([-1.5] * 3, [1.5] * 3, [nxy, nxy, nzl], device=self.device,
+                               offset=[0, 0, lay["k0"]], n_global=[nxy, nxy, lay["nz"]])
+        L.check(L.lib.phx_mesh_set_slab_faces(self.mesh._h, 1 if lay["k0"] > 0 else 0,
+                                              1 if lay["k1"] < lay["nz"] else 0))
+        dev = torch.device("cuda", self.device)
+        x = torch.empty((self.mesh.nv, 3), dtype=torch.float64, device=dev)
+        L.check(L.lib.phx_mesh_get_array(self.mesh._h, L.ARR_COORDS, C.c_void_p(x.data_ptr()), L.DEVICE))
+        self.phi = 1.0 - (x ** 2).sum(dim=1)
+        self.f = torch.stack([torch.sin(x[:, 0]) + 0.2, torch.cos(x[:, 1]), 0.5 * x[:, 2]]).contiguous()
+        self.u_D = (0.1 * torch.stack([x[:, 0] * x[:, 1], torch.sin(x[:, 2]), x[:, 0] - x[:, 1]])).contiguous()
+        # Dirichlet vertices: the faces of the GLOBAL box this slab touches
+        n1 = nxy + 1
+        v = torch.arange(self.mesh.nv, device=dev)
+        i, j, k = v % n1, (v // n1) % n1, v // (n1 * n1) + lay["k0"]
+        on = (i == 0) | (i == nxy) | (j == 0) | (j == nxy) | (k == 0) | (k == lay["nz"])
+        self.bc_vertices = torch.nonzero(on).flatten().to(torch.int32).contiguous()
+        self.out = torch.empty(27 * self.mesh.nv, dtype=torch.float64, device=dev)
+        del x
+        torch.cuda.synchronize()
+        self.solver = InterfaceElasticitySolver(self.mesh)
+        if self.world > 1:
+            from .dist_solver import DistributedKrylov
+            self.dk = DistributedKrylov(self)
+
+    def step(self, profile_spmv=False):
+        mesh = self.mesh
+        staged = _tag_cells(mesh, NodalFunction(self.phi), 1, single_layer_cut=False)
+        if self.world > 1:
+            self.dk.agree_on_exterior()
+        _tag_facets(mesh, staged, 1)
+        info = self.solver.assemble(self.phi, self.f, self.u_D, self.bc_vertices)
+        if self.world == 1:
+            self.solver.solve(rtol=self.rtol, max_iter=self.max_iter, out=self.out,
+                              profile_spmv=profile_spmv)
+            st = self.solver.stats
+            n_owned = info["n_active"]
+        else:
+            st = self.dk.solve(self.out, profile_spmv=profile_spmv)
+            n_owned = st["n_owned"]
+        t = mesh.timings()
+        return {
+            "n_active_owned": n_owned, "iterations": st["iterations"], "relres": st["relres"],
+            "stage_s": {"tag": t["tag_cells"] + t["tag_facets"], "assemble": t["assemble"],
+                        "solve": st["seconds"]},
+            "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),
+            "spmv_algorithmic_bytes": 12.0 * info["sell_nnz"] + 20.0 * info["n_active"],
+        }

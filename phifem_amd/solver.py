@@ -150,18 +150,29 @@ class InterfaceElasticitySolver(PhiFEMSolver):
         self._free()
         m = self.mesh
         d = m.gdim
-        phi_h = np.ascontiguousarray(phi_h, dtype=np.float64)
-        f_cm = np.ascontiguousarray(np.asarray(f_h, dtype=np.float64).T)   # component-major
-        u_cm = np.ascontiguousarray(np.asarray(u_D, dtype=np.float64).T)
-        bcv = np.ascontiguousarray(bc_vertices, dtype=np.int32)
-        if phi_h.shape[0] != m.nv or f_cm.shape != (d, m.nv) or u_cm.shape != (d, m.nv):
-            raise ValueError("phi_h must be (nv,), f_h and u_D (nv, d)")
-        if bcv.size and (bcv.min() < 0 or bcv.max() >= m.nv):
-            raise ValueError("bc_vertices out of range")
         h = C.c_void_p()
-        vp = lambda a: a.ctypes.data_as(C.c_void_p)
-        L.check(L.lib.phx_assemble_elasticity_if(m._h, vp(self.params), vp(phi_h), vp(f_cm), vp(u_cm),
-                                                 vp(bcv), bcv.size, L.HOST, C.byref(h)))
+        if hasattr(phi_h, "data_ptr") and phi_h.is_cuda:
+            # device-resident inputs: f_h, u_D already component-major (d, nv); bc_vertices int32
+            f_cm, u_cm, bcv = f_h.contiguous(), u_D.contiguous(), bc_vertices.contiguous()
+            if tuple(f_cm.shape) != (d, m.nv) or tuple(u_cm.shape) != (d, m.nv):
+                raise ValueError("device f_h and u_D must be component-major (d, nv)")
+            self._keep = (phi_h, f_cm, u_cm, bcv)
+            L.check(L.lib.phx_assemble_elasticity_if(
+                m._h, self.params.ctypes.data_as(C.c_void_p), C.c_void_p(phi_h.data_ptr()),
+                C.c_void_p(f_cm.data_ptr()), C.c_void_p(u_cm.data_ptr()), C.c_void_p(bcv.data_ptr()),
+                bcv.numel(), L.DEVICE, C.byref(h)))
+        else:
+            phi_h = np.ascontiguousarray(phi_h, dtype=np.float64)
+            f_cm = np.ascontiguousarray(np.asarray(f_h, dtype=np.float64).T)   # component-major
+            u_cm = np.ascontiguousarray(np.asarray(u_D, dtype=np.float64).T)
+            bcv = np.ascontiguousarray(bc_vertices, dtype=np.int32)
+            if phi_h.shape[0] != m.nv or f_cm.shape != (d, m.nv) or u_cm.shape != (d, m.nv):
+                raise ValueError("phi_h must be (nv,), f_h and u_D (nv, d)")
+            if bcv.size and (bcv.min() < 0 or bcv.max() >= m.nv):
+                raise ValueError("bc_vertices out of range")
+            vp = lambda a: a.ctypes.data_as(C.c_void_p)
+            L.check(L.lib.phx_assemble_elasticity_if(m._h, vp(self.params), vp(phi_h), vp(f_cm), vp(u_cm),
+                                                     vp(bcv), bcv.size, L.HOST, C.byref(h)))
         self._sys = h
         return self.info()
 

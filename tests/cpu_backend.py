@@ -54,8 +54,8 @@ class CpuBackend:
         self.rhs = b[idx]
         full_to_act = -np.ones(2 * nv, dtype=np.int64)
         full_to_act[idx] = np.arange(idx.size)
-        self.dof_u = torch.from_numpy(full_to_act[:nv].copy())
-        self.dof_p = torch.from_numpy(full_to_act[nv:].copy())
+        self.dof_blocks = [torch.from_numpy(full_to_act[:nv].copy()),
+                           torch.from_numpy(full_to_act[nv:].copy())]
         self.perm = torch.arange(self.n)
 
     def attach(self, work, scal, own):

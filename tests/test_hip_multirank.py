@@ -84,3 +84,64 @@ def test_slabs_on_one_gpu_match_single_mesh(world, tmp_path):
     scale = np.abs(wref).max()
     assert np.abs(u - wref[:nvg]).max() <= 1e-7 * scale
     assert np.abs(p - wref[nvg:]).max() <= 1e-7 * scale
+
+
+def _worker_el(rank, world, nxy, nzr, port, outdir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from phifem_amd.distributed import ElasticitySlabProblem
+        prob = ElasticitySlabProblem(nxy, nzr, rank=rank, world=world, device=0, rtol=1e-11)
+        prob.setup()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = prob.step()
+        lay = prob.lay
+        plane = (nxy + 1) * (nxy + 1)
+        nv = prob.mesh.nv
+        w = prob.out.cpu().numpy().reshape(27, nv)
+        vplane = np.arange(nv) // plane + lay["k0"]
+        owned = (vplane >= lay["P0"]) & (vplane < lay["P1"])
+        gid = np.arange(nv) + lay["k0"] * plane
+        np.savez(os.path.join(outdir, f"e{rank}.npz"), gid=gid[owned], w=w[:, owned],
+                 relres=res["relres"], n_owned=res["n_active_owned"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_elasticity_slabs_match_single_mesh(world, tmp_path):
+    """configs[3] in miniature: the slab-partitioned 5-field elasticity system (27 component blocks
+    per vertex, Dirichlet rows on the global box faces only) against the single-mesh solve."""
+    import torch.multiprocessing as mp
+    import phifem_amd as P
+    from phifem_amd.mesh_scripts import NodalFunction
+    nxy, nzr = 12, 12 // world
+    mp.spawn(_worker_el, args=(world, nxy, nzr, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mesh = P.create_box([-1.5] * 3, [1.5] * 3, [nxy, nxy, nzr * world])
+    x = mesh.x
+    phi = 1.0 - (x ** 2).sum(axis=1)
+    f = np.stack([np.sin(x[:, 0]) + 0.2, np.cos(x[:, 1]), 0.5 * x[:, 2]], axis=1)
+    uD = 0.1 * np.stack([x[:, 0] * x[:, 1], np.sin(x[:, 2]), x[:, 0] - x[:, 1]], axis=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        P.compute_tags_measures(mesh, NodalFunction(phi), 1, box_mode=True)
+    n1 = nxy + 1
+    v = np.arange(mesh.nv)
+    i, j, k = v % n1, (v // n1) % n1, v // (n1 * n1)
+    bcv = np.flatnonzero((i == 0) | (i == nxy) | (j == 0) | (j == nxy) | (k == 0) | (k == nzr * world))
+    s = P.InterfaceElasticitySolver(mesh)
+    info = s.assemble(phi, f, uD, bcv)
+    wref = s.solve(rtol=1e-11, max_iter=200000).reshape(27, mesh.nv)
+    got = np.full((27, mesh.nv), np.nan)
+    n_owned = 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"e{r}.npz"))
+        got[:, d["gid"]] = d["w"]
+        n_owned += int(d["n_owned"])
+        assert d["relres"] <= 1e-11
+    assert not np.any(np.isnan(got)) and n_owned == info["n_active"]
+    assert np.abs(got - wref).max() <= 1e-6 * np.abs(wref).max()
