@@ -25,6 +25,17 @@ def nasty(x):
     return np.sqrt(x[0] ** 2 + x[1] ** 2) * (th * np.sin(1.0 / th)) - 0.25
 
 
+def nasty_interpolated(x):
+    """`nasty` as the reference's discretize=True leg sees it (tests/test_compute_meshtags.py:153-158).
+    On the half line y = 0, x > 0 the formula is NaN (sin(1/0)); dolfinx interpolates at pushed-forward
+    reference nodes whose y is a round-off away from 0 [3P basix], where r*th*sin(1/th) - 0.25 evaluates
+    to its limit -0.25.  OBSERVED: with that value the 8 goldens of degrees 1 and 3 are reproduced
+    exactly; degree 2 keeps NaN on some edge midpoints and stays an expected failure."""
+    with np.errstate(all="ignore"):
+        v = np.asarray(nasty(x), dtype=np.float64)
+    return np.where(np.isnan(v), -0.25, v)
+
+
 def line(x):
     return x[0] + 0.35
 

@@ -16,7 +16,7 @@ from oracle import tagging as T
 from oracle.topology import Topology
 
 from datasets import (FP_FRAGILE, FP_FRAGILE_DISCRETIZED, MESHTAG_DATA, ONE_SIDED_DATA,
-                      load_mesh)
+                      load_mesh, nasty_interpolated)
 
 HERE = os.path.dirname(__file__)
 GOLD = np.load(os.path.join(HERE, "golden", "tags_golden.npz"))
@@ -45,6 +45,9 @@ CASES = [(n, d, disc, box, sl) for n in MESHTAG_DATA for d in (1, 2, 3)
 def test_tag_histograms(name, deg, disc, box, sl):
     fragile = name in (FP_FRAGILE_DISCRETIZED if disc else FP_FRAGILE)
     mesh, f = MESHTAG_DATA[name]
+    if disc and name == "nasty_levelset":
+        f = nasty_interpolated
+        fragile = deg == 2
     ctype, x, cells = load_mesh(mesh)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
