@@ -128,9 +128,14 @@ int phx_mesh_synchronize(phx_mesh *m);
 int phx_mesh_set_stream(phx_mesh *m, uint64_t stream);
 enum phx_option {
   PHX_OPT_PROFILE_SPMV = 1, /* bracket every SpMV launch of a solve with HIP events            */
-  PHX_OPT_HAS_EXTERIOR = 2  /* -1: `len(exterior_cells) == 0` (mesh_scripts.py:469) is decided
+  PHX_OPT_HAS_EXTERIOR = 2, /* -1: `len(exterior_cells) == 0` (mesh_scripts.py:469) is decided
                                from this mesh's tags; 0/1: imposed by a multi-GPU driver that
                                reduced it over all slabs                                        */
+  PHX_OPT_SPMV_XCD_GROUP = 3, /* G > 0: SpMV blocks are regrouped so that each XCD (blockIdx % 8)
+                               walks runs of G consecutive blocks; 0: plain order (default)      */
+  PHX_OPT_SPMV_VALUE_INDEX = 4 /* 1 (default): systems assembled from now on store SELL slices whose
+                               values take <= 64 distinct doubles as dictionary + byte codes
+                               (bit-identical products, 5 instead of 12 bytes per entry); 0: raw */
 };
 int phx_set_option(phx_mesh *m, int option, int64_t value);
 /* Tag counts of the current tagging: cells4[t] for t = 0..3, facets7[t] for t = 0..6. */
@@ -196,8 +201,10 @@ int phx_assemble_elasticity_if(phx_mesh *m, const double *params, const double *
                                const double *f_h, const double *u_D, const int32_t *bc_vertices,
                                int64_t nbc, int loc, phx_system **out);
 int phx_system_destroy(phx_system *s);
-/* info[8] = {n_active, n_active_u, nnz (structural, CSR), n_full (= 2*nv), sell_padded_nnz,
- *            slot_capacity, sell_nnz (explicit zeros dropped), n_slices} */
+/* info[11] = {n_active, n_active_u, nnz (structural, CSR), n_full (= 2*nv), sell_padded_nnz,
+ *             slot_capacity, sell_nnz (explicit zeros dropped), n_slices, value-indexed slices,
+ *             matrix bytes one SpMV of the solve streams (columns + value stream + slice table),
+ *             value-indexed slices whose dictionary exceeds 64 entries (LDS look-up)} */
 int phx_system_info(const phx_system *s, int64_t *info);
 /* CSR of the active system in ORIGINAL active numbering (sorted columns) + the map active row ->
  * full DoF index; host buffers: rowptr[n_active+1], col[nnz], val[nnz], rhs[n_active],

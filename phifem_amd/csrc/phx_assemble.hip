@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "phx_common.h"
+#include "phx_select.h"
 
 int phx_collect_entities(phx_mesh *m);
 int phx_system_build_sell(phx_system *s);
@@ -283,6 +284,106 @@ k_assemble_rows(int64_t nv, const int64_t *__restrict__ v2c_ptr, const int32_t *
   }
 }
 
+// --- the same rows on a Kuhn box (phx_mesh_create_box): the star of a vertex is known in closed form.
+// Simplex t of cube o walks o, o+e_p0, o+e_p0+e_p1(, ...) for the t-th axis permutation p
+// (k_box_cells), so vertex V is path vertex m of simplex t of the cube at V - e_p0 - ... - e_p(m-1):
+// 24 tetrahedra / 6 triangles and 14 / 6 neighbours at fixed lattice offsets.  With every loop
+// unrolled the accumulators are registers addressed at compile time: no v2c list, no connectivity
+// loads, no LDS hash, and every interior row runs the very same arithmetic (which is what lets
+// k_sell_index fold the interior values into a dictionary).
+struct BoxDims { int64_t n[3]; };
+
+template <int D>
+__global__ void __launch_bounds__(256)
+k_assemble_rows_box(int64_t nv, BoxDims bd, AsmArgs A) {
+  constexpr int N = D + 1, NPERM = D == 3 ? 6 : 2, NCODE = D == 3 ? 27 : 9;
+  constexpr int P[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};  // c_perm3 / c_perm2
+  constexpr int P2[2][3] = {{0, 1, 0}, {1, 0, 0}};
+  constexpr int POW3[3] = {1, 3, 9};
+  constexpr double c2 = D == 3 ? 1.0 / 20.0 : 1.0 / 12.0;
+  const int64_t vtx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (vtx >= nv) return;
+  const int32_t row = A.du[vtx];
+  if (row < 0) return;
+  const int64_t n0 = bd.n[0] + 1, n1 = bd.n[1] + 1;
+  int64_t idx[3] = {vtx % n0, D == 3 ? (vtx / n0) % n1 : vtx / n0, D == 3 ? vtx / (n0 * n1) : 0};
+  const int64_t vstride[3] = {1, n0, n0 * n1};
+  const int64_t cstride[3] = {1, bd.n[0], bd.n[0] * bd.n[1]};
+  // neighbour coordinates and source values, once (offset code = sum (d_a + 1) 3^a)
+  double nx[NCODE][D], nf[NCODE], acc[NCODE];
+  bool seen[NCODE];
+#pragma unroll
+  for (int code = 0; code < NCODE; ++code) {
+    int d[3] = {code % 3 - 1, (code / 3) % 3 - 1, D == 3 ? code / 9 - 1 : 0};
+    // Kuhn neighbours: all non-zero components share one sign
+    bool pos = false, neg = false;
+    for (int a = 0; a < D; ++a) { pos |= d[a] > 0; neg |= d[a] < 0; }
+    acc[code] = 0.0;
+    seen[code] = false;
+    nf[code] = 0.0;
+    for (int a = 0; a < D; ++a) nx[code][a] = 0.0;
+    if (pos && neg) continue;
+    bool in = true;
+    int64_t w = vtx;
+    for (int a = 0; a < D; ++a) {
+      const int64_t q = idx[a] + d[a];
+      in = in && q >= 0 && q <= bd.n[a];
+      w += d[a] * vstride[a];
+    }
+    if (!in) continue;
+    for (int a = 0; a < D; ++a) nx[code][a] = A.x[w * D + a];
+    nf[code] = A.f[w];
+  }
+  constexpr int SELF = D == 3 ? 13 : 4;
+  double rhs = 0.0;
+#pragma unroll
+  for (int t = 0; t < NPERM; ++t) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+      int dd[3] = {0, 0, 0};
+      for (int q = 0; q < m; ++q) dd[D == 3 ? P[t][q] : P2[t][q]] -= 1;
+      bool in = true;
+      int64_t cube = 0;
+      for (int a = 0; a < D; ++a) {
+        const int64_t o = idx[a] + dd[a];
+        in = in && o >= 0 && o < bd.n[a];
+        cube += o * cstride[a];
+      }
+      if (!in) continue;
+      const int tag = A.ctags[cube * NPERM + t] & PHX_TAG_MASK;
+      if (tag != 1 && tag != 2) continue;
+      int code[N];
+      double X[N][D];
+      double sf = 0.0;
+      for (int q = 0; q < N; ++q) {
+        code[q] = 0;
+        for (int a = 0; a < D; ++a) code[q] += (dd[a] + 1) * POW3[a];
+        for (int a = 0; a < D; ++a) X[q][a] = nx[code[q]][a];
+        sf += nf[code[q]];
+        if (q < D) dd[D == 3 ? P[t][q] : P2[t][q]] += 1;
+      }
+      Geo<D> G;
+      simplex_geometry<D>(X, G);
+      for (int j = 0; j < N; ++j) {
+        double k = 0.0;
+        for (int a = 0; a < D; ++a) k += G.g[m][a] * G.g[j][a];
+        acc[code[j]] += k * G.vol;
+        seen[code[j]] = true;
+      }
+      rhs += G.vol * c2 * (sf + nf[SELF]);  // int f_h N_i
+    }
+  }
+  A.rhs[row] = rhs;
+#pragma unroll
+  for (int code = 0; code < NCODE; ++code) {
+    if (!seen[code]) continue;
+    int64_t w = vtx;
+    w += (code % 3 - 1) * vstride[0] + ((code / 3) % 3 - 1) * vstride[1];
+    if (D == 3) w += (code / 9 - 1) * vstride[2];
+    slot_add_owned(A.slots, row, (int32_t)w, acc[code]);
+  }
+}
+
 // --- cut cells, main.py:115-122,144-149 (penalisation): 64 lanes per cell, lane = (a, b) of the mixed
 // (u,p) x (u,p) element tensor, a = i (u_i) or N + i (p_i) ---------------------------------------
 template <int D>
@@ -423,20 +524,7 @@ __global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const in
 
 template <typename Pred>
 static int build_list(phx_mesh *m, int64_t n, Pred pred, int32_t **list, int64_t *count) {
-  int64_t *dcount = nullptr;
-  PHX_HIP(phx_malloc(list, sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
-  PHX_HIP(phx_malloc(&dcount, sizeof(int64_t)));
-  hipcub::CountingInputIterator<int32_t> it(0);
-  size_t bytes = 0;
-  PHX_HIP(hipcub::DeviceSelect::If(nullptr, bytes, it, *list, dcount, (int)n, pred, m->stream));
-  void *tmp = nullptr;
-  PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-  PHX_HIP(hipcub::DeviceSelect::If(tmp, bytes, it, *list, dcount, (int)n, pred, m->stream));
-  PHX_HIP(hipMemcpyAsync(count, dcount, sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
-  PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(phx_free(tmp));
-  PHX_HIP(phx_free(dcount));
-  return PHX_OK;
+  return phx_select_indices(m->stream, n, pred, list, count);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -559,7 +647,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active, s->rowptr, s->col,
                   s->val, s->rhs, s->diag, s->slice_ptr, s->sell_col, s->sell_val,
-                  s->sell_val_raw, s->perm, s->iperm, s->work, s->scal};
+                  s->sell_val_raw, s->sell_kind, s->perm, s->iperm, s->work, s->scal};
   for (void *p : ptrs) (void)phx_free(p);
   if (s->scal_h) (void)hipHostFree(s->scal_h);
   for (auto &e : s->prof_ev) (void)hipEventDestroy(e);
@@ -678,9 +766,16 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut));
   PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac));
   {
-    const dim3 g((unsigned)phx_div_up(m->nv, ROW_THREADS)), b(ROW_THREADS);
-    if (D == 2) k_assemble_rows<2><<<g, b, 0, m->stream>>>(m->nv, m->v2c_ptr, m->v2c_idx, A);
-    else k_assemble_rows<3><<<g, b, 0, m->stream>>>(m->nv, m->v2c_ptr, m->v2c_idx, A);
+    if (m->is_box) {
+      const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}};
+      const dim3 g((unsigned)phx_div_up(m->nv, 256));
+      if (D == 2) k_assemble_rows_box<2><<<g, block, 0, m->stream>>>(m->nv, bd, A);
+      else k_assemble_rows_box<3><<<g, block, 0, m->stream>>>(m->nv, bd, A);
+    } else {
+      const dim3 g((unsigned)phx_div_up(m->nv, ROW_THREADS)), b(ROW_THREADS);
+      if (D == 2) k_assemble_rows<2><<<g, b, 0, m->stream>>>(m->nv, m->v2c_ptr, m->v2c_idx, A);
+      else k_assemble_rows<3><<<g, b, 0, m->stream>>>(m->nv, m->v2c_ptr, m->v2c_idx, A);
+    }
   }
   if (n_cut > 0) {
     const dim3 g((unsigned)phx_div_up(n_cut * 64, 256));
@@ -759,7 +854,7 @@ extern "C" int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab
               PHX_ERR_NOT_IMPLEMENTED, "assembly supports simplices (triangle, tetrahedron) only");
   PHX_REQUIRE(m->have_cell_tags && m->have_facet_tags, PHX_ERR_VALUE,
               "cell and facet tags must be computed before assembly");
-  PHX_CHECK(build_v2c(m));
+  if (!m->is_box) PHX_CHECK(build_v2c(m));  // Kuhn boxes enumerate vertex stars in closed form
   const double *dphi, *df, *dud;
   double *o1, *o2, *o3;
   PHX_CHECK(to_device(m, phi_h, loc, m->nv, &dphi, &o1));
@@ -779,6 +874,7 @@ extern "C" int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab
 extern "C" int phx_system_info(const phx_system *s, int64_t *info) {
   info[0] = s->n; info[1] = s->nu; info[2] = s->nnz; info[3] = s->nfull;
   info[4] = s->sell_nnz; info[5] = s->slot_cap; info[6] = s->sell_true_nnz; info[7] = s->nslices;
+  info[8] = s->sell_indexed_slices; info[9] = s->sell_stream_bytes; info[10] = s->sell_indexed_large;
   return PHX_OK;
 }
 

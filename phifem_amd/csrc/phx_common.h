@@ -105,6 +105,8 @@ struct phx_mesh {
   double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool own_stream = true;
   int profile_spmv = 0;
+  int spmv_xcd_group = 0;          // PHX_OPT_SPMV_XCD_GROUP
+  int spmv_value_index = 1;        // PHX_OPT_SPMV_VALUE_INDEX
   int has_exterior_override = -1;  // -1: decide from the local tags; 0/1: imposed (multi-GPU)
 };
 
@@ -129,6 +131,9 @@ struct phx_system {
   int32_t *sell_col = nullptr;   // [sell_nnz] solver-order column ids
   double *sell_val = nullptr;    // [sell_nnz] values of A*D^-1 (right Jacobi scaling)
   double *sell_val_raw = nullptr;// [sell_nnz] values of A
+  uint8_t *sell_kind = nullptr;      // [nslices] dictionary size of a value-indexed slice of sell_val, 0 = raw doubles
+  uint8_t *sell_kind_raw = nullptr;  // same for sell_val_raw (second half of the sell_kind allocation)
+  int64_t sell_indexed_slices = 0, sell_indexed_large = 0, sell_stream_bytes = 0;
   int32_t *perm = nullptr;       // [n] solver position -> original active row
   int32_t *iperm = nullptr;      // [n] original active row -> solver position
   // solver workspace

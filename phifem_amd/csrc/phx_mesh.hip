@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "phx_common.h"
+#include "phx_select.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -347,31 +348,18 @@ __global__ void k_bfacet_pairs(int64_t nbf, const int32_t *__restrict__ bf,
 
 static int build_boundary_list(phx_mesh *m) {
   int32_t *sel = nullptr;
-  int64_t *dcount = nullptr;
-  PHX_HIP(phx_malloc(&sel, sizeof(int32_t) * (size_t)m->nf));
-  PHX_HIP(phx_malloc(&dcount, sizeof(int64_t)));
-  hipcub::CountingInputIterator<int32_t> it(0);
-  IsBoundary pred{m->f2c};
-  size_t tmp_bytes = 0;
-  PHX_HIP(hipcub::DeviceSelect::If(nullptr, tmp_bytes, it, sel, dcount, (int)m->nf, pred, m->stream));
-  void *tmp = nullptr;
-  PHX_HIP(phx_malloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-  PHX_HIP(hipcub::DeviceSelect::If(tmp, tmp_bytes, it, sel, dcount, (int)m->nf, pred, m->stream));
   int64_t nbf = 0;
-  PHX_HIP(hipMemcpyAsync(&nbf, dcount, sizeof(int64_t), hipMemcpyDeviceToHost, m->stream));
-  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_CHECK(phx_select_indices(m->stream, m->nf, IsBoundary{m->f2c}, &sel, &nbf));
   m->nbf = nbf;
   PHX_HIP(phx_malloc(&m->bfacets, sizeof(int32_t) * 2 * (size_t)(nbf > 0 ? nbf : 1)));
   if (nbf > 0)
     k_bfacet_pairs<<<dim3((unsigned)phx_div_up(nbf, 256)), dim3(256), 0, m->stream>>>(
         nbf, sel, m->f2c, m->c2f, m->ci.nfpc, m->bfacets);
   PHX_HIP(hipStreamSynchronize(m->stream));
-  PHX_HIP(phx_free(tmp));
   PHX_HIP(phx_malloc(&m->bfacet_ids, sizeof(int32_t) * (size_t)(nbf > 0 ? nbf : 1)));
   if (nbf > 0)
     PHX_HIP(hipMemcpy(m->bfacet_ids, sel, sizeof(int32_t) * (size_t)nbf, hipMemcpyDeviceToDevice));
   PHX_HIP(phx_free(sel));
-  PHX_HIP(phx_free(dcount));
   return PHX_OK;
 }
 
@@ -803,6 +791,11 @@ extern "C" int phx_set_option(phx_mesh *m, int option, int64_t value) {
   switch (option) {
     case PHX_OPT_PROFILE_SPMV: m->profile_spmv = value != 0; return PHX_OK;
     case PHX_OPT_HAS_EXTERIOR: m->has_exterior_override = (int)value; return PHX_OK;
+    case PHX_OPT_SPMV_VALUE_INDEX: m->spmv_value_index = value != 0; return PHX_OK;
+    case PHX_OPT_SPMV_XCD_GROUP:
+      PHX_REQUIRE(value >= 0 && value < (1 << 24), PHX_ERR_VALUE, "XCD group size out of range");
+      m->spmv_xcd_group = (int)value;
+      return PHX_OK;
     default: phx_set_error("unknown option %d", option); return PHX_ERR_VALUE;
   }
 }

@@ -1,0 +1,62 @@
+// Ordered stream compaction of entity indices: list = [i in 0..n-1 : pred(i)], ascending.
+// The entity arrays here have 1e8..1e9 items of which a thin layer (cut cells, ghost-penalty facets)
+// is kept, and the predicates read one tag byte per item: a wavefront walks a contiguous chunk in
+// rounds of 64 consecutive items (one 64-byte request per round), ranks the kept ones with a ballot,
+// and the per-chunk counts are scanned in between -- two streaming passes over the tag bytes instead
+// of a generic look-back select (measured on 2e8 facets: 2.0 ms -> see DESIGN.md).
+#pragma once
+#include <hipcub/hipcub.hpp>
+
+#include "phx_common.h"
+
+#define PHX_SEL_ROUNDS 32
+#define PHX_SEL_CHUNK (64 * PHX_SEL_ROUNDS)
+
+template <typename Pred, bool FILL>
+__global__ void __launch_bounds__(256)
+k_select_chunks(int64_t n, Pred pred, int32_t *__restrict__ chunk_counts,
+                const int32_t *__restrict__ chunk_offsets, int32_t *__restrict__ list) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t base = chunk * PHX_SEL_CHUNK;
+  if (base >= n) return;
+  int64_t pos = FILL ? chunk_offsets[chunk] : 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int r = 0; r < PHX_SEL_ROUNDS; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    const bool keep = i < n && pred((int32_t)i);
+    const unsigned long long mask = __ballot(keep);
+    if (FILL && keep) list[pos + __popcll(mask & below)] = (int32_t)i;
+    pos += __popcll(mask);
+  }
+  if (!FILL && lane == 0) chunk_counts[chunk] = (int32_t)pos;
+}
+
+// Allocates *list with exactly the kept count (at least one entry) and returns the count.
+template <typename Pred>
+static int phx_select_indices(hipStream_t stream, int64_t n, Pred pred, int32_t **list, int64_t *count) {
+  *list = nullptr;
+  *count = 0;
+  const int64_t nchunks = phx_div_up(n > 0 ? n : 1, (int64_t)PHX_SEL_CHUNK);
+  int32_t *cnt = nullptr, *off = nullptr;
+  PHX_HIP(phx_malloc(&cnt, sizeof(int32_t) * (size_t)(nchunks + 1)));
+  PHX_HIP(phx_malloc(&off, sizeof(int32_t) * (size_t)(nchunks + 1)));
+  PHX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(nchunks + 1), stream));
+  const dim3 block(256), grid((unsigned)phx_div_up(nchunks, 4));
+  if (n > 0) k_select_chunks<Pred, false><<<grid, block, 0, stream>>>(n, pred, cnt, nullptr, nullptr);
+  size_t bytes = 0;
+  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt, off, (int)(nchunks + 1), stream));
+  void *tmp = nullptr;
+  PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, cnt, off, (int)(nchunks + 1), stream));
+  int32_t total = 0;
+  PHX_HIP(hipMemcpyAsync(&total, off + nchunks, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  PHX_HIP(hipStreamSynchronize(stream));
+  PHX_HIP(phx_malloc(list, sizeof(int32_t) * (size_t)(total > 0 ? total : 1)));
+  if (total > 0) k_select_chunks<Pred, true><<<grid, block, 0, stream>>>(n, pred, nullptr, off, *list);
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipStreamSynchronize(stream));
+  PHX_HIP(phx_free(tmp)); PHX_HIP(phx_free(cnt)); PHX_HIP(phx_free(off));
+  *count = total;
+  return PHX_OK;
+}

@@ -113,6 +113,85 @@ __global__ void k_sell_fill(int64_t n, const int64_t *__restrict__ rowptr,
   }
 }
 
+// Value-indexed slices (CSR-VI idea on SELL).  phi-FEM matrices on a structured background mesh repeat
+// a handful of doubles over the interior rows (7-point rows: ~6 distinct values per slice when the cell
+// size is a dyadic rational, a few dozen otherwise), so a slice whose values take K <= 192 distinct bit
+// patterns is rewritten IN PLACE, inside its own value region, as
+//   [ceil(K/64) x 64-entry dictionary][one byte code per entry, 4 consecutive k packed per lane dword]:
+// 5 instead of 12 bytes per entry for the SpMV to stream, and the products are bit-identical.
+// kind[s] = K (0: the slice keeps raw doubles).  One wavefront per slice; `totals` = {indexed slices,
+// bytes of value stream the SpMV reads, slices with K > 64}.
+#define VI_MAX 192
+typedef uint32_t __attribute__((may_alias)) u32_alias;
+typedef unsigned long long __attribute__((may_alias)) u64_alias;
+
+__global__ void __launch_bounds__(256)
+k_sell_index(int64_t nslices, const int64_t *__restrict__ slice_ptr, double *sval,
+             uint8_t *__restrict__ kind, unsigned long long *__restrict__ totals, int enable) {
+  __shared__ unsigned long long sdict[4][VI_MAX];
+  const int lane = threadIdx.x & 63;
+  unsigned long long *dict = sdict[threadIdx.x >> 6];  // private to this wavefront
+  const int64_t s = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (s >= nslices) return;
+  const int64_t base = slice_ptr[s];
+  const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+  u64_alias *v = reinterpret_cast<u64_alias *>(sval + base);
+  int K = 0;
+  bool ok = enable != 0;
+  for (int k = 0; k < width && ok; ++k) {
+    const unsigned long long val = v[(int64_t)k * SELL_C + lane];
+    bool found = false;
+    for (int j = 0; j < K; ++j) found |= (val == dict[j]);
+    unsigned long long pending = __ballot(!found);
+    while (pending) {
+      if (K == VI_MAX) { ok = false; break; }
+      const int src = __ffsll((long long)pending) - 1;
+      const unsigned long long nv = (unsigned long long)__shfl((long long)val, src);
+      if (lane == 0) dict[K] = nv;
+      ++K;
+      pending &= ~__ballot(val == nv);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // the region (512 B per k) must hold dictionary chunks + codes; chunks <= 3 keeps the in-place
+  // rewrite below from clobbering rows it has not read yet
+  const int chunks = (K + SELL_C - 1) / SELL_C, code_rows = (width + 3) / 4;
+  if (ok && 2 * chunks + code_rows > 2 * width) ok = false;
+  if (!ok) {
+    if (lane == 0) {
+      kind[s] = 0;
+      atomicAdd(&totals[1], (unsigned long long)width * SELL_C * 8ull);
+    }
+    return;
+  }
+  u32_alias *cw = reinterpret_cast<u32_alias *>(v + (int64_t)chunks * SELL_C);
+  for (int k4 = 0; k4 < code_rows; ++k4) {
+    unsigned long long q[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 4 * k4 + j;
+      q[j] = k < width ? v[(int64_t)k * SELL_C + lane] : 0ull;
+    }
+    uint32_t codes = 0;
+    for (int e = 0; e < K; ++e) {
+      const unsigned long long d = dict[e];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * k4 + j < width && q[j] == d) codes |= (uint32_t)e << (8 * j);
+    }
+    // rows 4 k4 .. 4 k4 + 3 were read by every lane above; the dword lands in row
+    // chunks + k4 / 2 <= 3 + k4 / 2 <= 4 k4 + 3, never in a row still to be read
+    cw[(int64_t)k4 * SELL_C + lane] = codes;
+  }
+  for (int j = lane; j < chunks * SELL_C; j += SELL_C) v[j] = j < K ? dict[j] : 0ull;
+  if (lane == 0) {
+    kind[s] = (uint8_t)K;
+    atomicAdd(&totals[0], 1ull);
+    if (chunks > 1) atomicAdd(&totals[2], 1ull);
+    atomicAdd(&totals[1], (unsigned long long)K * 8ull + (unsigned long long)code_rows * 256ull);
+  }
+}
+
 int phx_system_build_sell(phx_system *s) {
   phx_mesh *m = s->mesh;
   const int64_t n = s->n;
@@ -167,6 +246,25 @@ int phx_system_build_sell(phx_system *s) {
       n, s->rowptr, s->col, s->val, s->diag, s->perm, s->iperm, s->slice_ptr, s->sell_col,
       s->sell_val, s->sell_val_raw);
   PHX_HIP(hipGetLastError());
+  {
+    PHX_HIP(phx_malloc(&s->sell_kind, (size_t)s->nslices * 2));
+    s->sell_kind_raw = s->sell_kind + s->nslices;
+    unsigned long long *tot = nullptr, htot[8];
+    PHX_HIP(phx_malloc(&tot, sizeof(htot)));
+    PHX_HIP(hipMemsetAsync(tot, 0, sizeof(htot), m->stream));
+    const dim3 gi((unsigned)phx_div_up(s->nslices, 4));
+    k_sell_index<<<gi, block, 0, m->stream>>>(s->nslices, s->slice_ptr, s->sell_val, s->sell_kind, tot, m->spmv_value_index);
+    // the unscaled copy only serves phx_spmv (inspection): it stays raw
+    PHX_HIP(hipMemsetAsync(s->sell_kind_raw, 0, (size_t)s->nslices, m->stream));
+    PHX_HIP(hipGetLastError());
+    PHX_HIP(hipMemcpyAsync(htot, tot, sizeof(htot), hipMemcpyDeviceToHost, m->stream));
+    PHX_HIP(hipStreamSynchronize(m->stream));
+    PHX_HIP(phx_free(tot));
+    s->sell_indexed_slices = (int64_t)htot[0];
+    s->sell_indexed_large = (int64_t)htot[2];
+    // what one SpMV of the solve streams from the matrix: columns + value stream + slice table
+    s->sell_stream_bytes = 4 * s->sell_nnz + (int64_t)htot[1] + 9 * s->nslices;
+  }
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(tmp)); PHX_HIP(phx_free(keys)); PHX_HIP(phx_free(keys2)); PHX_HIP(phx_free(rows));
   PHX_HIP(phx_free(widths));
@@ -192,18 +290,21 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
             const int32_t *__restrict__ scol, const double *__restrict__ sval,
             const double *__restrict__ x, double *__restrict__ y,
             const uint8_t *__restrict__ own, const double *__restrict__ d0,
-            double *__restrict__ out0, double *__restrict__ out1) {
+            double *__restrict__ out0, double *__restrict__ out1, int xcd_group,
+            const uint8_t *__restrict__ kind) {
+  __shared__ double vi_dict[4][VI_MAX];
   const int lane = threadIdx.x & 63;
-  // XCD-aware block -> slice-group map: blocks b and b+8 share an XCD (and its 4 MiB L2), so XCD k
-  // is given the k-th CONTIGUOUS eighth of the slices; the x entries its rows gather then live in
-  // one L2 instead of being pulled into all eight (speed only; any placement is correct).
+  // Optional XCD-aware block -> slice map (PHX_OPT_SPMV_XCD_GROUP): blocks b and b+8 share an XCD and
+  // its L2; inside every run of 8*G consecutive block ids XCD k is handed G CONSECUTIVE slice groups,
+  // so the x entries its rows gather stay in one L2.  Speed only: any placement is correct.
   int64_t bid = blockIdx.x;
-#ifdef PHX_SPMV_XCD
-  {
-    const int64_t nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  if (xcd_group > 0) {
+    const int64_t super = 8 * (int64_t)xcd_group, sg = bid / super;
+    if ((sg + 1) * super <= (int64_t)gridDim.x) {
+      const int64_t rem = bid - sg * super;
+      bid = sg * super + (rem & 7) * xcd_group + (rem >> 3);
+    }
   }
-#endif
   const int64_t s = bid * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   double acc = 0.0;
   int64_t row = -1;
@@ -212,7 +313,40 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
     const int width = (int)((slice_ptr[s + 1] - base) >> 6);
     const int32_t *c = scol + base + lane;
     const double *v = sval + base + lane;
+    const int nd = kind[s];
     int k = 0;
+    if (nd) {
+      // value-indexed slice (k_sell_index): one code byte per entry; dictionaries of up to 64 doubles
+      // live one per lane (looked up with a cross-lane read), larger ones in this wave's LDS strip
+      const int chunks = (nd + SELL_C - 1) >> 6;
+      const uint32_t *cw = reinterpret_cast<const uint32_t *>(sval + base + chunks * SELL_C) + lane;
+      if (chunks == 1) {
+        const double dreg = lane < nd ? v[0] : 0.0;
+        for (; k + 4 <= width; k += 4) {
+          const uint32_t w4 = NT_LOAD(&cw[(k >> 2) * SELL_C]);
+          const int32_t c0 = NT_LOAD(&c[(k + 0) * SELL_C]), c1 = NT_LOAD(&c[(k + 1) * SELL_C]);
+          const int32_t c2 = NT_LOAD(&c[(k + 2) * SELL_C]), c3 = NT_LOAD(&c[(k + 3) * SELL_C]);
+          acc += __shfl(dreg, (int)(w4 & 255u)) * x[c0];
+          acc += __shfl(dreg, (int)((w4 >> 8) & 255u)) * x[c1];
+          acc += __shfl(dreg, (int)((w4 >> 16) & 255u)) * x[c2];
+          acc += __shfl(dreg, (int)(w4 >> 24)) * x[c3];
+        }
+        if (k < width) {
+          uint32_t w4 = NT_LOAD(&cw[(k >> 2) * SELL_C]);
+          for (; k < width; ++k, w4 >>= 8) acc += __shfl(dreg, (int)(w4 & 255u)) * x[NT_LOAD(&c[k * SELL_C])];
+        }
+      } else {
+        double *sd = vi_dict[threadIdx.x >> 6];
+        for (int j = lane; j < nd; j += SELL_C) sd[j] = sval[base + j];
+        __builtin_amdgcn_wave_barrier();
+        for (; k < width; k += 4) {
+          uint32_t w4 = NT_LOAD(&cw[(k >> 2) * SELL_C]);
+          const int ke = min(k + 4, width);
+          for (int kk = k; kk < ke; ++kk, w4 >>= 8) acc += sd[w4 & 255u] * x[NT_LOAD(&c[kk * SELL_C])];
+        }
+        k = width;
+      }
+    }
     // the matrix is streamed once: non-temporal loads keep it from evicting x out of L2 / MALL
     for (; k + 4 <= width; k += 4) {
       const int32_t c0 = NT_LOAD(&c[(k + 0) * SELL_C]), c1 = NT_LOAD(&c[(k + 1) * SELL_C]);
@@ -434,12 +568,14 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   hipStream_t st = s->mesh->stream;
   const dim3 block(256), grid((unsigned)phx_div_up(s->nslices, 4));
   const uint8_t *own = s->own;
+  const int xg = s->mesh->spmv_xcd_group;
+  const uint8_t *kinds = vals == s->sell_val ? s->sell_kind : s->sell_kind_raw;
   if (dots == 0)
-    k_spmv_sell<0><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1);
+    k_spmv_sell<0><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds);
   else if (dots == 1)
-    k_spmv_sell<1><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1);
+    k_spmv_sell<1><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds);
   else
-    k_spmv_sell<2><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1);
+    k_spmv_sell<2><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
 }

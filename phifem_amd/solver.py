@@ -78,10 +78,10 @@ class PhiFEMSolver:
         return self.mesh.nv if self.degree == 1 else self.mesh.nv + self.mesh.ne
 
     def info(self):
-        i = (C.c_int64 * 8)()
+        i = (C.c_int64 * 11)()
         L.check(L.lib.phx_system_info(self._sys, i))
         keys = ("n_active", "n_active_u", "nnz", "n_full", "sell_padded_nnz", "slot_capacity",
-                "sell_nnz", "n_slices")
+                "sell_nnz", "n_slices", "indexed_slices", "spmv_matrix_bytes", "indexed_slices_lds")
         return dict(zip(keys, (int(v) for v in i)))
 
     def export_csr(self):

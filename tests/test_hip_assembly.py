@@ -266,3 +266,42 @@ def test_native_rccl_loop_world1(P):
     assert torch.equal(vec[recv], send.to(torch.float64))
     assert torch.equal(vec[send], send.to(torch.float64))
     L.check(L.lib.phx_comm_destroy(comm))
+
+
+@pytest.mark.parametrize("d,n", [(2, 64), (3, 32), (3, 20), (3, 27), (2, 100), (2, 96)])
+def test_value_indexed_slices_are_bit_identical(P, d, n):
+    """SELL slices stored as dictionary + byte codes (PHX_OPT_SPMV_VALUE_INDEX) must give the very same
+    products as raw doubles.  Two assemblies differ in the last bits on rows that receive atomic
+    scatter (cut cells, facets), so bit equality is asserted on the rows whose CSR values are
+    bit-identical in both -- the gathered interior rows, which are the ones that get indexed."""
+    from phifem_amd import _lib as L
+    work, phi, f, uex, A, b, act = setup_problem(P, d, n)
+    rng = np.random.default_rng(5)
+    ys, sols, infos, mats = [], [], [], []
+    for flag in (1, 0):
+        L.check(L.lib.phx_set_option(work._h, L.OPT_SPMV_VALUE_INDEX, flag))
+        s = P.PhiFEMSolver(work)
+        info = s.assemble(phi, f, uex)
+        infos.append(info)
+        if flag:
+            x = rng.standard_normal(info["n_active"])
+        ys.append(s.spmv(x))
+        sols.append(s.solve(rtol=1e-10))
+        mats.append(hip_matrix(s)[0])
+    L.check(L.lib.phx_set_option(work._h, L.OPT_SPMV_VALUE_INDEX, 1))
+    print(d, n, {k: infos[0][k] for k in ("n_slices", "indexed_slices", "indexed_slices_lds")})
+    assert infos[1]["indexed_slices"] == 0
+    if (3 * 2 ** 20) % n == 0:
+        # cell size exactly representable: interior rows repeat bit for bit
+        assert infos[0]["indexed_slices"] > 0
+        assert infos[0]["spmv_matrix_bytes"] < infos[1]["spmv_matrix_bytes"]
+    M0, M1 = mats
+    assert np.array_equal(M0.indptr, M1.indptr) and np.array_equal(M0.indices, M1.indices)
+    differs = np.add.reduceat((M0.data != M1.data).astype(np.int64), M0.indptr[:-1]) > 0
+    same = ~differs
+    assert same.mean() > 0.2
+    assert np.array_equal(ys[0][same], ys[1][same])
+    scale = np.abs(M0).max() * np.abs(x).max()
+    assert np.abs(ys[0] - ys[1]).max() <= 1e-13 * scale
+    assert np.abs(ys[0] - M0 @ x).max() <= 1e-13 * scale
+    assert np.abs(sols[0] - sols[1]).max() <= 1e-8 * np.abs(sols[1]).max()
