@@ -322,18 +322,24 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
       const uint32_t *cw = reinterpret_cast<const uint32_t *>(sval + base + chunks * SELL_C) + lane;
       if (chunks == 1) {
         const double dreg = lane < nd ? v[0] : 0.0;
-        for (; k + 4 <= width; k += 4) {
-          const uint32_t w4 = NT_LOAD(&cw[(k >> 2) * SELL_C]);
-          const int32_t c0 = NT_LOAD(&c[(k + 0) * SELL_C]), c1 = NT_LOAD(&c[(k + 1) * SELL_C]);
-          const int32_t c2 = NT_LOAD(&c[(k + 2) * SELL_C]), c3 = NT_LOAD(&c[(k + 3) * SELL_C]);
-          acc += __shfl(dreg, (int)(w4 & 255u)) * x[c0];
-          acc += __shfl(dreg, (int)((w4 >> 8) & 255u)) * x[c1];
-          acc += __shfl(dreg, (int)((w4 >> 16) & 255u)) * x[c2];
-          acc += __shfl(dreg, (int)(w4 >> 24)) * x[c3];
-        }
-        if (k < width) {
-          uint32_t w4 = NT_LOAD(&cw[(k >> 2) * SELL_C]);
-          for (; k < width; ++k, w4 >>= 8) acc += __shfl(dreg, (int)(w4 & 255u)) * x[NT_LOAD(&c[k * SELL_C])];
+        // eight entries per trip (the 7-point interior rows in one): all column and code loads are
+        // issued before the first gather; indices past the row end are clamped and their terms skipped
+        const int klast = width - 1;
+        for (; k < width; k += 8) {
+          const uint32_t wa = NT_LOAD(&cw[(k >> 2) * SELL_C]);
+          const uint32_t wb = NT_LOAD(&cw[(min(k + 4, klast) >> 2) * SELL_C]);
+          int32_t cc[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cc[j] = NT_LOAD(&c[min(k + j, klast) * SELL_C]);
+          double xs[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) xs[j] = x[cc[j]];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const uint32_t code = ((j < 4 ? wa : wb) >> (8 * (j & 3))) & 255u;
+            const double dv = __shfl(dreg, (int)code);
+            acc = k + j < width ? __builtin_fma(dv, xs[j], acc) : acc;
+          }
         }
       } else {
         double *sd = vi_dict[threadIdx.x >> 6];
@@ -342,23 +348,34 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
         for (; k < width; k += 4) {
           uint32_t w4 = NT_LOAD(&cw[(k >> 2) * SELL_C]);
           const int ke = min(k + 4, width);
-          for (int kk = k; kk < ke; ++kk, w4 >>= 8) acc += sd[w4 & 255u] * x[NT_LOAD(&c[kk * SELL_C])];
+          for (int kk = k; kk < ke; ++kk, w4 >>= 8) acc = __builtin_fma(sd[w4 & 255u], x[NT_LOAD(&c[kk * SELL_C])], acc);
         }
         k = width;
       }
     }
-    // the matrix is streamed once: non-temporal loads keep it from evicting x out of L2 / MALL
+    // raw slice.  The matrix is streamed once: non-temporal loads keep it from evicting x out of
+    // L2 / MALL; eight entries per trip so that eight gathers are in flight per lane
+    for (; k + 8 <= width; k += 8) {
+      int32_t cc[8];
+      double vv[8], xs[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { cc[j] = NT_LOAD(&c[(k + j) * SELL_C]); vv[j] = NT_LOAD(&v[(k + j) * SELL_C]); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xs[j] = x[cc[j]];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = __builtin_fma(vv[j], xs[j], acc);
+    }
     for (; k + 4 <= width; k += 4) {
       const int32_t c0 = NT_LOAD(&c[(k + 0) * SELL_C]), c1 = NT_LOAD(&c[(k + 1) * SELL_C]);
       const int32_t c2 = NT_LOAD(&c[(k + 2) * SELL_C]), c3 = NT_LOAD(&c[(k + 3) * SELL_C]);
       const double v0 = NT_LOAD(&v[(k + 0) * SELL_C]), v1 = NT_LOAD(&v[(k + 1) * SELL_C]);
       const double v2 = NT_LOAD(&v[(k + 2) * SELL_C]), v3 = NT_LOAD(&v[(k + 3) * SELL_C]);
-      acc += v0 * x[c0];
-      acc += v1 * x[c1];
-      acc += v2 * x[c2];
-      acc += v3 * x[c3];
+      acc = __builtin_fma(v0, x[c0], acc);
+      acc = __builtin_fma(v1, x[c1], acc);
+      acc = __builtin_fma(v2, x[c2], acc);
+      acc = __builtin_fma(v3, x[c3], acc);
     }
-    for (; k < width; ++k) acc += NT_LOAD(&v[k * SELL_C]) * x[NT_LOAD(&c[k * SELL_C])];
+    for (; k < width; ++k) acc = __builtin_fma(NT_LOAD(&v[k * SELL_C]), x[NT_LOAD(&c[k * SELL_C])], acc);
     row = s * SELL_C + lane;
     if (row < n) {
       if (own && !own[row]) acc = 0.0;  // ghost rows stay zero; the halo exchange refreshes them
@@ -418,14 +435,13 @@ __device__ __forceinline__ void block_atomic_sum(double v, double *out) {
   __syncthreads();
 }
 
-// value of dot product q of the running iteration
+// value of dot product q of the running iteration.  Native loop: every wavefront folds the 64 slots
+// itself -- lane k loads slot k, a fixed butterfly adds them -- so all waves of all blocks obtain the
+// same bits from one load per lane (a serial 64-term sum per thread cost ~4 us per kernel).
 __device__ __forceinline__ double dotv(const double *S, int par, int q) {
   if (S[S_MODE] != 0.0) return S[R_OFF + q];
   const double *p = S + P_OFF + ((par * 8 + q) * NSLOT) * SLOT_STRIDE;
-  double v = 0.0;
-#pragma unroll 8
-  for (int k = 0; k < NSLOT; ++k) v += p[k * SLOT_STRIDE];
-  return v;
+  return wave_sum(p[(threadIdx.x & (NSLOT - 1)) * SLOT_STRIDE]);
 }
 
 // fold the slots of quantities q0..q0+nq-1 into R; `clear` also zeroes them (one wave)
