@@ -85,6 +85,18 @@ def cpu_baseline(n, rtol):
                       f"{r1['n_active'] / dt1:.0f} DoF/s"}
 
 
+# every 8th SpMV launch of the timed region is bracketed by HIP events on the launch stream
+SPMV_EVENT_STRIDE = 8
+
+
+def event_pair_overhead_us(mesh):
+    import ctypes as C
+    from phifem_amd import _lib as L
+    sec = C.c_double(0.0)
+    L.check(L.lib.phx_event_pair_overhead(mesh._h, C.byref(sec)))
+    return 1e6 * sec.value
+
+
 def spmv_traffic(cubes):
     """HBM bytes per SpMV launch from the committed PMC passes (profiles/): collected with
     rocprofv3 --pmc in separate passes and corrected as the MI355X guide prescribes; only valid
@@ -147,7 +159,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            res = prob.step(profile_spmv=True)
+            res = prob.step(profile_spmv=SPMV_EVENT_STRIDE)
         barrier()
         dt = time.perf_counter() - t0
     if world > 1:
@@ -193,6 +205,9 @@ def main():
                 "traffic": spmv_traffic(n),
                 "bytes_per_launch": res["spmv_algorithmic_bytes"],
                 "avg_launch_us": 1e6 * spmv_s, "launches_timed": res["spmv_count"],
+                # not subtracted: what an EMPTY event pair measures on the same stream (the
+                # rocprofv3 kernel-trace average in profiles/ is lower by about this much)
+                "event_pair_overhead_us": event_pair_overhead_us(prob.mesh),
             },
         }
         if not args.no_cpu_baseline:

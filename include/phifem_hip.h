@@ -127,7 +127,7 @@ int phx_mesh_synchronize(phx_mesh *m);
  * torch.distributed collectives and the kernels order without extra synchronisation). */
 int phx_mesh_set_stream(phx_mesh *m, uint64_t stream);
 enum phx_option {
-  PHX_OPT_PROFILE_SPMV = 1, /* bracket every SpMV launch of a solve with HIP events            */
+  PHX_OPT_PROFILE_SPMV = 1, /* k > 0: bracket every k-th SpMV launch of a solve with HIP events  */
   PHX_OPT_HAS_EXTERIOR = 2, /* -1: `len(exterior_cells) == 0` (mesh_scripts.py:469) is decided
                                from this mesh's tags; 0/1: imposed by a multi-GPU driver that
                                reduced it over all slabs                                        */
@@ -138,6 +138,9 @@ enum phx_option {
                                (bit-identical products, 5 instead of 12 bytes per entry); 0: raw */
 };
 int phx_set_option(phx_mesh *m, int option, int64_t value);
+/* Mean elapsed time of an empty HIP event pair on the mesh stream: the cost the bracketing of
+ * PHX_OPT_PROFILE_SPMV adds to each timed launch (measurement aid of bench.py). */
+int phx_event_pair_overhead(phx_mesh *m, double *seconds);
 /* Tag counts of the current tagging: cells4[t] for t = 0..3, facets7[t] for t = 0..6. */
 int phx_mesh_tag_histogram(const phx_mesh *m, int64_t *cells4, int64_t *facets7);
 

@@ -57,6 +57,7 @@ SIGNATURES = {
     "phx_mesh_synchronize": ([_vp], _i),
     "phx_mesh_set_stream": ([_vp, C.c_uint64], _i),
     "phx_set_option": ([_vp, _i, _i64], _i),
+    "phx_event_pair_overhead": ([_vp, _pd], _i),
     "phx_mesh_tag_histogram": ([_vp, _pi64, _pi64], _i),
     "phx_krylov_attach": ([_vp, _vp, _vp, _vp], _i),
     "phx_krylov_phase": ([_vp, _i], _i),

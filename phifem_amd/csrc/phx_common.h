@@ -144,7 +144,7 @@ struct phx_system {
   double *kr_work = nullptr, *kr_scal = nullptr;
   const uint8_t *own = nullptr;
   std::vector<hipEvent_t> prof_ev;
-  int prof_used = 0;
+  int prof_used = 0, prof_seen = 0;
 };
 
 // helpers implemented in phx_mesh.hip

@@ -789,7 +789,10 @@ extern "C" int phx_mesh_set_stream(phx_mesh *m, uint64_t stream) {
 
 extern "C" int phx_set_option(phx_mesh *m, int option, int64_t value) {
   switch (option) {
-    case PHX_OPT_PROFILE_SPMV: m->profile_spmv = value != 0; return PHX_OK;
+    case PHX_OPT_PROFILE_SPMV:
+      PHX_REQUIRE(value >= 0 && value <= 1024, PHX_ERR_VALUE, "SpMV profiling stride out of range");
+      m->profile_spmv = (int)value;
+      return PHX_OK;
     case PHX_OPT_HAS_EXTERIOR: m->has_exterior_override = (int)value; return PHX_OK;
     case PHX_OPT_SPMV_VALUE_INDEX: m->spmv_value_index = value != 0; return PHX_OK;
     case PHX_OPT_SPMV_XCD_GROUP:

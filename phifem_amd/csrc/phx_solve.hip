@@ -608,19 +608,27 @@ static inline double *kr_scal(phx_system *s) { return s->kr_scal ? s->kr_scal : 
 
 // SpMV launches inside the solve can be bracketed by HIP events on the launch stream
 // (phx_set_option PHX_OPT_PROFILE_SPMV): the roofline figure of bench.py comes from here.
+// The option value is the sampling stride: 1 brackets every launch, k every k-th (an event pair costs
+// ~2.5 us of stream time, 4 % of a solve when every launch carries one).
+static inline bool prof_sampled(const phx_system *s) {
+  return s->mesh->profile_spmv > 0 && s->prof_used < (int)s->prof_ev.size() / 2 &&
+         s->prof_seen % s->mesh->profile_spmv == 0;
+}
 static int prof_begin(phx_system *s) {
-  if (!s->mesh->profile_spmv || s->prof_used >= (int)s->prof_ev.size() / 2) return PHX_OK;
-  PHX_HIP(hipEventRecord(s->prof_ev[2 * s->prof_used], s->mesh->stream));
+  if (prof_sampled(s)) PHX_HIP(hipEventRecord(s->prof_ev[2 * s->prof_used], s->mesh->stream));
   return PHX_OK;
 }
 static int prof_end(phx_system *s) {
-  if (!s->mesh->profile_spmv || s->prof_used >= (int)s->prof_ev.size() / 2) return PHX_OK;
-  PHX_HIP(hipEventRecord(s->prof_ev[2 * s->prof_used + 1], s->mesh->stream));
-  s->prof_used++;
+  if (prof_sampled(s)) {
+    PHX_HIP(hipEventRecord(s->prof_ev[2 * s->prof_used + 1], s->mesh->stream));
+    s->prof_used++;
+  }
+  s->prof_seen++;
   return PHX_OK;
 }
 static int prof_reset(phx_system *s) {
   s->prof_used = 0;
+  s->prof_seen = 0;
   if (s->mesh->profile_spmv && s->prof_ev.empty()) {
     s->prof_ev.resize(2 * 1024);
     for (auto &e : s->prof_ev) PHX_HIP(hipEventCreate(&e));
@@ -726,6 +734,29 @@ extern "C" int phx_krylov_attach(phx_system *s, double *work, double *scal, cons
   s->kr_work = work;
   s->kr_scal = scal;
   s->own = own;
+  return PHX_OK;
+}
+
+// Elapsed time of an EMPTY event pair on the mesh stream (mean of 32): what the bracketing itself adds
+// to every figure PHX_OPT_PROFILE_SPMV reports; bench.py prints it next to the raw average.
+extern "C" int phx_event_pair_overhead(phx_mesh *m, double *seconds) {
+  PHX_HIP(hipSetDevice(m->device));
+  const int reps = 32;
+  hipEvent_t ev[2 * reps];
+  for (auto &e : ev) PHX_HIP(hipEventCreate(&e));
+  for (int i = 0; i < reps; ++i) {
+    PHX_HIP(hipEventRecord(ev[2 * i], m->stream));
+    PHX_HIP(hipEventRecord(ev[2 * i + 1], m->stream));
+  }
+  PHX_HIP(hipEventSynchronize(ev[2 * reps - 1]));
+  double tot = 0.0;
+  for (int i = 0; i < reps; ++i) {
+    float ms = 0.f;
+    PHX_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    tot += ms;
+  }
+  for (auto &e : ev) PHX_HIP(hipEventDestroy(e));
+  *seconds = tot * 1e-3 / reps;
   return PHX_OK;
 }
 

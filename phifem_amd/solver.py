@@ -106,7 +106,7 @@ class PhiFEMSolver:
             out = np.empty(nfull, dtype=np.float64)
         p, loc = L.ptr(out)
         st = (C.c_double * 6)()
-        L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_PROFILE_SPMV, 1 if profile_spmv else 0))
+        L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_PROFILE_SPMV, int(profile_spmv)))
         L.check(L.lib.phx_solve(self._sys, 0, float(rtol), int(max_iter), p, loc, st))
         self.stats = {"iterations": int(st[0]), "relres": st[1], "seconds": st[2],
                       "spmv": int(st[3]), "spmv_avg_s": st[4], "spmv_timed": int(st[5])}

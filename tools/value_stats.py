@@ -54,3 +54,29 @@ for blk in (64,):
     bad = np.zeros(b.max() + 1, dtype=bool)
     bad[b[far]] = True
     print("slices with every delta in int16:", 1.0 - bad.mean())
+
+# column compressibility per slice: col = base[k] + lane + delta, delta in int8 / int16
+lens2 = np.bincount(r2, minlength=nr)
+o = np.lexsort((c2, r2))            # entries by (row, col); SELL keeps CSR (column-sorted) order per row
+r3, c3 = r2[o], c2[o]
+start = np.zeros(nr + 1, dtype=np.int64)
+np.cumsum(lens2, out=start[1:])
+kpos = np.arange(r3.size) - start[r3]
+sl = r3 // 64
+lane = r3 % 64
+key = sl * 64 + kpos                # (slice, k) group (k < 64 in 3-D P1)
+assert kpos.max() < 64
+d = c3 - lane
+gmin = np.full(key.max() + 1, np.iinfo(np.int64).max)
+gmax = np.full(key.max() + 1, np.iinfo(np.int64).min)
+np.minimum.at(gmin, key, d)
+np.maximum.at(gmax, key, d)
+rng = (gmax - gmin)[key]            # range of the group each entry belongs to
+nsl = sl.max() + 1
+worst = np.zeros(nsl, dtype=np.int64)
+np.maximum.at(worst, sl, rng)
+ent = np.bincount(sl, minlength=nsl)
+for name, lim in (("int8", 255), ("int16", 65535)):
+    okm = worst <= lim
+    print(f"slices whose every (slice,k) column group spans <= {lim}: {okm.mean():.3f} of slices, "
+          f"{ent[okm].sum() / ent.sum():.3f} of entries")
