@@ -289,9 +289,12 @@ k_assemble_rows(int64_t nv, const int64_t *__restrict__ v2c_ptr, const int32_t *
 // (k_box_cells), so vertex V is path vertex m of simplex t of the cube at V - e_p0 - ... - e_p(m-1):
 // 24 tetrahedra / 6 triangles and 14 / 6 neighbours at fixed lattice offsets.  With every loop
 // unrolled the accumulators are registers addressed at compile time: no v2c list, no connectivity
-// loads, no LDS hash, and every interior row runs the very same arithmetic (which is what lets
-// k_sell_index fold the interior values into a dictionary).
-struct BoxDims { int64_t n[3]; };
+// loads, no LDS hash.  The simplices are built from the lattice spacing h_a = (hi_a - lo_a) / n_a, not from
+// differences of the stored (rounded) coordinates: a box IS uniform, and with translation-invariant
+// geometry every interior row runs the very same arithmetic on the very same numbers for ANY n, which
+// is what lets k_sell_index fold the interior values into a dictionary (entries differ from a
+// coordinate-based evaluation by a few ulp).
+struct BoxDims { int64_t n[3]; double h[3]; };
 
 template <int D>
 __global__ void __launch_bounds__(256)
@@ -309,8 +312,8 @@ k_assemble_rows_box(int64_t nv, BoxDims bd, AsmArgs A) {
   int64_t idx[3] = {vtx % n0, D == 3 ? (vtx / n0) % n1 : vtx / n0, D == 3 ? vtx / (n0 * n1) : 0};
   const int64_t vstride[3] = {1, n0, n0 * n1};
   const int64_t cstride[3] = {1, bd.n[0], bd.n[0] * bd.n[1]};
-  // neighbour coordinates and source values, once (offset code = sum (d_a + 1) 3^a)
-  double nx[NCODE][D], nf[NCODE], acc[NCODE];
+  // neighbour source values, once (offset code = sum (d_a + 1) 3^a)
+  double nf[NCODE], acc[NCODE];
   bool seen[NCODE];
 #pragma unroll
   for (int code = 0; code < NCODE; ++code) {
@@ -321,7 +324,6 @@ k_assemble_rows_box(int64_t nv, BoxDims bd, AsmArgs A) {
     acc[code] = 0.0;
     seen[code] = false;
     nf[code] = 0.0;
-    for (int a = 0; a < D; ++a) nx[code][a] = 0.0;
     if (pos && neg) continue;
     bool in = true;
     int64_t w = vtx;
@@ -331,7 +333,6 @@ k_assemble_rows_box(int64_t nv, BoxDims bd, AsmArgs A) {
       w += d[a] * vstride[a];
     }
     if (!in) continue;
-    for (int a = 0; a < D; ++a) nx[code][a] = A.x[w * D + a];
     nf[code] = A.f[w];
   }
   constexpr int SELF = D == 3 ? 13 : 4;
@@ -358,7 +359,7 @@ k_assemble_rows_box(int64_t nv, BoxDims bd, AsmArgs A) {
       for (int q = 0; q < N; ++q) {
         code[q] = 0;
         for (int a = 0; a < D; ++a) code[q] += (dd[a] + 1) * POW3[a];
-        for (int a = 0; a < D; ++a) X[q][a] = nx[code[q]][a];
+        for (int a = 0; a < D; ++a) X[q][a] = (double)dd[a] * bd.h[a];
         sf += nf[code[q]];
         if (q < D) dd[D == 3 ? P[t][q] : P2[t][q]] += 1;
       }
@@ -767,7 +768,7 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac));
   {
     if (m->is_box) {
-      const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}};
+      const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}, {m->box_h[0], m->box_h[1], m->box_h[2]}};
       const dim3 g((unsigned)phx_div_up(m->nv, 256));
       if (D == 2) k_assemble_rows_box<2><<<g, block, 0, m->stream>>>(m->nv, bd, A);
       else k_assemble_rows_box<3><<<g, block, 0, m->stream>>>(m->nv, bd, A);

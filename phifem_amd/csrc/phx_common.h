@@ -86,6 +86,7 @@ struct phx_mesh {
   int32_t *edges = nullptr;  // [ne*2] vertex pairs, ascending
   bool c2e_is_alias = false;
   int64_t box_n[3] = {0, 0, 0};
+  double box_h[3] = {0.0, 0.0, 0.0};  // exact lattice spacing (hi - lo) / n_global per axis
   int64_t *v2c_ptr = nullptr;  // [nv+1]
   int32_t *v2c_idx = nullptr;  // [nc*nvpc]
   bool is_box = false;

@@ -291,10 +291,9 @@ def test_value_indexed_slices_are_bit_identical(P, d, n):
     L.check(L.lib.phx_set_option(work._h, L.OPT_SPMV_VALUE_INDEX, 1))
     print(d, n, {k: infos[0][k] for k in ("n_slices", "indexed_slices", "indexed_slices_lds")})
     assert infos[1]["indexed_slices"] == 0
-    if (3 * 2 ** 20) % n == 0:
-        # cell size exactly representable: interior rows repeat bit for bit
-        assert infos[0]["indexed_slices"] > 0
-        assert infos[0]["spmv_matrix_bytes"] < infos[1]["spmv_matrix_bytes"]
+    # box rows are built from the exact lattice spacing: interior rows repeat bit for bit for any n
+    assert infos[0]["indexed_slices"] > 0
+    assert infos[0]["spmv_matrix_bytes"] < infos[1]["spmv_matrix_bytes"]
     M0, M1 = mats
     assert np.array_equal(M0.indptr, M1.indptr) and np.array_equal(M0.indices, M1.indices)
     differs = np.add.reduceat((M0.data != M1.data).astype(np.int64), M0.indptr[:-1]) > 0
