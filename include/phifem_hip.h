@@ -133,11 +133,19 @@ enum phx_option {
                                reduced it over all slabs                                        */
   PHX_OPT_SPMV_XCD_GROUP = 3, /* G > 0: SpMV blocks are regrouped so that each XCD (blockIdx % 8)
                                walks runs of G consecutive blocks; 0: plain order (default)      */
+  PHX_OPT_PRECOND = 5, /* 1 (default): P1 Poisson systems on 3-D Kuhn boxes are preconditioned with the
+                               lattice Laplacian of a box around the active vertices, inverted by sine
+                               transforms (u block; p block: Jacobi); 0: Jacobi everywhere            */
   PHX_OPT_SPMV_VALUE_INDEX = 4 /* 1 (default): systems assembled from now on store SELL slices whose
                                values take <= 64 distinct doubles as dictionary + byte codes
                                (bit-identical products, 5 instead of 12 bytes per entry); 0: raw */
 };
 int phx_set_option(phx_mesh *m, int option, int64_t value);
+/* Direct solve of the 7-point lattice Laplacian K = sum_a (h_b h_c / h_a) tridiag(-1, 2, -1)_a with
+ * homogeneous Dirichlet faces on an (L0-1) x (L1-1) x (L2-1) interior lattice (x fastest), by type-I sine
+ * transforms on the device; L_a in {64, 96, 128, 192, 256, 384, 512, 768, 1024}.  u overwrites f (host).
+ * This is the kernel sequence of the fictitious-domain preconditioner (PHX_OPT_PRECOND), exposed for tests. */
+int phx_box_poisson_solve(int device, const int *L, const double *h, double *f_host);
 /* Mean elapsed time of an empty HIP event pair on the mesh stream: the cost the bracketing of
  * PHX_OPT_PROFILE_SPMV adds to each timed launch (measurement aid of bench.py). */
 int phx_event_pair_overhead(phx_mesh *m, double *seconds);
@@ -225,13 +233,18 @@ int phx_solve(phx_system *s, int method, double rtol, int64_t max_iter, double *
               double *stats);
 
 /* --- pieces of the solve for externally driven (multi-GPU) iterations ------------------------
- * The driver owns the loop, does the halo exchange of p / s before phases 2 / 4 and all-reduces
- * the 8 reduction scalars (scal[8..15]) after phases 0, 2, 4 and 5.  Vectors are in SOLVER order
- * (row i of the solver = active row perm[i]).
- *   work: 8 vectors of n doubles {r, rhat, p, v, s, t, y, b};  scal: 8208 doubles (16 scalars + 2 x 8 x 64 dot-product slots of 64 B)
- *   own : n bytes in solver order, 1 = this rank owns the row (NULL = all)                     */
+ * The driver owns the loop, does the halo exchange of the SpMV inputs before phases 2 / 4 and
+ * all-reduces the 8 reduction scalars (scal[8..15]) after phases 0, 2, 4 and 5.  Vectors are in SOLVER
+ * order (row i of the solver = active row perm[i]).
+ *   work: 10 vectors of n doubles {r, rhat, p, v, s, t, y, b, phat, shat};  scal: 8208 doubles (16
+ *         scalars + 2 x 8 x 64 dot-product slots of 64 B)
+ *   own : n bytes in solver order, 1 = this rank owns the row (NULL = all)
+ * SpMV inputs: p / s, or -- when phx_krylov_precond_active says 1 after phase 0 -- phat / shat, which
+ * phases 7 / 8 compute from p / s (rank-local block preconditioner on the owned rows). */
 int phx_krylov_attach(phx_system *s, double *work, double *scal, const uint8_t *own);
-/* phase 0 begin, 1 begin2, 2 v=Ap, 3 s-update, 4 t=As, 5 x/r-update, 6 p-update + roll */
+int phx_krylov_precond_active(const phx_system *s, int *active);
+/* phase 0 begin, 1 begin2, 2 v=A phat, 3 s-update, 4 t=A shat, 5 x/r-update, 6 p-update + roll,
+ * 7 phat = P p, 8 shat = P s (no-ops without a preconditioner) */
 int phx_krylov_phase(phx_system *s, int phase);
 int phx_krylov_finish(phx_system *s, double *x, int loc);
 /* reset != 0: arm the SpMV event profile; else collect {average seconds, launches timed}. */

@@ -650,6 +650,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
                   s->val, s->rhs, s->diag, s->slice_ptr, s->sell_col, s->sell_val,
                   s->sell_val_raw, s->sell_kind, s->perm, s->iperm, s->work, s->scal};
   for (void *p : ptrs) (void)phx_free(p);
+  phx_box_precond_destroy(s->precond);
   if (s->scal_h) (void)hipHostFree(s->scal_h);
   for (auto &e : s->prof_ev) (void)hipEventDestroy(e);
   delete s;
@@ -718,6 +719,7 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   s->nent = m->nv;
   s->nfull = 2 * m->nv;
   s->slot_cap = W;
+  s->u_vertex_block = true;
   const int D = m->gdim;
   const dim3 block(256);
   // ---- active numbering

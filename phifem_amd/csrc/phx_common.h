@@ -108,6 +108,7 @@ struct phx_mesh {
   int profile_spmv = 0;
   int spmv_xcd_group = 0;          // PHX_OPT_SPMV_XCD_GROUP
   int spmv_value_index = 1;        // PHX_OPT_SPMV_VALUE_INDEX
+  int precond = 1;                 // PHX_OPT_PRECOND: 0 Jacobi, 1 box sine-transform where applicable
   int has_exterior_override = -1;  // -1: decide from the local tags; 0/1: imposed (multi-GPU)
 };
 
@@ -144,6 +145,10 @@ struct phx_system {
   // externally attached Krylov buffers (multi-GPU driver) and ownership mask (solver order)
   double *kr_work = nullptr, *kr_scal = nullptr;
   const uint8_t *own = nullptr;
+  // fictitious-domain preconditioner (phx_precond.inc.hip): built on demand for P1 Poisson systems on 3-D boxes
+  bool u_vertex_block = false;     // rows [0, nu) are one scalar u DoF per active vertex
+  struct phx_box_precond *precond = nullptr;
+  int precond_state = 0;           // 0 not tried, 1 built, -1 not applicable
   std::vector<hipEvent_t> prof_ev;
   int prof_used = 0, prof_seen = 0;
 };
@@ -153,3 +158,6 @@ int phx_mesh_alloc_common(phx_mesh *m);
 int phx_begin_timing(phx_mesh *m);
 int phx_end_timing(phx_mesh *m, int slot);
 int phx_mesh_build_edges(phx_mesh *m);
+
+struct phx_box_precond;
+void phx_box_precond_destroy(phx_box_precond *bp);  // phx_solve.hip

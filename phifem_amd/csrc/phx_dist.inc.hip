@@ -158,7 +158,6 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     PHX_HIP(phx_malloc(&H.sbuf[p], sizeof(double) * (size_t)(H.nsend[p] > 0 ? H.nsend[p] : 1)));
     PHX_HIP(phx_malloc(&H.rbuf[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)));
   }
-  const KrVecs V = kr_vecs(s);
   double *S = kr_scal(s);
   const int check_every = 8;
   int rc = PHX_OK;
@@ -168,17 +167,20 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     PHX_CHECK(phx_krylov_phase(s, 0));
     PHX_CHECK(allreduce_R(s, c, R_RHO, R_RHO + 1));
     PHX_CHECK(phx_krylov_phase(s, 1));
+    const KrVecs V = kr_vecs(s);  // after phase 0: the preconditioner decides where phat / shat live
     PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
     PHX_HIP(hipStreamSynchronize(st));
     const double bb = s->scal_h[S_BB];
     int64_t it = 0;
     double relres = bb == 0.0 ? 0.0 : 1.0;
     while (bb != 0.0 && it < max_iter) {
-      PHX_CHECK(halo_exchange(s, c, H, V.p));
+      PHX_CHECK(phx_krylov_phase(s, 7));
+      PHX_CHECK(halo_exchange(s, c, H, V.phat));
       PHX_CHECK(phx_krylov_phase(s, 2));
       PHX_CHECK(allreduce_R(s, c, R_RV, R_RV + 1));
       PHX_CHECK(phx_krylov_phase(s, 3));
-      PHX_CHECK(halo_exchange(s, c, H, V.sv));
+      PHX_CHECK(phx_krylov_phase(s, 8));
+      PHX_CHECK(halo_exchange(s, c, H, V.shat));
       PHX_CHECK(phx_krylov_phase(s, 4));
       PHX_CHECK(allreduce_R(s, c, R_TS, R_TT + 1));
       PHX_CHECK(phx_krylov_phase(s, 5));

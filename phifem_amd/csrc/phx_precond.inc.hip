@@ -1,0 +1,552 @@
+// Fictitious-domain preconditioner for systems assembled on a Kuhn box (included by phx_solve.hip).
+//
+// The u-u block of the phi-FEM matrix is, away from Gamma_h, the P1 stiffness matrix of the uniform
+// lattice = the 7-point finite-difference Laplacian  K = cx T_x + cy T_y + cz T_z,  T = tridiag(-1,2,-1),
+// c_a = h_b h_c / h_a.  M^-1 = R K_box^-1 R^T (R: restriction of a lattice box around the active vertices
+// to the active u DoFs; homogeneous Dirichlet on the box faces) makes the Krylov iteration count
+// independent of h (CPU prototype, sphere: 43/49/50/51/49 iterations for n = 16..64 against
+// 78/121/164/194/230 with Jacobi); the p block keeps Jacobi.  K_box is diagonalised by the type-I
+// discrete sine transform in every axis:  u = S_x S_y S_z diag(1/lambda) S_z S_y S_x r.
+//
+// DST-I of two real lines at a time: z = a + i b, odd extension to length N2 = 2 L, one complex FFT in
+// LDS (Stockham autosort, radices 8/4/3/2, twiddles from a table):  S_a[k] = -Im Z_k / 2,
+// S_b[k] = Re Z_k / 2.  x lines are contiguous; y and z lines are walked as tiles of W adjacent columns so
+// that every global access is a contiguous run of W doubles.  Five passes over the grid per application:
+// x (gather from the Krylov vector), y, z (forward + 1/lambda + inverse fused in LDS), y, x (scatter).
+#include <limits.h>
+#include <math.h>
+
+#include <map>
+
+struct DstPlan {
+  int N2 = 0, L = 0, nstage = 0, pairs = 0, tp = 0;  // pairs per block, threads per pair (N2 / 8)
+  int radix[8], pw[8], tws[8];  // per stage: radix R, sub-transform size p so far (a power of two), N2 / (p R)
+  double2 *tw = nullptr;        // device, exp(-2 pi i j / N2), j < N2
+};
+
+static std::map<std::pair<int, int>, DstPlan> g_dst_plans;  // (device, L) -> plan
+
+// L = 2^a 3^b, b <= 1, 64 <= L <= 1024
+static int dst_pick_length(int64_t need) {
+  const int cand[] = {64, 96, 128, 192, 256, 384, 512, 768, 1024};
+  for (int c : cand)
+    if (c >= need) return c;
+  return -1;
+}
+
+static int dst_get_plan(int device, int L, DstPlan *out) {
+  auto key = std::make_pair(device, L);
+  auto it = g_dst_plans.find(key);
+  if (it != g_dst_plans.end()) { *out = it->second; return PHX_OK; }
+  DstPlan P;
+  P.L = L;
+  P.N2 = 2 * L;
+  int rest = P.N2;
+  P.nstage = 0;
+  // radix 3 (if any) goes LAST so that every stage's p is a power of two (k = i & (p - 1))
+  const bool three = rest % 3 == 0;
+  if (three) rest /= 3;
+  while (rest % 8 == 0) { P.radix[P.nstage++] = 8; rest /= 8; }
+  if (rest % 4 == 0) { P.radix[P.nstage++] = 4; rest /= 4; }
+  if (rest % 2 == 0) { P.radix[P.nstage++] = 2; rest /= 2; }
+  PHX_REQUIRE(rest == 1, PHX_ERR_VALUE, "unsupported transform length %d", L);
+  if (three) P.radix[P.nstage++] = 3;
+  for (int st = 0, pp = 1; st < P.nstage; ++st) {
+    P.pw[st] = pp;
+    P.tws[st] = P.N2 / (pp * P.radix[st]);
+    pp *= P.radix[st];
+  }
+  P.tp = P.N2 / 8;
+  P.pairs = std::max(1, 4096 / P.N2);          // 64 KB of LDS: 4096 complex doubles
+  while (P.pairs * P.tp > 512) --P.pairs;      // and at most 512 threads
+  std::vector<double2> tw((size_t)P.N2);
+  for (int j = 0; j < P.N2; ++j) {
+    const long double a = -2.0L * 3.141592653589793238462643383279502884L * (long double)j / (long double)P.N2;
+    tw[j] = make_double2((double)cosl(a), (double)sinl(a));
+  }
+  PHX_HIP(hipMalloc(&P.tw, sizeof(double2) * tw.size()));  // lives as long as the process (a few KB per length)
+  PHX_HIP(hipMemcpy(P.tw, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice));
+  g_dst_plans[key] = P;
+  *out = P;
+  return PHX_OK;
+}
+
+// LDS index padding: one extra 16-byte element after every 8, so that the stride-8 / stride-64 write
+// patterns of the first Stockham stages spread over the banks (unpadded: up to 32-way conflicts)
+#define ZP(n) ((n) + ((n) >> 3))
+#define ZLEN(N2) ((N2) + ((N2) >> 3))
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }  // a * (-i)
+
+template <int R> __device__ __forceinline__ void dft_r(double2 *v);
+template <> __device__ __forceinline__ void dft_r<2>(double2 *v) {
+  const double2 a = v[0], b = v[1];
+  v[0] = cadd(a, b); v[1] = csub(a, b);
+}
+template <> __device__ __forceinline__ void dft_r<3>(double2 *v) {
+  const double s = 0.86602540378443864676;  // sin(2 pi / 3)
+  const double2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+  const double2 m = make_double2(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y);
+  const double2 r = make_double2(s * d.y, -s * d.x);  // -i s d
+  v[0] = cadd(v[0], t); v[1] = cadd(m, r); v[2] = csub(m, r);
+}
+template <> __device__ __forceinline__ void dft_r<4>(double2 *v) {
+  const double2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+  const double2 t2 = cadd(v[1], v[3]), t3 = mul_mi(csub(v[1], v[3]));
+  v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
+}
+template <> __device__ __forceinline__ void dft_r<8>(double2 *v) {
+  double2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+  dft_r<4>(e); dft_r<4>(o);
+  const double h = 0.70710678118654752440;
+  o[1] = make_double2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));    // * (1 - i)/sqrt2
+  o[2] = mul_mi(o[2]);
+  o[3] = make_double2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));   // * (-1 - i)/sqrt2
+  for (int k = 0; k < 4; ++k) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
+}
+
+// one Stockham stage of radix R on the N2-point sequence `z` of this pair: `t` = thread within the pair.
+// All inputs are read into registers, the block synchronises, then the outputs are written in place.
+template <int R>
+__device__ __forceinline__ void fft_stage(double2 *z, int nb, int tp, int t, int p, int tws,
+                                          const double2 *__restrict__ tw) {
+  constexpr int MAXB = (8 + R - 1) / R;
+  double2 u[MAXB][R];
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int i = t + b * tp;
+    if (i < nb) {
+      const int k = i & (p - 1);
+      const int step = tws * k;  // twiddle exponent of q = 1; q * step < N2 for q < R
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        double2 w = z[ZP(i + q * nb)];
+        if (q > 0 && k > 0) w = cmul(w, tw[q * step]);
+        u[b][q] = w;
+      }
+      dft_r<R>(u[b]);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int i = t + b * tp;
+    if (i < nb) {
+      const int k = i & (p - 1);
+      const int j = (i - k) * R + k;
+#pragma unroll
+      for (int q = 0; q < R; ++q) z[ZP(j + q * p)] = u[b][q];
+    }
+  }
+  __syncthreads();
+}
+
+// forward complex FFT of this pair's sequence `z` in LDS.  Every thread of the block must call it (block
+// barriers inside); threads of an idle pair slot pass live = false and do no work.
+__device__ __forceinline__ void fft_pairs(double2 *z, const DstPlan &P, int t, bool live) {
+  const int tt = live ? t : P.N2;  // empty butterfly range
+  for (int s = 0; s < P.nstage; ++s) {
+    const int R = P.radix[s], p = P.pw[s], tws = P.tws[s];
+    if (R == 8) fft_stage<8>(z, P.N2 >> 3, P.tp, tt, p, tws, P.tw);
+    else if (R == 4) fft_stage<4>(z, P.N2 >> 2, P.tp, tt, p, tws, P.tw);
+    else if (R == 3) fft_stage<3>(z, tws * p, P.tp, tt, p, tws, P.tw);  // N2 / 3 butterflies
+    else fft_stage<2>(z, P.N2 >> 1, P.tp, tt, p, tws, P.tw);
+  }
+}
+
+struct BoxGrid {
+  int m[3];          // stored interior points per axis (= L - 1)
+  int L[3];          // transform lengths
+  int64_t pitch, plane;
+  double scale;      // (2/Lx)(2/Ly)(2/Lz): the three inverse transforms
+  const double *lam[3];  // c_a (2 - 2 cos(pi k / L_a)), k = 0 .. L_a - 1 (device)
+};
+
+// LDS layout of a pair: z[0..N2), z[j] = (a_j, b_j) for j = 1..L-1, z[0] = z[L] = 0, z[N2-j] = -z[j]
+__device__ __forceinline__ void put_odd(double2 *z, int N2, int j, double a, double b) {
+  z[ZP(j)] = make_double2(a, b);
+  z[ZP(N2 - j)] = make_double2(-a, -b);
+}
+
+// ---- x lines (contiguous): pair = two consecutive lines of the flattened (y, z) index.
+// IO = 1: the input is gathered from the Krylov vector through gmap (solver position of the u DoF at the
+// lattice point, -1: none); IO = 2: the result is scattered out the same way, times dscale.
+template <int IO>
+__global__ void __launch_bounds__(512)
+k_dst_x(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict__ gmap,
+        const double *__restrict__ vin, double *__restrict__ vout, const double *__restrict__ dscale) {
+  extern __shared__ double2 zs[];
+  const int pr = threadIdx.x / P.tp, t = threadIdx.x % P.tp;
+  const int64_t nlines = (int64_t)g.m[1] * g.m[2];
+  const int64_t line0 = ((int64_t)blockIdx.x * P.pairs + pr) * 2;
+  const bool live = line0 < nlines;
+  double2 *z = zs + (size_t)pr * ZLEN(P.N2);
+  const int mx = g.m[0], L = P.L, N2 = P.N2;
+  int64_t base[2] = {0, 0};
+  bool has[2] = {false, false};
+  if (live) {
+    for (int c = 0; c < 2; ++c) {
+      const int64_t l = line0 + c;
+      has[c] = l < nlines;
+      base[c] = has[c] ? (l % g.m[1]) * g.pitch + (l / g.m[1]) * g.plane : 0;
+    }
+    // j = t + 4 i tp / 4 ... : L / tp = 4 trips; all loads are issued before the first LDS write
+    double va[4], vb[4];
+    if (IO == 1) {
+      int32_t qa[4], qb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = t + i * P.tp;
+        const bool in = j >= 1 && j <= mx;
+        qa[i] = in && has[0] ? gmap[base[0] + j - 1] : -1;
+        qb[i] = in && has[1] ? gmap[base[1] + j - 1] : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        va[i] = qa[i] >= 0 ? vin[qa[i]] : 0.0;
+        vb[i] = qb[i] >= 0 ? vin[qb[i]] : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = t + i * P.tp;
+        const bool in = j >= 1 && j <= mx;
+        va[i] = in && has[0] ? G[base[0] + j - 1] : 0.0;
+        vb[i] = in && has[1] ? G[base[1] + j - 1] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = t + i * P.tp;
+      if (j == 0) { z[0] = make_double2(0.0, 0.0); z[ZP(L)] = make_double2(0.0, 0.0); }
+      else if (j < L) put_odd(z, N2, j, va[i], vb[i]);
+    }
+  }
+  __syncthreads();
+  fft_pairs(z, P, t, live);
+  if (!live) return;
+  for (int k = t + 1; k <= mx; k += P.tp) {
+    const double2 Z = z[ZP(k)];
+    const double sa = -0.5 * Z.y, sb = 0.5 * Z.x;
+    if (IO == 2) {
+      if (has[0]) { const int32_t q = gmap[base[0] + k - 1]; if (q >= 0) vout[q] = sa * dscale[q]; }
+      if (has[1]) { const int32_t q = gmap[base[1] + k - 1]; if (q >= 0) vout[q] = sb * dscale[q]; }
+    } else {
+      if (has[0]) G[base[0] + k - 1] = sa;
+      if (has[1]) G[base[1] + k - 1] = sb;
+    }
+  }
+}
+
+// ---- y / z lines (strided): a block takes W = 2 * pairs adjacent x columns of one `outer` index, so every
+// global access is a run of W consecutive doubles.  AXIS = 1: lines along y (outer = z), AXIS = 2: lines
+// along z (outer = y).  SOLVE (z only): forward transform, times scale / lambda, inverse transform, all in LDS.
+template <int AXIS, bool SOLVE>
+__global__ void __launch_bounds__(512)
+k_dst_s(BoxGrid g, DstPlan P, double *__restrict__ G) {
+  extern __shared__ double2 zs[];
+  const int pr = threadIdx.x / P.tp, t = threadIdx.x % P.tp;
+  const int W = 2 * P.pairs, L = P.L, N2 = P.N2;
+  const int mx = g.m[0];
+  const int ncb = (mx + W - 1) / W;                 // column blocks
+  const int col0 = (int)(blockIdx.x % ncb) * W;
+  const int64_t outer = blockIdx.x / ncb;
+  const int len = g.m[AXIS];
+  const int64_t estride = AXIS == 1 ? g.pitch : g.plane;
+  const int64_t base = col0 + outer * (AXIS == 1 ? g.plane : g.pitch);
+  const int ncols = min(W, mx - col0);
+  const bool live = 2 * pr < ncols;
+  double2 *z = zs + (size_t)pr * ZLEN(N2);
+  // cooperative tile load: thread -> fixed column, rows row0, row0 + rstep, ...  (blockDim = W * tp / 2)
+  const int tcol = threadIdx.x % W, row0 = threadIdx.x / W, rstep = blockDim.x / W;
+  double *zcol = reinterpret_cast<double *>(zs + (size_t)(tcol >> 1) * ZLEN(N2)) + (tcol & 1);
+  {
+    // (L - 1) / rstep <= 8 trips (rstep = L / 8): all loads in flight before the first LDS write
+    double vv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = row0 + i * rstep;
+      vv[i] = (row < len && tcol < ncols) ? G[base + row * estride + tcol] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = row0 + i * rstep;
+      if (row < L - 1) {
+        zcol[2 * ZP(row + 1)] = vv[i];
+        zcol[2 * ZP(N2 - row - 1)] = -vv[i];
+      }
+    }
+  }
+  if (t == 0) { z[0] = make_double2(0.0, 0.0); z[ZP(L)] = make_double2(0.0, 0.0); }
+  __syncthreads();
+  fft_pairs(z, P, t, live);
+  if (SOLVE) {
+    if (live) {
+      const double *lx = g.lam[0], *ly = g.lam[1], *lz = g.lam[2];
+      const int kx = col0 + 2 * pr + 1;
+      const double lxy0 = lx[kx] + ly[outer + 1];
+      const double lxy1 = (kx + 1 < g.L[0] ? lx[kx + 1] : lx[kx]) + ly[outer + 1];
+      for (int k = t + 1; k < L; k += P.tp) {
+        const double2 Z = z[ZP(k)];
+        const double lzk = lz[k];
+        put_odd(z, N2, k, -0.5 * Z.y * g.scale / (lxy0 + lzk), 0.5 * Z.x * g.scale / (lxy1 + lzk));
+      }
+      if (t == 0) { z[0] = make_double2(0.0, 0.0); z[ZP(L)] = make_double2(0.0, 0.0); }
+    }
+    __syncthreads();
+    fft_pairs(z, P, t, live);
+  }
+  // extract (results sit at z[k], k = 1..L-1) and store the tile
+  if (tcol < ncols) {
+    const double2 *zc = zs + (size_t)(tcol >> 1) * ZLEN(N2);
+    for (int row = row0; row < len; row += rstep) {
+      const double2 Z = zc[ZP(row + 1)];
+      G[base + row * estride + tcol] = (tcol & 1) ? 0.5 * Z.x : -0.5 * Z.y;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+struct phx_box_precond {
+  BoxGrid g;
+  DstPlan plan[3];
+  double *G = nullptr;
+  int32_t *gmap = nullptr;   // [plane * m2] solver position of the u DoF, -1 none
+  double *dscale = nullptr;  // [n] diag of A in solver order
+  double *vec = nullptr;     // [2 n] preconditioned directions of the library-owned workspace
+  const uint8_t *own_ptr = nullptr;  // ownership mask the maps were built for
+  double *lam[3] = {nullptr, nullptr, nullptr};
+  int lo[3] = {0, 0, 0};     // lattice index of the lower Dirichlet face
+};
+
+static void box_precond_free(phx_box_precond *bp) {
+  if (!bp) return;
+  (void)phx_free(bp->G); (void)phx_free(bp->gmap); (void)phx_free(bp->dscale); (void)phx_free(bp->vec);
+  for (int a = 0; a < 3; ++a) (void)phx_free(bp->lam[a]);
+  delete bp;
+}
+
+static int dst_allow_lds() {
+  static bool done = false;
+  if (done) return PHX_OK;
+  const int bytes = 80 * 1024;  // 4096 padded complex doubles = 72 KB, above the 64 KB default
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<0>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done = true;
+  return PHX_OK;
+}
+
+static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const double h[3]) {
+  PHX_CHECK(dst_allow_lds());
+  BoxGrid &g = bp->g;
+  for (int a = 0; a < 3; ++a) {
+    g.L[a] = L[a];
+    g.m[a] = L[a] - 1;
+    PHX_CHECK(dst_get_plan(device, L[a], &bp->plan[a]));
+  }
+  g.pitch = L[0];
+  g.plane = g.pitch * g.m[1];
+  g.scale = (2.0 / L[0]) * (2.0 / L[1]) * (2.0 / L[2]);
+  const double c[3] = {h[1] * h[2] / h[0], h[0] * h[2] / h[1], h[0] * h[1] / h[2]};
+  for (int a = 0; a < 3; ++a) {
+    std::vector<double> lam((size_t)L[a]);
+    for (int k = 0; k < L[a]; ++k)
+      lam[k] = c[a] * (2.0 - 2.0 * cos(3.14159265358979323846 * (double)k / (double)L[a]));
+    PHX_HIP(phx_malloc(&bp->lam[a], sizeof(double) * (size_t)L[a]));
+    PHX_HIP(hipMemcpy(bp->lam[a], lam.data(), sizeof(double) * (size_t)L[a], hipMemcpyHostToDevice));
+    g.lam[a] = bp->lam[a];
+  }
+  PHX_HIP(phx_malloc(&bp->G, sizeof(double) * (size_t)(g.plane * g.m[2])));
+  return PHX_OK;
+}
+
+// the three middle passes (y, z with the spectral solve, y) on G
+static int box_solve_middle(phx_box_precond *bp, hipStream_t st) {
+  const BoxGrid &g = bp->g;
+  const DstPlan &py = bp->plan[1], &pz = bp->plan[2];
+  {
+    const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
+    const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.tp));
+    const size_t lds = sizeof(double2) * (size_t)py.pairs * ZLEN(py.N2);
+    k_dst_s<1, false><<<grid, block, lds, st>>>(g, py, bp->G);
+  }
+  {
+    const int W = 2 * pz.pairs, ncb = (g.m[0] + W - 1) / W;
+    const dim3 grid((unsigned)((int64_t)ncb * g.m[1])), block((unsigned)(pz.pairs * pz.tp));
+    const size_t lds = sizeof(double2) * (size_t)pz.pairs * ZLEN(pz.N2);
+    k_dst_s<2, true><<<grid, block, lds, st>>>(g, pz, bp->G);
+  }
+  {
+    const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
+    const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.tp));
+    const size_t lds = sizeof(double2) * (size_t)py.pairs * ZLEN(py.N2);
+    k_dst_s<1, false><<<grid, block, lds, st>>>(g, py, bp->G);
+  }
+  PHX_HIP(hipGetLastError());
+  return PHX_OK;
+}
+
+template <int IO>
+static int box_pass_x(phx_box_precond *bp, hipStream_t st, const double *vin, double *vout) {
+  const BoxGrid &g = bp->g;
+  const DstPlan &px = bp->plan[0];
+  const int64_t npairs = ((int64_t)g.m[1] * g.m[2] + 1) / 2;
+  const dim3 grid((unsigned)phx_div_up(npairs, px.pairs)), block((unsigned)(px.pairs * px.tp));
+  const size_t lds = sizeof(double2) * (size_t)px.pairs * ZLEN(px.N2);
+  k_dst_x<IO><<<grid, block, lds, st>>>(g, px, bp->G, bp->gmap, vin, vout, bp->dscale);
+  PHX_HIP(hipGetLastError());
+  return PHX_OK;
+}
+
+void phx_box_precond_destroy(phx_box_precond *bp) { box_precond_free(bp); }
+
+// lattice bounding box of the (owned) active u vertices: out[0..2] = min, out[3..5] = max.
+// Grid-stride with private bounds, then one atomic per block and axis (same-address atomics from every
+// wavefront serialise: the z maximum improves with almost every wave in index order, 3.7 ms at 256^3).
+__global__ void __launch_bounds__(256)
+k_active_bbox(int64_t nv, int64_t n0, int64_t n1, const int32_t *__restrict__ du,
+              const int32_t *__restrict__ iperm, const uint8_t *__restrict__ own, int *__restrict__ out) {
+  __shared__ int red[6][4];
+  int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {-1, -1, -1};
+  const uint32_t m0 = (uint32_t)n0, m1 = (uint32_t)n1;  // nv < 2^31
+  for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t d = du[v];
+    if (d >= 0 && (!own || own[iperm[d]])) {
+      const uint32_t w = (uint32_t)v, q = w / m0;
+      const int idx[3] = {(int)(w - q * m0), (int)(q % m1), (int)(q / m1)};
+      for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], idx[a]); hi[a] = max(hi[a], idx[a]); }
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], o));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], o));
+    }
+    if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    const int l = min(min(red[a][0], red[a][1]), min(red[a][2], red[a][3]));
+    const int h = max(max(red[3 + a][0], red[3 + a][1]), max(red[3 + a][2], red[3 + a][3]));
+    if (h >= 0) { atomicMin(&out[a], l); atomicMax(&out[3 + a], h); }
+  }
+}
+
+__global__ void k_box_gmap(BoxGrid g, int lo0, int lo1, int lo2, int64_t n0, int64_t n1, int64_t n2,
+                           const int32_t *__restrict__ du, const int32_t *__restrict__ iperm,
+                           const uint8_t *__restrict__ own, int32_t *__restrict__ gmap) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= g.plane * g.m[2]) return;
+  const int x = (int)(e % g.pitch), y = (int)((e / g.pitch) % g.m[1]), z = (int)(e / g.plane);
+  int32_t q = -1;
+  const int64_t i = lo0 + 1 + x, j = lo1 + 1 + y, k = lo2 + 1 + z;
+  if (x < g.m[0] && i >= 0 && i < n0 && j >= 0 && j < n1 && k >= 0 && k < n2) {
+    const int32_t d = du[i + n0 * (j + n1 * k)];
+    if (d >= 0) {
+      const int32_t pos = iperm[d];
+      if (!own || own[pos]) q = pos;
+    }
+  }
+  gmap[e] = q;
+}
+
+__global__ void k_dscale(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ diag,
+                         double *__restrict__ dscale) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dscale[i] = diag[perm[i]];
+}
+
+// Builds the preconditioner of system `s` (state 1) or marks it not applicable (state -1).
+#define PHX_PRECOND_MARGIN 4
+static int box_precond_setup(phx_system *s) {
+  phx_mesh *m = s->mesh;
+  s->precond_state = -1;
+  if (!m->precond || !m->is_box || m->gdim != 3 || !s->u_vertex_block) return PHX_OK;
+  hipStream_t st = m->stream;
+  const int64_t n0 = m->box_n[0] + 1, n1 = m->box_n[1] + 1, n2 = m->box_n[2] + 1;
+  int *dbb = nullptr, hbb[6] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1};
+  PHX_HIP(phx_malloc(&dbb, sizeof(hbb)));
+  PHX_HIP(hipMemcpyAsync(dbb, hbb, sizeof(hbb), hipMemcpyHostToDevice, st));
+  k_active_bbox<<<dim3((unsigned)std::min<int64_t>(phx_div_up(m->nv, 256), 1024)), dim3(256), 0, st>>>(
+      m->nv, n0, n1, s->dof_of_vertex_u, s->iperm, s->own, dbb);
+  PHX_HIP(hipMemcpyAsync(hbb, dbb, sizeof(hbb), hipMemcpyDeviceToHost, st));
+  PHX_HIP(hipStreamSynchronize(st));
+  PHX_HIP(phx_free(dbb));
+  if (hbb[3] < 0) return PHX_OK;  // no active u DoF here
+  int L[3], lo[3];
+  for (int a = 0; a < 3; ++a) {
+    const int extent = hbb[3 + a] - hbb[a] + 1;
+    L[a] = dst_pick_length(extent + 2 * PHX_PRECOND_MARGIN + 1);
+    if (L[a] < 0) return PHX_OK;  // larger than the longest transform: stay with Jacobi
+    lo[a] = hbb[a] - 1 - (L[a] - 1 - extent) / 2;
+  }
+  phx_box_precond *bp = new phx_box_precond();
+  int rc = box_grid_setup(bp, m->device, L, m->box_h);
+  if (rc != PHX_OK) { box_precond_free(bp); return rc; }
+  for (int a = 0; a < 3; ++a) bp->lo[a] = lo[a];
+  const int64_t tot = bp->g.plane * bp->g.m[2];
+  if (phx_malloc(&bp->gmap, sizeof(int32_t) * (size_t)tot) != hipSuccess ||
+      phx_malloc(&bp->dscale, sizeof(double) * (size_t)s->n) != hipSuccess ||
+      phx_malloc(&bp->vec, sizeof(double) * (size_t)s->n * 2) != hipSuccess) {
+    box_precond_free(bp);
+    return PHX_ERR_HIP;
+  }
+  k_box_gmap<<<dim3((unsigned)phx_div_up(tot, 256)), dim3(256), 0, st>>>(
+      bp->g, lo[0], lo[1], lo[2], n0, n1, n2, s->dof_of_vertex_u, s->iperm, s->own, bp->gmap);
+  k_dscale<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(s->n, s->perm, s->diag, bp->dscale);
+  if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+  bp->own_ptr = s->own;
+  s->precond = bp;
+  s->precond_state = 1;
+  return PHX_OK;
+}
+
+// vout = P vin:  u rows: D K_box^-1 (the SELL copy holds A D^-1, so P = D M^-1), all other rows: identity
+static int box_precond_apply(phx_system *s, const double *vin, double *vout) {
+  phx_box_precond *bp = s->precond;
+  hipStream_t st = s->mesh->stream;
+  PHX_HIP(hipMemcpyAsync(vout, vin, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, st));
+  PHX_CHECK(box_pass_x<1>(bp, st, vin, nullptr));
+  PHX_CHECK(box_solve_middle(bp, st));
+  PHX_CHECK(box_pass_x<2>(bp, st, nullptr, vout));
+  return PHX_OK;
+}
+
+// Test / inspection entry: solve K_box u = f on an (L0-1) x (L1-1) x (L2-1) interior lattice with spacings h
+// (x fastest, no padding in `f`); u overwrites f.
+extern "C" int phx_box_poisson_solve(int device, const int *L, const double *h, double *f_host) {
+  PHX_HIP(hipSetDevice(device));
+  for (int a = 0; a < 3; ++a)
+    PHX_REQUIRE(dst_pick_length(L[a]) == L[a], PHX_ERR_VALUE, "L[%d] = %d is not a supported transform length", a, L[a]);
+  phx_box_precond *bp = new phx_box_precond();
+  int rc = box_grid_setup(bp, device, L, h);
+  if (rc != PHX_OK) { box_precond_free(bp); return rc; }
+  const BoxGrid &g = bp->g;
+  const size_t bytes = sizeof(double) * (size_t)(g.plane * g.m[2]);
+  std::vector<double> tmp((size_t)(g.plane * g.m[2]), 0.0);
+  for (int64_t z = 0; z < g.m[2]; ++z)
+    for (int64_t y = 0; y < g.m[1]; ++y)
+      memcpy(&tmp[z * g.plane + y * g.pitch], &f_host[(z * g.m[1] + y) * g.m[0]], sizeof(double) * (size_t)g.m[0]);
+  hipStream_t st = nullptr;
+  if (hipMemcpy(bp->G, tmp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+  rc = box_pass_x<0>(bp, st, nullptr, nullptr);
+  if (rc == PHX_OK) rc = box_solve_middle(bp, st);
+  if (rc == PHX_OK) rc = box_pass_x<0>(bp, st, nullptr, nullptr);
+  if (rc == PHX_OK && hipDeviceSynchronize() != hipSuccess) rc = PHX_ERR_HIP;
+  if (rc == PHX_OK && hipMemcpy(tmp.data(), bp->G, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = PHX_ERR_HIP;
+  if (rc == PHX_OK)
+    for (int64_t z = 0; z < g.m[2]; ++z)
+      for (int64_t y = 0; y < g.m[1]; ++y)
+        memcpy(&f_host[(z * g.m[1] + y) * g.m[0]], &tmp[z * g.plane + y * g.pitch], sizeof(double) * (size_t)g.m[0]);
+  box_precond_free(bp);
+  return rc;
+}

@@ -497,10 +497,10 @@ k_update_s(int64_t n, int par, const uint8_t *__restrict__ own, const double *__
   if (blockIdx.x == 0 && threadIdx.x == 0) { S[S_ALPHA] = alpha; S[S_RHO] = rho; }
 }
 
-// x += alpha p + omega s;  r = s - omega t;  accumulates rho_next = (rhat,r) and (r,r)
+// x += alpha phat + omega shat;  r = s - omega t;  accumulates rho_next = (rhat,r) and (r,r)
 __global__ void __launch_bounds__(256)
-k_update_xr(int64_t n, int par, const uint8_t *__restrict__ own, const double *__restrict__ p,
-            const double *__restrict__ sv, const double *__restrict__ t,
+k_update_xr(int64_t n, int par, const uint8_t *__restrict__ own, const double *__restrict__ phat,
+            const double *__restrict__ shat, const double *__restrict__ sv, const double *__restrict__ t,
             const double *__restrict__ rhat, double *__restrict__ x, double *__restrict__ r,
             double *__restrict__ S) {
   const double alpha = S[S_ALPHA];
@@ -511,7 +511,7 @@ k_update_xr(int64_t n, int par, const uint8_t *__restrict__ own, const double *_
     const double si = sv[i];
     double ri = 0.0;
     if (mine) {
-      x[i] += alpha * p[i] + omega * si;
+      x[i] += alpha * phat[i] + omega * shat[i];
       ri = si - omega * t[i];
     }
     r[i] = ri;
@@ -596,13 +596,23 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   return PHX_OK;
 }
 
+#include "phx_precond.inc.hip"
+
+// phat / shat are the preconditioned directions P p, P s the two SpMVs act on; without a preconditioner
+// beyond the Jacobi scaling folded into the SELL values they ARE p and s.
 struct KrVecs {
-  double *r, *rhat, *p, *v, *sv, *t, *y, *b;
+  double *r, *rhat, *p, *v, *sv, *t, *y, *b, *phat, *shat;
 };
 static inline KrVecs kr_vecs(phx_system *s) {
   double *w = s->kr_work ? s->kr_work : s->work;
   const int64_t n = s->n;
-  return {w, w + n, w + 2 * n, w + 3 * n, w + 4 * n, w + 5 * n, w + 6 * n, w + 7 * n};
+  KrVecs V{w, w + n, w + 2 * n, w + 3 * n, w + 4 * n, w + 5 * n, w + 6 * n, w + 7 * n, w + 2 * n, w + 4 * n};
+  if (s->precond_state == 1) {
+    // attached workspaces (multi-GPU drivers, 10 n doubles) carry the two extra vectors themselves
+    V.phat = s->kr_work ? w + 8 * n : s->precond->vec;
+    V.shat = s->kr_work ? w + 9 * n : s->precond->vec + n;
+  }
+  return V;
 }
 static inline double *kr_scal(phx_system *s) { return s->kr_scal ? s->kr_scal : s->scal; }
 
@@ -661,6 +671,15 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
   phx_mesh *m = s->mesh;
   const int64_t n = s->n;
   hipStream_t st = m->stream;
+  if (phase == 0) {
+    // (re)build the preconditioner for this system and ownership mask
+    if (s->precond_state == 1 && s->precond->own_ptr != s->own) {
+      phx_box_precond_destroy(s->precond);
+      s->precond = nullptr;
+      s->precond_state = 0;
+    }
+    if (s->precond_state == 0) PHX_CHECK(box_precond_setup(s));
+  }
   const KrVecs V = kr_vecs(s);
   double *S = kr_scal(s);
   const dim3 block(256);
@@ -675,7 +694,7 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       break;
     case 2:
       PHX_CHECK(prof_begin(s));
-      PHX_CHECK(launch_spmv(s, s->sell_val, V.p, V.v, 1, V.rhat, slot_base(S, par, R_RV), nullptr));
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.phat, V.v, 1, V.rhat, slot_base(S, par, R_RV), nullptr));
       PHX_CHECK(prof_end(s));
       if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_RV, 1, 1);
       break;
@@ -684,16 +703,22 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       break;
     case 4:
       PHX_CHECK(prof_begin(s));
-      PHX_CHECK(launch_spmv(s, s->sell_val, V.sv, V.t, 2, V.sv, slot_base(S, par, R_TS), slot_base(S, par, R_TT)));
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.shat, V.t, 2, V.sv, slot_base(S, par, R_TS), slot_base(S, par, R_TT)));
       PHX_CHECK(prof_end(s));
       if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_TS, 2, 1);
       break;
     case 5:
-      k_update_xr<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.p, V.sv, V.t, V.rhat, V.y, V.r, S);
+      k_update_xr<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.phat, V.shat, V.sv, V.t, V.rhat, V.y, V.r, S);
       if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_RHO, 2, 1);
       break;
     case 6:
       k_update_p<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.r, V.v, V.p, V.rhat, S);
+      break;
+    case 7:  // phat = P p   (before the halo exchange of phat and phase 2)
+      if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.p, V.phat));
+      break;
+    case 8:  // shat = P s   (before the halo exchange of shat and phase 4)
+      if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.sv, V.shat));
       break;
     default:
       phx_set_error("unknown Krylov phase %d", phase);
@@ -727,6 +752,13 @@ extern "C" int phx_krylov_finish(phx_system *s, double *x_out, int loc) {
     PHX_HIP(hipMemcpy(x_out, owned, sizeof(double) * (size_t)s->nfull, hipMemcpyDeviceToHost));
     PHX_HIP(phx_free(owned));
   }
+  return PHX_OK;
+}
+
+// after phase 0: 1 when the system is preconditioned beyond Jacobi (phases 7 / 8 then fill phat / shat,
+// the vectors a multi-GPU driver must halo-exchange instead of p / s)
+extern "C" int phx_krylov_precond_active(const phx_system *s, int *active) {
+  *active = s->precond_state == 1 ? 1 : 0;
   return PHX_OK;
 }
 
@@ -790,7 +822,8 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
   int rc = PHX_OK;
   while (bb != 0.0 && it < max_iter) {
     const int par = (int)(it & 1);
-    for (int ph = 2; ph <= 5; ++ph) PHX_CHECK(kr_phase(s, ph, 0, par));
+    static const int seq[6] = {7, 2, 3, 8, 4, 5};
+    for (int ph : seq) PHX_CHECK(kr_phase(s, ph, 0, par));
     spmvs += 2;
     ++it;
     if ((it % check_every == 0) || it == max_iter) {

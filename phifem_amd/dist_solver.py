@@ -63,6 +63,11 @@ class HipBackend:
     def phase(self, k):
         self.L.check(self.L.lib.phx_krylov_phase(self.sys, k))
 
+    def precond_active(self):
+        a = C.c_int(0)
+        self.L.check(self.L.lib.phx_krylov_precond_active(self.sys, C.byref(a)))
+        return bool(a.value)
+
     def finish(self, out):
         self.L.check(self.L.lib.phx_krylov_finish(self.sys, C.c_void_p(out.data_ptr()), self.L.DEVICE))
 
@@ -136,10 +141,12 @@ class DistributedSolver:
         self.own, self.halos = ownership_and_halos(torch, backend, plane_size, k0, P0, P1, rank,
                                                    world, n_planes_local)
         n = backend.n
-        self.work = torch.zeros(8 * n, dtype=torch.float64, device=dev)
+        self.work = torch.zeros(10 * n, dtype=torch.float64, device=dev)
         self.scal = torch.zeros(SCAL_DOUBLES, dtype=torch.float64, device=dev)
         self.p = self.work[2 * n:3 * n]
         self.s = self.work[4 * n:5 * n]
+        self.phat = self.work[8 * n:9 * n]
+        self.shat = self.work[9 * n:10 * n]
         backend.attach(self.work, self.scal, self.own)
         self.n_owned = int(self.own.sum().item())
         self._verify_halos()
@@ -205,12 +212,19 @@ class DistributedSolver:
         b.phase(1)
         bb = float(self.scal[S_BB].item())
         it, relres = 0, (0.0 if bb == 0.0 else 1.0)
+        # with a rank-local block preconditioner the SpMV inputs are phat = P p, shat = P s
+        pc = getattr(b, "precond_active", lambda: False)()
+        vp, vs = (self.phat, self.shat) if pc else (self.p, self.s)
         while bb != 0.0 and it < self.max_iter:
-            self.halo_exchange(self.p)
+            if pc:
+                b.phase(7)
+            self.halo_exchange(vp)
             b.phase(2)
             self._allreduce(R_RV, R_RV + 1)
             b.phase(3)
-            self.halo_exchange(self.s)
+            if pc:
+                b.phase(8)
+            self.halo_exchange(vs)
             b.phase(4)
             self._allreduce(R_TS, R_TT + 1)
             b.phase(5)
