@@ -243,6 +243,10 @@ int phx_solve(phx_system *s, int method, double rtol, int64_t max_iter, double *
  * phases 7 / 8 compute from p / s (rank-local block preconditioner on the owned rows). */
 int phx_krylov_attach(phx_system *s, double *work, double *scal, const uint8_t *own);
 int phx_krylov_precond_active(const phx_system *s, int *active);
+/* After a solve: out[8] = {preconditioner active (0/1), transform lengths L0, L1, L2, lattice points of
+ * the box, sampled average seconds of one y-pass launch of the sine transforms (PHX_OPT_PROFILE_SPMV),
+ * launches sampled, y-pass launches per preconditioner application}. */
+int phx_precond_info(phx_system *s, double *out);
 /* phase 0 begin, 1 begin2, 2 v=A phat, 3 s-update, 4 t=A shat, 5 x/r-update, 6 p-update + roll,
  * 7 phat = P p, 8 shat = P s (no-ops without a preconditioner) */
 int phx_krylov_phase(phx_system *s, int phase);

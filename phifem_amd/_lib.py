@@ -61,6 +61,7 @@ SIGNATURES = {
     "phx_box_poisson_solve": ([_i, _pi, _pd, _vp], _i),
     "phx_mesh_tag_histogram": ([_vp, _pi64, _pi64], _i),
     "phx_krylov_precond_active": ([_vp, _pi], _i),
+    "phx_precond_info": ([_vp, _pd], _i),
     "phx_krylov_attach": ([_vp, _vp, _vp, _vp], _i),
     "phx_krylov_phase": ([_vp, _i], _i),
     "phx_krylov_finish": ([_vp, _vp, _i], _i),

@@ -652,7 +652,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
   for (void *p : ptrs) (void)phx_free(p);
   phx_box_precond_destroy(s->precond);
   if (s->scal_h) (void)hipHostFree(s->scal_h);
-  for (auto &e : s->prof_ev) (void)hipEventDestroy(e);
+  for (auto &pe : s->prof_ev) for (auto &e : pe) (void)hipEventDestroy(e);
   delete s;
   return PHX_OK;
 }

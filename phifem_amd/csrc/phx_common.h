@@ -149,8 +149,8 @@ struct phx_system {
   bool u_vertex_block = false;     // rows [0, nu) are one scalar u DoF per active vertex
   struct phx_box_precond *precond = nullptr;
   int precond_state = 0;           // 0 not tried, 1 built, -1 not applicable
-  std::vector<hipEvent_t> prof_ev;
-  int prof_used = 0, prof_seen = 0;
+  std::vector<hipEvent_t> prof_ev[2];  // event pairs of the sampled launches: [0] SpMV, [1] sine-transform y pass
+  int prof_used[2] = {0, 0}, prof_seen[2] = {0, 0};
 };
 
 // helpers implemented in phx_mesh.hip

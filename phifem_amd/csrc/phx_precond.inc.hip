@@ -8,20 +8,28 @@
 // 78/121/164/194/230 with Jacobi); the p block keeps Jacobi.  K_box is diagonalised by the type-I
 // discrete sine transform in every axis:  u = S_x S_y S_z diag(1/lambda) S_z S_y S_x r.
 //
-// DST-I of two real lines at a time: z = a + i b, odd extension to length N2 = 2 L, one complex FFT in
-// LDS (Stockham autosort, radices 8/4/3/2, twiddles from a table):  S_a[k] = -Im Z_k / 2,
-// S_b[k] = Re Z_k / 2.  x lines are contiguous; y and z lines are walked as tiles of W adjacent columns so
-// that every global access is a contiguous run of W doubles.  Five passes over the grid per application:
-// x (gather from the Krylov vector), y, z (forward + 1/lambda + inverse fused in LDS), y, x (scatter).
+// DST-I of two real lines a, b at a time through ONE complex FFT of length L (not 2L): with
+//   y_j = sin(pi j / L) (x_j + x_{L-j}) + (x_j - x_{L-j}) / 2,   w = y^a + i y^b,   W = FFT_L(w),
+//   Y^a_k = (W_k + conj W_{L-k}) / 2,  Y^b_k = (W_k - conj W_{L-k}) / (2i)
+// the sine coefficients F_k = sum_j x_j sin(pi j k / L) are  F_{2k} = -Im Y_k  and
+// F_{2k+1} = F_{2k-1} + Re Y_k  (F_1 = Re Y_0 / 2): a prefix sum, done per thread and across the threads
+// of the pair in LDS.  The FFT is a Stockham autosort in LDS (radices 8/4/2, a radix-3 stage last so that
+// every sub-transform size is a power of two), twiddles from a table.  x lines are contiguous; y and z lines
+// are walked as tiles of W adjacent columns so that every global access is a contiguous run of W doubles.
+// Five passes over the lattice per application: x (gather from the Krylov vector), y, z (forward +
+// 1/lambda + inverse fused in LDS), y, x (scatter).
 #include <limits.h>
 #include <math.h>
 
 #include <map>
 
 struct DstPlan {
-  int N2 = 0, L = 0, nstage = 0, pairs = 0, tp = 0;  // pairs per block, threads per pair (N2 / 8)
-  int radix[8], pw[8], tws[8];  // per stage: radix R, sub-transform size p so far (a power of two), N2 / (p R)
-  double2 *tw = nullptr;        // device, exp(-2 pi i j / N2), j < N2
+  int L = 0, nstage = 0, pairs = 0, tp = 0;  // pairs per block, threads per pair (L / 8)
+  int radix[8], pw[8], tws[8];  // per stage: radix R, sub-transform size p so far (a power of two), L / (p R)
+  int scr = 0;                  // scan scratch per pair (complex doubles)
+  int lds = 0;                  // dynamic LDS bytes per block
+  double2 *tw = nullptr;        // device, exp(-2 pi i j / L), j < L
+  double *sintab = nullptr;     // device, sin(pi j / L), j <= L / 2
 };
 
 static std::map<std::pair<int, int>, DstPlan> g_dst_plans;  // (device, L) -> plan
@@ -34,14 +42,18 @@ static int dst_pick_length(int64_t need) {
   return -1;
 }
 
+// LDS index padding: one extra 16-byte element after every 8, so that the stride-8 / stride-64 write
+// patterns of the first Stockham stages spread over the banks (unpadded: up to 32-way conflicts)
+#define ZP(n) ((n) + ((n) >> 3))
+#define ZLEN(N) ((N) + ((N) >> 3) + 1)
+
 static int dst_get_plan(int device, int L, DstPlan *out) {
   auto key = std::make_pair(device, L);
   auto it = g_dst_plans.find(key);
   if (it != g_dst_plans.end()) { *out = it->second; return PHX_OK; }
   DstPlan P;
   P.L = L;
-  P.N2 = 2 * L;
-  int rest = P.N2;
+  int rest = L;
   P.nstage = 0;
   // radix 3 (if any) goes LAST so that every stage's p is a power of two (k = i & (p - 1))
   const bool three = rest % 3 == 0;
@@ -53,28 +65,35 @@ static int dst_get_plan(int device, int L, DstPlan *out) {
   if (three) P.radix[P.nstage++] = 3;
   for (int st = 0, pp = 1; st < P.nstage; ++st) {
     P.pw[st] = pp;
-    P.tws[st] = P.N2 / (pp * P.radix[st]);
+    P.tws[st] = L / (pp * P.radix[st]);
     pp *= P.radix[st];
   }
-  P.tp = P.N2 / 8;
-  P.pairs = std::max(1, 4096 / P.N2);          // 64 KB of LDS: 4096 complex doubles
-  while (P.pairs * P.tp > 512) --P.pairs;      // and at most 512 threads
-  std::vector<double2> tw((size_t)P.N2);
-  for (int j = 0; j < P.N2; ++j) {
-    const long double a = -2.0L * 3.141592653589793238462643383279502884L * (long double)j / (long double)P.N2;
+  P.tp = L / 8;
+  // pairs per block: a power of two (W = 2 pairs adjacent columns per strided tile), at most 512 threads
+  // and ~40 KB of LDS so that four blocks share a CU (measured at L = 192: 16 pairs 41.7 ms per solve,
+  // 8 pairs 37.1, 4 pairs 41.3); the long transforms get 80 KB to keep W >= 8
+  int budget = (L >= 768 ? 80 : 40) * 1024;
+  if (const char *e = getenv("PHX_DST_LDS_KB")) budget = atoi(e) > 0 ? atoi(e) * 1024 : budget;  // tuning aid
+  P.pairs = 1;
+  while (2 * P.pairs * (int)sizeof(double2) * ZLEN(L) <= budget && 2 * P.pairs * P.tp <= 512) P.pairs *= 2;
+  P.scr = P.tp + (P.tp + 7) / 8 + 1;
+  P.lds = (int)sizeof(double2) * P.pairs * (ZLEN(L) + P.scr);
+  std::vector<double2> tw((size_t)L);
+  const long double pi = 3.141592653589793238462643383279502884L;
+  for (int j = 0; j < L; ++j) {
+    const long double a = -2.0L * pi * (long double)j / (long double)L;
     tw[j] = make_double2((double)cosl(a), (double)sinl(a));
   }
-  PHX_HIP(hipMalloc(&P.tw, sizeof(double2) * tw.size()));  // lives as long as the process (a few KB per length)
+  std::vector<double> st((size_t)L / 2 + 1);
+  for (int j = 0; j <= L / 2; ++j) st[j] = (double)sinl(pi * (long double)j / (long double)L);
+  PHX_HIP(hipMalloc(&P.tw, sizeof(double2) * tw.size()));  // live as long as the process (a few KB per length)
+  PHX_HIP(hipMalloc(&P.sintab, sizeof(double) * st.size()));
   PHX_HIP(hipMemcpy(P.tw, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice));
+  PHX_HIP(hipMemcpy(P.sintab, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
   g_dst_plans[key] = P;
   *out = P;
   return PHX_OK;
 }
-
-// LDS index padding: one extra 16-byte element after every 8, so that the stride-8 / stride-64 write
-// patterns of the first Stockham stages spread over the banks (unpadded: up to 32-way conflicts)
-#define ZP(n) ((n) + ((n) >> 3))
-#define ZLEN(N2) ((N2) + ((N2) >> 3))
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
   return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -110,7 +129,7 @@ template <> __device__ __forceinline__ void dft_r<8>(double2 *v) {
   for (int k = 0; k < 4; ++k) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
 }
 
-// one Stockham stage of radix R on the N2-point sequence `z` of this pair: `t` = thread within the pair.
+// one Stockham stage of radix R on the L-point sequence `z` of this pair: `t` = thread within the pair.
 // All inputs are read into registers, the block synchronises, then the outputs are written in place.
 template <int R>
 __device__ __forceinline__ void fft_stage(double2 *z, int nb, int tp, int t, int p, int tws,
@@ -122,7 +141,7 @@ __device__ __forceinline__ void fft_stage(double2 *z, int nb, int tp, int t, int
     const int i = t + b * tp;
     if (i < nb) {
       const int k = i & (p - 1);
-      const int step = tws * k;  // twiddle exponent of q = 1; q * step < N2 for q < R
+      const int step = tws * k;  // twiddle exponent of q = 1; q * step < L for q < R
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         double2 w = z[ZP(i + q * nb)];
@@ -149,14 +168,82 @@ __device__ __forceinline__ void fft_stage(double2 *z, int nb, int tp, int t, int
 // forward complex FFT of this pair's sequence `z` in LDS.  Every thread of the block must call it (block
 // barriers inside); threads of an idle pair slot pass live = false and do no work.
 __device__ __forceinline__ void fft_pairs(double2 *z, const DstPlan &P, int t, bool live) {
-  const int tt = live ? t : P.N2;  // empty butterfly range
+  const int tt = live ? t : P.L;  // empty butterfly range
   for (int s = 0; s < P.nstage; ++s) {
     const int R = P.radix[s], p = P.pw[s], tws = P.tws[s];
-    if (R == 8) fft_stage<8>(z, P.N2 >> 3, P.tp, tt, p, tws, P.tw);
-    else if (R == 4) fft_stage<4>(z, P.N2 >> 2, P.tp, tt, p, tws, P.tw);
-    else if (R == 3) fft_stage<3>(z, tws * p, P.tp, tt, p, tws, P.tw);  // N2 / 3 butterflies
-    else fft_stage<2>(z, P.N2 >> 1, P.tp, tt, p, tws, P.tw);
+    if (R == 8) fft_stage<8>(z, P.L >> 3, P.tp, tt, p, tws, P.tw);
+    else if (R == 4) fft_stage<4>(z, P.L >> 2, P.tp, tt, p, tws, P.tw);
+    else if (R == 3) fft_stage<3>(z, tws * p, P.tp, tt, p, tws, P.tw);  // L / 3 butterflies
+    else fft_stage<2>(z, P.L >> 1, P.tp, tt, p, tws, P.tw);
   }
+}
+
+// In:  w[ZP(j)] = (a_j, b_j), j = 1 .. L-1 (w[0] arbitrary).   Out: w[ZP(k)] = (F^a_k, F^b_k), k = 1 .. L-1,
+// F_k = sum_j x_j sin(pi j k / L).  `scr`: tp + tp/8 + 1 complex doubles of scan scratch of this pair.
+// Block-wide barriers inside: every thread of the block calls it.
+__device__ __forceinline__ void dst_core(double2 *w, double2 *scr, const DstPlan &P, int t, bool live) {
+  const int L = P.L, tp = P.tp, H = L >> 1;
+  if (live) {
+    for (int j = 1 + t; j < H; j += tp) {
+      const double2 X = w[ZP(j)], Y = w[ZP(L - j)];
+      const double s = P.sintab[j];
+      const double2 e = make_double2(s * (X.x + Y.x), s * (X.y + Y.y));
+      const double2 o = make_double2(0.5 * (X.x - Y.x), 0.5 * (X.y - Y.y));
+      w[ZP(j)] = cadd(e, o);
+      w[ZP(L - j)] = csub(e, o);
+    }
+    if (t == 0) {
+      w[0] = make_double2(0.0, 0.0);
+      const double2 X = w[ZP(H)];
+      w[ZP(H)] = make_double2(2.0 * X.x, 2.0 * X.y);
+    }
+  }
+  __syncthreads();
+  fft_pairs(w, P, t, live);
+  // thread t owns k = 4 t .. 4 t + 3  (k < L / 2)
+  double2 Wk[4], Wm[4], c[4];
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 4 * t + i;
+      Wk[i] = w[ZP(k)];
+      Wm[i] = w[ZP(k == 0 ? 0 : L - k)];
+    }
+  }
+  __syncthreads();
+  double2 *tot = scr, *gt = scr + tp;
+  if (live) {
+    double2 run = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = 4 * t + i;
+      double2 R;
+      if (k == 0) {
+        R = make_double2(0.5 * Wk[i].x, 0.5 * Wk[i].y);  // F_1 = Re Y_0 / 2 starts the running sum
+      } else {
+        R = make_double2(0.5 * (Wk[i].x + Wm[i].x), 0.5 * (Wk[i].y + Wm[i].y));
+        w[ZP(2 * k)] = make_double2(-0.5 * (Wk[i].y - Wm[i].y), 0.5 * (Wk[i].x - Wm[i].x));
+      }
+      run = cadd(run, R);
+      c[i] = run;
+    }
+    tot[t] = run;
+  }
+  __syncthreads();
+  if (live && t < (tp + 7) / 8) {
+    double2 g = make_double2(0.0, 0.0);
+    for (int q = 8 * t; q < min(8 * t + 8, tp); ++q) g = cadd(g, tot[q]);
+    gt[t] = g;
+  }
+  __syncthreads();
+  if (live) {
+    double2 E = make_double2(0.0, 0.0);
+    for (int g = 0; g < (t >> 3); ++g) E = cadd(E, gt[g]);
+    for (int q = t & ~7; q < t; ++q) E = cadd(E, tot[q]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[ZP(2 * (4 * t + i) + 1)] = cadd(E, c[i]);
+  }
+  __syncthreads();
 }
 
 struct BoxGrid {
@@ -166,12 +253,6 @@ struct BoxGrid {
   double scale;      // (2/Lx)(2/Ly)(2/Lz): the three inverse transforms
   const double *lam[3];  // c_a (2 - 2 cos(pi k / L_a)), k = 0 .. L_a - 1 (device)
 };
-
-// LDS layout of a pair: z[0..N2), z[j] = (a_j, b_j) for j = 1..L-1, z[0] = z[L] = 0, z[N2-j] = -z[j]
-__device__ __forceinline__ void put_odd(double2 *z, int N2, int j, double a, double b) {
-  z[ZP(j)] = make_double2(a, b);
-  z[ZP(N2 - j)] = make_double2(-a, -b);
-}
 
 // ---- x lines (contiguous): pair = two consecutive lines of the flattened (y, z) index.
 // IO = 1: the input is gathered from the Krylov vector through gmap (solver position of the u DoF at the
@@ -185,8 +266,9 @@ k_dst_x(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict_
   const int64_t nlines = (int64_t)g.m[1] * g.m[2];
   const int64_t line0 = ((int64_t)blockIdx.x * P.pairs + pr) * 2;
   const bool live = line0 < nlines;
-  double2 *z = zs + (size_t)pr * ZLEN(P.N2);
-  const int mx = g.m[0], L = P.L, N2 = P.N2;
+  double2 *w = zs + (size_t)pr * ZLEN(P.L);
+  double2 *scr = zs + (size_t)P.pairs * ZLEN(P.L) + (size_t)pr * P.scr;
+  const int mx = g.m[0], L = P.L;
   int64_t base[2] = {0, 0};
   bool has[2] = {false, false};
   if (live) {
@@ -195,25 +277,25 @@ k_dst_x(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict_
       has[c] = l < nlines;
       base[c] = has[c] ? (l % g.m[1]) * g.pitch + (l / g.m[1]) * g.plane : 0;
     }
-    // j = t + 4 i tp / 4 ... : L / tp = 4 trips; all loads are issued before the first LDS write
-    double va[4], vb[4];
+    // j = t + i tp, L / tp = 8 trips; all loads are issued before the first LDS write
+    double va[8], vb[8];
     if (IO == 1) {
-      int32_t qa[4], qb[4];
+      int32_t qa[8], qb[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {
         const int j = t + i * P.tp;
         const bool in = j >= 1 && j <= mx;
         qa[i] = in && has[0] ? gmap[base[0] + j - 1] : -1;
         qb[i] = in && has[1] ? gmap[base[1] + j - 1] : -1;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {
         va[i] = qa[i] >= 0 ? vin[qa[i]] : 0.0;
         vb[i] = qb[i] >= 0 ? vin[qb[i]] : 0.0;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {
         const int j = t + i * P.tp;
         const bool in = j >= 1 && j <= mx;
         va[i] = in && has[0] ? G[base[0] + j - 1] : 0.0;
@@ -221,24 +303,22 @@ k_dst_x(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict_
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const int j = t + i * P.tp;
-      if (j == 0) { z[0] = make_double2(0.0, 0.0); z[ZP(L)] = make_double2(0.0, 0.0); }
-      else if (j < L) put_odd(z, N2, j, va[i], vb[i]);
+      if (j >= 1 && j < L) w[ZP(j)] = make_double2(va[i], vb[i]);
     }
   }
   __syncthreads();
-  fft_pairs(z, P, t, live);
+  dst_core(w, scr, P, t, live);
   if (!live) return;
   for (int k = t + 1; k <= mx; k += P.tp) {
-    const double2 Z = z[ZP(k)];
-    const double sa = -0.5 * Z.y, sb = 0.5 * Z.x;
+    const double2 F = w[ZP(k)];
     if (IO == 2) {
-      if (has[0]) { const int32_t q = gmap[base[0] + k - 1]; if (q >= 0) vout[q] = sa * dscale[q]; }
-      if (has[1]) { const int32_t q = gmap[base[1] + k - 1]; if (q >= 0) vout[q] = sb * dscale[q]; }
+      if (has[0]) { const int32_t q = gmap[base[0] + k - 1]; if (q >= 0) vout[q] = F.x * dscale[q]; }
+      if (has[1]) { const int32_t q = gmap[base[1] + k - 1]; if (q >= 0) vout[q] = F.y * dscale[q]; }
     } else {
-      if (has[0]) G[base[0] + k - 1] = sa;
-      if (has[1]) G[base[1] + k - 1] = sb;
+      if (has[0]) G[base[0] + k - 1] = F.x;
+      if (has[1]) G[base[1] + k - 1] = F.y;
     }
   }
 }
@@ -251,7 +331,7 @@ __global__ void __launch_bounds__(512)
 k_dst_s(BoxGrid g, DstPlan P, double *__restrict__ G) {
   extern __shared__ double2 zs[];
   const int pr = threadIdx.x / P.tp, t = threadIdx.x % P.tp;
-  const int W = 2 * P.pairs, L = P.L, N2 = P.N2;
+  const int W = 2 * P.pairs, L = P.L;
   const int mx = g.m[0];
   const int ncb = (mx + W - 1) / W;                 // column blocks
   const int col0 = (int)(blockIdx.x % ncb) * W;
@@ -261,30 +341,27 @@ k_dst_s(BoxGrid g, DstPlan P, double *__restrict__ G) {
   const int64_t base = col0 + outer * (AXIS == 1 ? g.plane : g.pitch);
   const int ncols = min(W, mx - col0);
   const bool live = 2 * pr < ncols;
-  double2 *z = zs + (size_t)pr * ZLEN(N2);
-  // cooperative tile load: thread -> fixed column, rows row0, row0 + rstep, ...  (blockDim = W * tp / 2)
+  double2 *w = zs + (size_t)pr * ZLEN(L);
+  double2 *scr = zs + (size_t)P.pairs * ZLEN(L) + (size_t)pr * P.scr;
+  // cooperative tile load: thread -> fixed column, rows row0, row0 + rstep, ...  (blockDim = W tp / 2,
+  // rstep = L / 16: 16 trips, all loads in flight before the first LDS write)
   const int tcol = threadIdx.x % W, row0 = threadIdx.x / W, rstep = blockDim.x / W;
-  double *zcol = reinterpret_cast<double *>(zs + (size_t)(tcol >> 1) * ZLEN(N2)) + (tcol & 1);
+  double *wcol = reinterpret_cast<double *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
   {
-    // (L - 1) / rstep <= 8 trips (rstep = L / 8): all loads in flight before the first LDS write
-    double vv[8];
+    double vv[16];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 16; ++i) {
       const int row = row0 + i * rstep;
       vv[i] = (row < len && tcol < ncols) ? G[base + row * estride + tcol] : 0.0;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 16; ++i) {
       const int row = row0 + i * rstep;
-      if (row < L - 1) {
-        zcol[2 * ZP(row + 1)] = vv[i];
-        zcol[2 * ZP(N2 - row - 1)] = -vv[i];
-      }
+      if (row < L - 1) wcol[2 * ZP(row + 1)] = vv[i];
     }
   }
-  if (t == 0) { z[0] = make_double2(0.0, 0.0); z[ZP(L)] = make_double2(0.0, 0.0); }
   __syncthreads();
-  fft_pairs(z, P, t, live);
+  dst_core(w, scr, P, t, live);
   if (SOLVE) {
     if (live) {
       const double *lx = g.lam[0], *ly = g.lam[1], *lz = g.lam[2];
@@ -292,22 +369,17 @@ k_dst_s(BoxGrid g, DstPlan P, double *__restrict__ G) {
       const double lxy0 = lx[kx] + ly[outer + 1];
       const double lxy1 = (kx + 1 < g.L[0] ? lx[kx + 1] : lx[kx]) + ly[outer + 1];
       for (int k = t + 1; k < L; k += P.tp) {
-        const double2 Z = z[ZP(k)];
+        const double2 F = w[ZP(k)];
         const double lzk = lz[k];
-        put_odd(z, N2, k, -0.5 * Z.y * g.scale / (lxy0 + lzk), 0.5 * Z.x * g.scale / (lxy1 + lzk));
+        w[ZP(k)] = make_double2(F.x * g.scale / (lxy0 + lzk), F.y * g.scale / (lxy1 + lzk));
       }
-      if (t == 0) { z[0] = make_double2(0.0, 0.0); z[ZP(L)] = make_double2(0.0, 0.0); }
     }
     __syncthreads();
-    fft_pairs(z, P, t, live);
+    dst_core(w, scr, P, t, live);
   }
-  // extract (results sit at z[k], k = 1..L-1) and store the tile
   if (tcol < ncols) {
-    const double2 *zc = zs + (size_t)(tcol >> 1) * ZLEN(N2);
-    for (int row = row0; row < len; row += rstep) {
-      const double2 Z = zc[ZP(row + 1)];
-      G[base + row * estride + tcol] = (tcol & 1) ? 0.5 * Z.x : -0.5 * Z.y;
-    }
+    const double *wc = reinterpret_cast<const double *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
+    for (int row = row0; row < len; row += rstep) G[base + row * estride + tcol] = wc[2 * ZP(row + 1)];
   }
 }
 
@@ -334,7 +406,7 @@ static void box_precond_free(phx_box_precond *bp) {
 static int dst_allow_lds() {
   static bool done = false;
   if (done) return PHX_OK;
-  const int bytes = 80 * 1024;  // 4096 padded complex doubles = 72 KB, above the 64 KB default
+  const int bytes = 96 * 1024;  // 4096 padded complex doubles + scan scratch: above the 64 KB default
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<0>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -369,26 +441,30 @@ static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const
 }
 
 // the three middle passes (y, z with the spectral solve, y) on G
-static int box_solve_middle(phx_box_precond *bp, hipStream_t st) {
+static int box_solve_middle(phx_box_precond *bp, hipStream_t st, phx_system *prof = nullptr) {
   const BoxGrid &g = bp->g;
   const DstPlan &py = bp->plan[1], &pz = bp->plan[2];
   {
     const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
     const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.tp));
-    const size_t lds = sizeof(double2) * (size_t)py.pairs * ZLEN(py.N2);
+    const size_t lds = (size_t)py.lds;
+    if (prof) PHX_CHECK(prof_begin(prof, 1));
     k_dst_s<1, false><<<grid, block, lds, st>>>(g, py, bp->G);
+    if (prof) PHX_CHECK(prof_end(prof, 1));
   }
   {
     const int W = 2 * pz.pairs, ncb = (g.m[0] + W - 1) / W;
     const dim3 grid((unsigned)((int64_t)ncb * g.m[1])), block((unsigned)(pz.pairs * pz.tp));
-    const size_t lds = sizeof(double2) * (size_t)pz.pairs * ZLEN(pz.N2);
+    const size_t lds = (size_t)pz.lds;
     k_dst_s<2, true><<<grid, block, lds, st>>>(g, pz, bp->G);
   }
   {
     const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
     const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.tp));
-    const size_t lds = sizeof(double2) * (size_t)py.pairs * ZLEN(py.N2);
+    const size_t lds = (size_t)py.lds;
+    if (prof) PHX_CHECK(prof_begin(prof, 1));
     k_dst_s<1, false><<<grid, block, lds, st>>>(g, py, bp->G);
+    if (prof) PHX_CHECK(prof_end(prof, 1));
   }
   PHX_HIP(hipGetLastError());
   return PHX_OK;
@@ -400,7 +476,7 @@ static int box_pass_x(phx_box_precond *bp, hipStream_t st, const double *vin, do
   const DstPlan &px = bp->plan[0];
   const int64_t npairs = ((int64_t)g.m[1] * g.m[2] + 1) / 2;
   const dim3 grid((unsigned)phx_div_up(npairs, px.pairs)), block((unsigned)(px.pairs * px.tp));
-  const size_t lds = sizeof(double2) * (size_t)px.pairs * ZLEN(px.N2);
+  const size_t lds = (size_t)px.lds;
   k_dst_x<IO><<<grid, block, lds, st>>>(g, px, bp->G, bp->gmap, vin, vout, bp->dscale);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
@@ -516,7 +592,7 @@ static int box_precond_apply(phx_system *s, const double *vin, double *vout) {
   hipStream_t st = s->mesh->stream;
   PHX_HIP(hipMemcpyAsync(vout, vin, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, st));
   PHX_CHECK(box_pass_x<1>(bp, st, vin, nullptr));
-  PHX_CHECK(box_solve_middle(bp, st));
+  PHX_CHECK(box_solve_middle(bp, st, s));
   PHX_CHECK(box_pass_x<2>(bp, st, nullptr, vout));
   return PHX_OK;
 }

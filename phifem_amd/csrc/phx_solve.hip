@@ -596,6 +596,58 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   return PHX_OK;
 }
 
+// Launches inside the solve can be bracketed by HIP events on the launch stream (phx_set_option
+// PHX_OPT_PROFILE_SPMV): the roofline figures of bench.py come from here.  Class 0: the SpMV launches,
+// class 1: the y passes of the sine-transform preconditioner.  The option value is the sampling stride:
+// 1 brackets every launch, k every k-th (an event pair costs ~2.5 us of stream time, 4 % of a solve when
+// every launch carries one).
+static inline bool prof_sampled(const phx_system *s, int c) {
+  return s->mesh->profile_spmv > 0 && s->prof_used[c] < (int)s->prof_ev[c].size() / 2 &&
+         s->prof_seen[c] % s->mesh->profile_spmv == 0;
+}
+static int prof_begin(phx_system *s, int c = 0) {
+  if (prof_sampled(s, c)) PHX_HIP(hipEventRecord(s->prof_ev[c][2 * s->prof_used[c]], s->mesh->stream));
+  return PHX_OK;
+}
+static int prof_end(phx_system *s, int c = 0) {
+  if (prof_sampled(s, c)) {
+    PHX_HIP(hipEventRecord(s->prof_ev[c][2 * s->prof_used[c] + 1], s->mesh->stream));
+    s->prof_used[c]++;
+  }
+  s->prof_seen[c]++;
+  return PHX_OK;
+}
+static int prof_reset(phx_system *s) {
+  for (int c = 0; c < 2; ++c) {
+    s->prof_used[c] = 0;
+    s->prof_seen[c] = 0;
+    if (s->mesh->profile_spmv && s->prof_ev[c].empty()) {
+      s->prof_ev[c].resize(2 * 1024);
+      for (auto &e : s->prof_ev[c]) PHX_HIP(hipEventCreate(&e));
+    }
+  }
+  return PHX_OK;
+}
+static int prof_collect(phx_system *s, double *avg_s, int *count, int c = 0) {
+  *avg_s = 0.0;
+  *count = 0;
+  if (!s->mesh->profile_spmv || s->prof_used[c] == 0) return PHX_OK;
+  PHX_HIP(hipEventSynchronize(s->prof_ev[c][2 * s->prof_used[c] - 1]));
+  double tot = 0.0;
+  for (int i = 0; i < s->prof_used[c]; ++i) {
+    float ms = 0.f;
+    PHX_HIP(hipEventElapsedTime(&ms, s->prof_ev[c][2 * i], s->prof_ev[c][2 * i + 1]));
+    tot += ms;
+  }
+  *avg_s = tot * 1e-3 / s->prof_used[c];
+  *count = s->prof_used[c];
+  if (c == 0) {
+    s->mesh->timings[4] = *avg_s;
+    s->mesh->timings[5] = (double)*count;
+  }
+  return PHX_OK;
+}
+
 #include "phx_precond.inc.hip"
 
 // phat / shat are the preconditioned directions P p, P s the two SpMVs act on; without a preconditioner
@@ -615,53 +667,6 @@ static inline KrVecs kr_vecs(phx_system *s) {
   return V;
 }
 static inline double *kr_scal(phx_system *s) { return s->kr_scal ? s->kr_scal : s->scal; }
-
-// SpMV launches inside the solve can be bracketed by HIP events on the launch stream
-// (phx_set_option PHX_OPT_PROFILE_SPMV): the roofline figure of bench.py comes from here.
-// The option value is the sampling stride: 1 brackets every launch, k every k-th (an event pair costs
-// ~2.5 us of stream time, 4 % of a solve when every launch carries one).
-static inline bool prof_sampled(const phx_system *s) {
-  return s->mesh->profile_spmv > 0 && s->prof_used < (int)s->prof_ev.size() / 2 &&
-         s->prof_seen % s->mesh->profile_spmv == 0;
-}
-static int prof_begin(phx_system *s) {
-  if (prof_sampled(s)) PHX_HIP(hipEventRecord(s->prof_ev[2 * s->prof_used], s->mesh->stream));
-  return PHX_OK;
-}
-static int prof_end(phx_system *s) {
-  if (prof_sampled(s)) {
-    PHX_HIP(hipEventRecord(s->prof_ev[2 * s->prof_used + 1], s->mesh->stream));
-    s->prof_used++;
-  }
-  s->prof_seen++;
-  return PHX_OK;
-}
-static int prof_reset(phx_system *s) {
-  s->prof_used = 0;
-  s->prof_seen = 0;
-  if (s->mesh->profile_spmv && s->prof_ev.empty()) {
-    s->prof_ev.resize(2 * 1024);
-    for (auto &e : s->prof_ev) PHX_HIP(hipEventCreate(&e));
-  }
-  return PHX_OK;
-}
-static int prof_collect(phx_system *s, double *avg_s, int *count) {
-  *avg_s = 0.0;
-  *count = 0;
-  if (!s->mesh->profile_spmv || s->prof_used == 0) return PHX_OK;
-  PHX_HIP(hipEventSynchronize(s->prof_ev[2 * s->prof_used - 1]));
-  double tot = 0.0;
-  for (int i = 0; i < s->prof_used; ++i) {
-    float ms = 0.f;
-    PHX_HIP(hipEventElapsedTime(&ms, s->prof_ev[2 * i], s->prof_ev[2 * i + 1]));
-    tot += ms;
-  }
-  *avg_s = tot * 1e-3 / s->prof_used;
-  *count = s->prof_used;
-  s->mesh->timings[4] = *avg_s;
-  s->mesh->timings[5] = (double)*count;
-  return PHX_OK;
-}
 
 // phases: 0 begin (local (b,b) -> R_RHO), 1 begin2 (after all-reduce), 2 v = A p (+R_RV),
 // 3 s-update, 4 t = A s (+R_TS, R_TT), 5 x/r-update (+R_RHO, R_RR), 6 p-update + roll.
@@ -799,6 +804,24 @@ extern "C" int phx_krylov_profile(phx_system *s, int reset, double *avg_seconds,
   PHX_CHECK(prof_collect(s, &a, &c));
   if (avg_seconds) *avg_seconds = a;
   if (count) *count = c;
+  return PHX_OK;
+}
+
+// out[8] = {preconditioner active (0/1), transform lengths L0, L1, L2, stored lattice points of the box,
+//           sampled average seconds of a y-pass launch, launches sampled, y-pass launches per application (2)}
+extern "C" int phx_precond_info(phx_system *s, double *out) {
+  for (int i = 0; i < 8; ++i) out[i] = 0.0;
+  if (s->precond_state != 1) return PHX_OK;
+  const BoxGrid &g = s->precond->g;
+  out[0] = 1.0;
+  for (int a = 0; a < 3; ++a) out[1 + a] = (double)g.L[a];
+  out[4] = (double)g.m[0] * (double)g.m[1] * (double)g.m[2];
+  double avg = 0.0;
+  int cnt = 0;
+  PHX_CHECK(prof_collect(s, &avg, &cnt, 1));
+  out[5] = avg;
+  out[6] = (double)cnt;
+  out[7] = 2.0;
   return PHX_OK;
 }
 

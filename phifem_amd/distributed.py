@@ -88,12 +88,17 @@ class SlabProblem:
             st = self.dk.solve(self.out, profile_spmv=profile_spmv)
             n_owned = st["n_owned"]
         t = mesh.timings()
+        pc = self.solver.precond_info()
         return {
             "n_active_owned": n_owned, "iterations": st["iterations"], "relres": st["relres"],
             "stage_s": {"tag": t["tag_cells"] + t["tag_facets"], "assemble": t["assemble"],
                         "solve": st["seconds"]},
             "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),
             "spmv_algorithmic_bytes": 12.0 * info["sell_nnz"] + 20.0 * info["n_active"],
+            # sine-transform y pass of the preconditioner: reads and writes every lattice point once
+            "precond": pc["precond"], "precond_L": pc["precond_L"],
+            "dst_avg_s": pc["dst_avg_s"], "dst_count": pc["dst_timed"],
+            "dst_algorithmic_bytes": 16.0 * pc["precond_points"],
         }
 
 
@@ -153,10 +158,15 @@ class ElasticitySlabProblem(SlabProblem):
             st = self.dk.solve(self.out, profile_spmv=profile_spmv)
             n_owned = st["n_owned"]
         t = mesh.timings()
+        pc = self.solver.precond_info()
         return {
             "n_active_owned": n_owned, "iterations": st["iterations"], "relres": st["relres"],
             "stage_s": {"tag": t["tag_cells"] + t["tag_facets"], "assemble": t["assemble"],
                         "solve": st["seconds"]},
             "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),
             "spmv_algorithmic_bytes": 12.0 * info["sell_nnz"] + 20.0 * info["n_active"],
+            # sine-transform y pass of the preconditioner: reads and writes every lattice point once
+            "precond": pc["precond"], "precond_L": pc["precond_L"],
+            "dst_avg_s": pc["dst_avg_s"], "dst_count": pc["dst_timed"],
+            "dst_algorithmic_bytes": 16.0 * pc["precond_points"],
         }

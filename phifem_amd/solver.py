@@ -110,12 +110,20 @@ class PhiFEMSolver:
         L.check(L.lib.phx_solve(self._sys, 0, float(rtol), int(max_iter), p, loc, st))
         self.stats = {"iterations": int(st[0]), "relres": st[1], "seconds": st[2],
                       "spmv": int(st[3]), "spmv_avg_s": st[4], "spmv_timed": int(st[5])}
+        self.stats.update(self.precond_info())
         return out
 
     def split(self, w):
         """solution_wh.split() (main.py:185): (u, p) views of the mixed vector."""
         nd = self.ndofs
         return w[:nd], w[nd:]
+
+    def precond_info(self):
+        """State of the fictitious-domain preconditioner after a solve (phx_precond_info)."""
+        o = (C.c_double * 8)()
+        L.check(L.lib.phx_precond_info(self._sys, o))
+        return {"precond": "box-dst" if o[0] else "jacobi", "precond_L": [int(o[1]), int(o[2]), int(o[3])],
+                "precond_points": int(o[4]), "dst_avg_s": o[5], "dst_timed": int(o[6])}
 
     def spmv(self, x):
         y = np.empty_like(x)
