@@ -202,8 +202,9 @@ def main():
             a2 = res["dst_algorithmic_bytes"] / dst_s / 1e9
             dst_roof = {
                 "bound": "hbm",
-                "kernel": "k_dst_s<1,false> (type-I sine transform along y of the preconditioner lattice, "
-                          "f64, one read + one write of every lattice point)",
+                "kernel": f"k_dst_s<{'float' if res['precond_value_bytes'] == 4 else 'double'},1,false> (type-I sine "
+                          f"transform along y of the preconditioner lattice, "
+                          f"f{8 * res['precond_value_bytes']}, one read + one write of every lattice point)",
                 "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("dst", n), "bytes_per_launch": res["dst_algorithmic_bytes"],
                 "avg_launch_us": 1e6 * dst_s, "launches_timed": res["dst_count"],
@@ -230,8 +231,9 @@ def main():
                             (f"3D interface elasticity phi-FEM, 5-field mixed P1 (27 comps/vertex), "
                              f"E_in=1, E_out=1e-3, nu=0.3, {n}^3 Kuhn box in {world} z-slab(s), box mode"),
                 "active_dofs": n_active,
-                "krylov": ("BiCGStab, right-preconditioned: lattice Laplacian of a box around the active vertices "
-                           "inverted by sine transforms (u), Jacobi (p)") if res.get("precond") == "box-dst"
+                "krylov": ("BiCGStab (f64), right-preconditioned: lattice Laplacian of a box around the active "
+                           f"vertices inverted by f{8 * res.get('precond_value_bytes', 8)} sine transforms (u), "
+                           "Jacobi (p)") if res.get("precond") == "box-dst"
                 else "BiCGStab + Jacobi (right)",
                 "rtol": args.rtol, "iterations": res["iterations"], "relres": res["relres"],
                 "stage_ms": {k: 1e3 * v for k, v in res["stage_s"].items()},

@@ -135,7 +135,9 @@ enum phx_option {
                                walks runs of G consecutive blocks; 0: plain order (default)      */
   PHX_OPT_PRECOND = 5, /* 1 (default): P1 Poisson systems on 3-D Kuhn boxes are preconditioned with the
                                lattice Laplacian of a box around the active vertices, inverted by sine
-                               transforms (u block; p block: Jacobi); 0: Jacobi everywhere            */
+                               transforms in f32 (u block; p block: Jacobi) -- an approximate inverse by
+                               construction, the Krylov vectors, SpMV and residual stay f64;
+                               2: the same with f64 transforms; 0: Jacobi everywhere                    */
   PHX_OPT_SPMV_VALUE_INDEX = 4 /* 1 (default): systems assembled from now on store SELL slices whose
                                values take <= 64 distinct doubles as dictionary + byte codes
                                (bit-identical products, 5 instead of 12 bytes per entry); 0: raw */
@@ -143,9 +145,10 @@ enum phx_option {
 int phx_set_option(phx_mesh *m, int option, int64_t value);
 /* Direct solve of the 7-point lattice Laplacian K = sum_a (h_b h_c / h_a) tridiag(-1, 2, -1)_a with
  * homogeneous Dirichlet faces on an (L0-1) x (L1-1) x (L2-1) interior lattice (x fastest), by type-I sine
- * transforms on the device; L_a in {64, 96, 128, 192, 256, 384, 512, 768, 1024}.  u overwrites f (host).
+ * transforms on the device (f32 != 0: lattice array and transforms in single precision);
+ * L_a in {64, 96, 128, 192, 256, 384, 512, 768, 1024}.  u overwrites f (host).
  * This is the kernel sequence of the fictitious-domain preconditioner (PHX_OPT_PRECOND), exposed for tests. */
-int phx_box_poisson_solve(int device, const int *L, const double *h, double *f_host);
+int phx_box_poisson_solve(int device, const int *L, const double *h, int f32, double *f_host);
 /* Mean elapsed time of an empty HIP event pair on the mesh stream: the cost the bracketing of
  * PHX_OPT_PROFILE_SPMV adds to each timed launch (measurement aid of bench.py). */
 int phx_event_pair_overhead(phx_mesh *m, double *seconds);
@@ -245,7 +248,7 @@ int phx_krylov_attach(phx_system *s, double *work, double *scal, const uint8_t *
 int phx_krylov_precond_active(const phx_system *s, int *active);
 /* After a solve: out[8] = {preconditioner active (0/1), transform lengths L0, L1, L2, lattice points of
  * the box, sampled average seconds of one y-pass launch of the sine transforms (PHX_OPT_PROFILE_SPMV),
- * launches sampled, y-pass launches per preconditioner application}. */
+ * launches sampled, bytes per lattice value (4: f32 transforms, 8: f64)}. */
 int phx_precond_info(phx_system *s, double *out);
 /* phase 0 begin, 1 begin2, 2 v=A phat, 3 s-update, 4 t=A shat, 5 x/r-update, 6 p-update + roll,
  * 7 phat = P p, 8 shat = P s (no-ops without a preconditioner) */

@@ -159,7 +159,6 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     PHX_HIP(phx_malloc(&H.rbuf[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)));
   }
   double *S = kr_scal(s);
-  const int check_every = 8;
   int rc = PHX_OK;
   auto body = [&]() -> int {
     PHX_CHECK(prof_reset(s));
@@ -168,6 +167,7 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     PHX_CHECK(allreduce_R(s, c, R_RHO, R_RHO + 1));
     PHX_CHECK(phx_krylov_phase(s, 1));
     const KrVecs V = kr_vecs(s);  // after phase 0: the preconditioner decides where phat / shat live
+    const int check_every = s->precond_state == 1 ? 2 : 8;
     PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
     PHX_HIP(hipStreamSynchronize(st));
     const double bb = s->scal_h[S_BB];

@@ -796,7 +796,10 @@ extern "C" int phx_set_option(phx_mesh *m, int option, int64_t value) {
       return PHX_OK;
     case PHX_OPT_HAS_EXTERIOR: m->has_exterior_override = (int)value; return PHX_OK;
     case PHX_OPT_SPMV_VALUE_INDEX: m->spmv_value_index = value != 0; return PHX_OK;
-    case PHX_OPT_PRECOND: m->precond = value != 0; return PHX_OK;
+    case PHX_OPT_PRECOND:
+      PHX_REQUIRE(value >= 0 && value <= 2, PHX_ERR_VALUE, "unknown preconditioner %lld", (long long)value);
+      m->precond = (int)value;
+      return PHX_OK;
     case PHX_OPT_SPMV_XCD_GROUP:
       PHX_REQUIRE(value >= 0 && value < (1 << 24), PHX_ERR_VALUE, "XCD group size out of range");
       m->spmv_xcd_group = (int)value;

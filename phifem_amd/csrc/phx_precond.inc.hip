@@ -27,9 +27,12 @@ struct DstPlan {
   int L = 0, nstage = 0, pairs = 0, tp = 0;  // pairs per block, threads per pair (L / 8)
   int radix[8], pw[8], tws[8];  // per stage: radix R, sub-transform size p so far (a power of two), L / (p R)
   int scr = 0;                  // scan scratch per pair (complex doubles)
-  int lds = 0;                  // dynamic LDS bytes per block
+  int tab_off = 0;              // offset (complex values) of the table copies in LDS
+  int lds_elems = 0;            // complex values of dynamic LDS per block
   double2 *tw = nullptr;        // device, exp(-2 pi i j / L), j < L
   double *sintab = nullptr;     // device, sin(pi j / L), j <= L / 2
+  float2 *tw_f = nullptr;       // the same tables rounded to f32
+  float *sintab_f = nullptr;
 };
 
 static std::map<std::pair<int, int>, DstPlan> g_dst_plans;  // (device, L) -> plan
@@ -75,9 +78,10 @@ static int dst_get_plan(int device, int L, DstPlan *out) {
   int budget = (L >= 768 ? 80 : 40) * 1024;
   if (const char *e = getenv("PHX_DST_LDS_KB")) budget = atoi(e) > 0 ? atoi(e) * 1024 : budget;  // tuning aid
   P.pairs = 1;
-  while (2 * P.pairs * (int)sizeof(double2) * ZLEN(L) <= budget && 2 * P.pairs * P.tp <= 512) P.pairs *= 2;
+  while ((2 * P.pairs * ZLEN(L) + 2 * L) * (int)sizeof(double2) <= budget && 2 * P.pairs * P.tp <= 512) P.pairs *= 2;
   P.scr = P.tp + (P.tp + 7) / 8 + 1;
-  P.lds = (int)sizeof(double2) * P.pairs * (ZLEN(L) + P.scr);
+  P.tab_off = P.pairs * (ZLEN(L) + P.scr);            // LDS copies of the tables: twiddles, then sines
+  P.lds_elems = P.tab_off + L + (L / 2 + 2 + 1) / 2;
   std::vector<double2> tw((size_t)L);
   const long double pi = 3.141592653589793238462643383279502884L;
   for (int j = 0; j < L; ++j) {
@@ -90,52 +94,73 @@ static int dst_get_plan(int device, int L, DstPlan *out) {
   PHX_HIP(hipMalloc(&P.sintab, sizeof(double) * st.size()));
   PHX_HIP(hipMemcpy(P.tw, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice));
   PHX_HIP(hipMemcpy(P.sintab, st.data(), sizeof(double) * st.size(), hipMemcpyHostToDevice));
+  std::vector<float2> twf(tw.size());
+  std::vector<float> stf(st.size());
+  for (size_t j = 0; j < tw.size(); ++j) twf[j] = make_float2((float)tw[j].x, (float)tw[j].y);
+  for (size_t j = 0; j < st.size(); ++j) stf[j] = (float)st[j];
+  PHX_HIP(hipMalloc(&P.tw_f, sizeof(float2) * twf.size()));
+  PHX_HIP(hipMalloc(&P.sintab_f, sizeof(float) * stf.size()));
+  PHX_HIP(hipMemcpy(P.tw_f, twf.data(), sizeof(float2) * twf.size(), hipMemcpyHostToDevice));
+  PHX_HIP(hipMemcpy(P.sintab_f, stf.data(), sizeof(float) * stf.size(), hipMemcpyHostToDevice));
   g_dst_plans[key] = P;
   *out = P;
   return PHX_OK;
 }
 
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
-  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+// complex pair of T (float: 8-byte, double: 16-byte LDS accesses)
+template <typename T> struct alignas(2 * sizeof(T)) C2 { T x, y; };
+template <typename T> __device__ __forceinline__ C2<T> mk(T x, T y) { C2<T> r; r.x = x; r.y = y; return r; }
+template <typename T> __device__ __forceinline__ C2<T> cmul(C2<T> a, C2<T> b) {
+  return mk<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }  // a * (-i)
+template <typename T> __device__ __forceinline__ C2<T> cadd(C2<T> a, C2<T> b) { return mk<T>(a.x + b.x, a.y + b.y); }
+template <typename T> __device__ __forceinline__ C2<T> csub(C2<T> a, C2<T> b) { return mk<T>(a.x - b.x, a.y - b.y); }
+template <typename T> __device__ __forceinline__ C2<T> mul_mi(C2<T> a) { return mk<T>(a.y, -a.x); }  // a * (-i)
 
-template <int R> __device__ __forceinline__ void dft_r(double2 *v);
-template <> __device__ __forceinline__ void dft_r<2>(double2 *v) {
-  const double2 a = v[0], b = v[1];
+template <typename T> __device__ __forceinline__ void dft2(C2<T> *v) {
+  const C2<T> a = v[0], b = v[1];
   v[0] = cadd(a, b); v[1] = csub(a, b);
 }
-template <> __device__ __forceinline__ void dft_r<3>(double2 *v) {
-  const double s = 0.86602540378443864676;  // sin(2 pi / 3)
-  const double2 t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
-  const double2 m = make_double2(v[0].x - 0.5 * t.x, v[0].y - 0.5 * t.y);
-  const double2 r = make_double2(s * d.y, -s * d.x);  // -i s d
+template <typename T> __device__ __forceinline__ void dft3(C2<T> *v) {
+  const T s = T(0.86602540378443864676), hf = T(0.5);  // sin(2 pi / 3)
+  const C2<T> t = cadd(v[1], v[2]), d = csub(v[1], v[2]);
+  const C2<T> m = mk<T>(v[0].x - hf * t.x, v[0].y - hf * t.y);
+  const C2<T> r = mk<T>(s * d.y, -s * d.x);  // -i s d
   v[0] = cadd(v[0], t); v[1] = cadd(m, r); v[2] = csub(m, r);
 }
-template <> __device__ __forceinline__ void dft_r<4>(double2 *v) {
-  const double2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
-  const double2 t2 = cadd(v[1], v[3]), t3 = mul_mi(csub(v[1], v[3]));
+template <typename T> __device__ __forceinline__ void dft4(C2<T> *v) {
+  const C2<T> t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+  const C2<T> t2 = cadd(v[1], v[3]), t3 = mul_mi(csub(v[1], v[3]));
   v[0] = cadd(t0, t2); v[1] = cadd(t1, t3); v[2] = csub(t0, t2); v[3] = csub(t1, t3);
 }
-template <> __device__ __forceinline__ void dft_r<8>(double2 *v) {
-  double2 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
-  dft_r<4>(e); dft_r<4>(o);
-  const double h = 0.70710678118654752440;
-  o[1] = make_double2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));    // * (1 - i)/sqrt2
+template <typename T> __device__ __forceinline__ void dft8(C2<T> *v) {
+  C2<T> e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+  dft4(e); dft4(o);
+  const T h = T(0.70710678118654752440);
+  o[1] = mk<T>(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));    // * (1 - i)/sqrt2
   o[2] = mul_mi(o[2]);
-  o[3] = make_double2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));   // * (-1 - i)/sqrt2
+  o[3] = mk<T>(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));   // * (-1 - i)/sqrt2
   for (int k = 0; k < 4; ++k) { v[k] = cadd(e[k], o[k]); v[k + 4] = csub(e[k], o[k]); }
 }
 
+// tables of the plan in the precision of the transform
+template <typename T> struct PlanTab;
+template <> struct PlanTab<double> {
+  static __device__ __forceinline__ const C2<double> *tw(const DstPlan &P) { return reinterpret_cast<const C2<double> *>(P.tw); }
+  static __device__ __forceinline__ const double *sn(const DstPlan &P) { return P.sintab; }
+};
+template <> struct PlanTab<float> {
+  static __device__ __forceinline__ const C2<float> *tw(const DstPlan &P) { return reinterpret_cast<const C2<float> *>(P.tw_f); }
+  static __device__ __forceinline__ const float *sn(const DstPlan &P) { return P.sintab_f; }
+};
+
 // one Stockham stage of radix R on the L-point sequence `z` of this pair: `t` = thread within the pair.
 // All inputs are read into registers, the block synchronises, then the outputs are written in place.
-template <int R>
-__device__ __forceinline__ void fft_stage(double2 *z, int nb, int tp, int t, int p, int tws,
-                                          const double2 *__restrict__ tw) {
+template <typename T, int R>
+__device__ __forceinline__ void fft_stage(C2<T> *z, int nb, int tp, int t, int p, int tws,
+                                          const C2<T> *__restrict__ tw) {
   constexpr int MAXB = (8 + R - 1) / R;
-  double2 u[MAXB][R];
+  C2<T> u[MAXB][R];
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
     const int i = t + b * tp;
@@ -144,11 +169,14 @@ __device__ __forceinline__ void fft_stage(double2 *z, int nb, int tp, int t, int
       const int step = tws * k;  // twiddle exponent of q = 1; q * step < L for q < R
 #pragma unroll
       for (int q = 0; q < R; ++q) {
-        double2 w = z[ZP(i + q * nb)];
+        C2<T> w = z[ZP(i + q * nb)];
         if (q > 0 && k > 0) w = cmul(w, tw[q * step]);
         u[b][q] = w;
       }
-      dft_r<R>(u[b]);
+      if constexpr (R == 8) dft8(u[b]);
+      else if constexpr (R == 4) dft4(u[b]);
+      else if constexpr (R == 3) dft3(u[b]);
+      else dft2(u[b]);
     }
   }
   __syncthreads();
@@ -167,41 +195,45 @@ __device__ __forceinline__ void fft_stage(double2 *z, int nb, int tp, int t, int
 
 // forward complex FFT of this pair's sequence `z` in LDS.  Every thread of the block must call it (block
 // barriers inside); threads of an idle pair slot pass live = false and do no work.
-__device__ __forceinline__ void fft_pairs(double2 *z, const DstPlan &P, int t, bool live) {
+template <typename T>
+__device__ __forceinline__ void fft_pairs(C2<T> *z, const DstPlan &P, int t, bool live, const C2<T> *tw) {
   const int tt = live ? t : P.L;  // empty butterfly range
   for (int s = 0; s < P.nstage; ++s) {
     const int R = P.radix[s], p = P.pw[s], tws = P.tws[s];
-    if (R == 8) fft_stage<8>(z, P.L >> 3, P.tp, tt, p, tws, P.tw);
-    else if (R == 4) fft_stage<4>(z, P.L >> 2, P.tp, tt, p, tws, P.tw);
-    else if (R == 3) fft_stage<3>(z, tws * p, P.tp, tt, p, tws, P.tw);  // L / 3 butterflies
-    else fft_stage<2>(z, P.L >> 1, P.tp, tt, p, tws, P.tw);
+    if (R == 8) fft_stage<T, 8>(z, P.L >> 3, P.tp, tt, p, tws, tw);
+    else if (R == 4) fft_stage<T, 4>(z, P.L >> 2, P.tp, tt, p, tws, tw);
+    else if (R == 3) fft_stage<T, 3>(z, tws * p, P.tp, tt, p, tws, tw);  // L / 3 butterflies
+    else fft_stage<T, 2>(z, P.L >> 1, P.tp, tt, p, tws, tw);
   }
 }
 
 // In:  w[ZP(j)] = (a_j, b_j), j = 1 .. L-1 (w[0] arbitrary).   Out: w[ZP(k)] = (F^a_k, F^b_k), k = 1 .. L-1,
-// F_k = sum_j x_j sin(pi j k / L).  `scr`: tp + tp/8 + 1 complex doubles of scan scratch of this pair.
+// F_k = sum_j x_j sin(pi j k / L).  `scr`: tp + tp/8 + 1 complex values of scan scratch of this pair.
 // Block-wide barriers inside: every thread of the block calls it.
-__device__ __forceinline__ void dst_core(double2 *w, double2 *scr, const DstPlan &P, int t, bool live) {
+template <typename T>
+__device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P, int t, bool live,
+                                         const C2<T> *tw, const T *sn) {
   const int L = P.L, tp = P.tp, H = L >> 1;
+  const T hf = T(0.5);
   if (live) {
     for (int j = 1 + t; j < H; j += tp) {
-      const double2 X = w[ZP(j)], Y = w[ZP(L - j)];
-      const double s = P.sintab[j];
-      const double2 e = make_double2(s * (X.x + Y.x), s * (X.y + Y.y));
-      const double2 o = make_double2(0.5 * (X.x - Y.x), 0.5 * (X.y - Y.y));
+      const C2<T> X = w[ZP(j)], Y = w[ZP(L - j)];
+      const T s = sn[j];
+      const C2<T> e = mk<T>(s * (X.x + Y.x), s * (X.y + Y.y));
+      const C2<T> o = mk<T>(hf * (X.x - Y.x), hf * (X.y - Y.y));
       w[ZP(j)] = cadd(e, o);
       w[ZP(L - j)] = csub(e, o);
     }
     if (t == 0) {
-      w[0] = make_double2(0.0, 0.0);
-      const double2 X = w[ZP(H)];
-      w[ZP(H)] = make_double2(2.0 * X.x, 2.0 * X.y);
+      w[0] = mk<T>(T(0), T(0));
+      const C2<T> X = w[ZP(H)];
+      w[ZP(H)] = mk<T>(X.x + X.x, X.y + X.y);
     }
   }
   __syncthreads();
-  fft_pairs(w, P, t, live);
+  fft_pairs<T>(w, P, t, live, tw);
   // thread t owns k = 4 t .. 4 t + 3  (k < L / 2)
-  double2 Wk[4], Wm[4], c[4];
+  C2<T> Wk[4], Wm[4], c[4];
   if (live) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -211,18 +243,18 @@ __device__ __forceinline__ void dst_core(double2 *w, double2 *scr, const DstPlan
     }
   }
   __syncthreads();
-  double2 *tot = scr, *gt = scr + tp;
+  C2<T> *tot = scr, *gt = scr + tp;
   if (live) {
-    double2 run = make_double2(0.0, 0.0);
+    C2<T> run = mk<T>(T(0), T(0));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = 4 * t + i;
-      double2 R;
+      C2<T> R;
       if (k == 0) {
-        R = make_double2(0.5 * Wk[i].x, 0.5 * Wk[i].y);  // F_1 = Re Y_0 / 2 starts the running sum
+        R = mk<T>(hf * Wk[i].x, hf * Wk[i].y);  // F_1 = Re Y_0 / 2 starts the running sum
       } else {
-        R = make_double2(0.5 * (Wk[i].x + Wm[i].x), 0.5 * (Wk[i].y + Wm[i].y));
-        w[ZP(2 * k)] = make_double2(-0.5 * (Wk[i].y - Wm[i].y), 0.5 * (Wk[i].x - Wm[i].x));
+        R = mk<T>(hf * (Wk[i].x + Wm[i].x), hf * (Wk[i].y + Wm[i].y));
+        w[ZP(2 * k)] = mk<T>(-hf * (Wk[i].y - Wm[i].y), hf * (Wk[i].x - Wm[i].x));
       }
       run = cadd(run, R);
       c[i] = run;
@@ -231,19 +263,33 @@ __device__ __forceinline__ void dst_core(double2 *w, double2 *scr, const DstPlan
   }
   __syncthreads();
   if (live && t < (tp + 7) / 8) {
-    double2 g = make_double2(0.0, 0.0);
+    C2<T> g = mk<T>(T(0), T(0));
     for (int q = 8 * t; q < min(8 * t + 8, tp); ++q) g = cadd(g, tot[q]);
     gt[t] = g;
   }
   __syncthreads();
   if (live) {
-    double2 E = make_double2(0.0, 0.0);
+    C2<T> E = mk<T>(T(0), T(0));
     for (int g = 0; g < (t >> 3); ++g) E = cadd(E, gt[g]);
     for (int q = t & ~7; q < t; ++q) E = cadd(E, tot[q]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[ZP(2 * (4 * t + i) + 1)] = cadd(E, c[i]);
   }
   __syncthreads();
+}
+
+// copies the twiddle and sine tables of the plan into LDS (the stage loops read them with LDS latency
+// instead of L1/L2 latency); the caller synchronises before the first use
+template <typename T>
+__device__ __forceinline__ void stage_tables(C2<T> *zs, const DstPlan &P, const C2<T> **tw, const T **sn) {
+  C2<T> *ltw = zs + P.tab_off;
+  T *lsn = reinterpret_cast<T *>(ltw + P.L);
+  const C2<T> *gtw = PlanTab<T>::tw(P);
+  const T *gsn = PlanTab<T>::sn(P);
+  for (int j = threadIdx.x; j < P.L; j += blockDim.x) ltw[j] = gtw[j];
+  for (int j = threadIdx.x; j <= P.L / 2; j += blockDim.x) lsn[j] = gsn[j];
+  *tw = ltw;
+  *sn = lsn;
 }
 
 struct BoxGrid {
@@ -257,18 +303,23 @@ struct BoxGrid {
 // ---- x lines (contiguous): pair = two consecutive lines of the flattened (y, z) index.
 // IO = 1: the input is gathered from the Krylov vector through gmap (solver position of the u DoF at the
 // lattice point, -1: none); IO = 2: the result is scattered out the same way, times dscale.
-template <int IO>
+// T: precision of the lattice array and of the transform (the Krylov vectors stay f64).
+template <typename T, int IO>
 __global__ void __launch_bounds__(512)
-k_dst_x(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict__ gmap,
+k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gmap,
         const double *__restrict__ vin, double *__restrict__ vout, const double *__restrict__ dscale) {
-  extern __shared__ double2 zs[];
+  extern __shared__ double2 zs_raw[];
+  C2<T> *zs = reinterpret_cast<C2<T> *>(zs_raw);
   const int pr = threadIdx.x / P.tp, t = threadIdx.x % P.tp;
   const int64_t nlines = (int64_t)g.m[1] * g.m[2];
   const int64_t line0 = ((int64_t)blockIdx.x * P.pairs + pr) * 2;
   const bool live = line0 < nlines;
-  double2 *w = zs + (size_t)pr * ZLEN(P.L);
-  double2 *scr = zs + (size_t)P.pairs * ZLEN(P.L) + (size_t)pr * P.scr;
+  C2<T> *w = zs + (size_t)pr * ZLEN(P.L);
+  C2<T> *scr = zs + (size_t)P.pairs * ZLEN(P.L) + (size_t)pr * P.scr;
   const int mx = g.m[0], L = P.L;
+  const C2<T> *tw;
+  const T *sn;
+  stage_tables<T>(zs, P, &tw, &sn);
   int64_t base[2] = {0, 0};
   bool has[2] = {false, false};
   if (live) {
@@ -278,7 +329,7 @@ k_dst_x(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict_
       base[c] = has[c] ? (l % g.m[1]) * g.pitch + (l / g.m[1]) * g.plane : 0;
     }
     // j = t + i tp, L / tp = 8 trips; all loads are issued before the first LDS write
-    double va[8], vb[8];
+    T va[8], vb[8];
     if (IO == 1) {
       int32_t qa[8], qb[8];
 #pragma unroll
@@ -290,33 +341,54 @@ k_dst_x(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict_
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        va[i] = qa[i] >= 0 ? vin[qa[i]] : 0.0;
-        vb[i] = qb[i] >= 0 ? vin[qb[i]] : 0.0;
+        va[i] = qa[i] >= 0 ? (T)vin[qa[i]] : T(0);
+        vb[i] = qb[i] >= 0 ? (T)vin[qb[i]] : T(0);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int j = t + i * P.tp;
         const bool in = j >= 1 && j <= mx;
-        va[i] = in && has[0] ? G[base[0] + j - 1] : 0.0;
-        vb[i] = in && has[1] ? G[base[1] + j - 1] : 0.0;
+        va[i] = in && has[0] ? G[base[0] + j - 1] : T(0);
+        vb[i] = in && has[1] ? G[base[1] + j - 1] : T(0);
       }
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int j = t + i * P.tp;
-      if (j >= 1 && j < L) w[ZP(j)] = make_double2(va[i], vb[i]);
+      if (j >= 1 && j < L) w[ZP(j)] = mk<T>(va[i], vb[i]);
     }
   }
   __syncthreads();
-  dst_core(w, scr, P, t, live);
+  dst_core<T>(w, scr, P, t, live, tw, sn);
   if (!live) return;
-  for (int k = t + 1; k <= mx; k += P.tp) {
-    const double2 F = w[ZP(k)];
-    if (IO == 2) {
-      if (has[0]) { const int32_t q = gmap[base[0] + k - 1]; if (q >= 0) vout[q] = F.x * dscale[q]; }
-      if (has[1]) { const int32_t q = gmap[base[1] + k - 1]; if (q >= 0) vout[q] = F.y * dscale[q]; }
-    } else {
+  if (IO == 2) {
+    // k = t + 1 + i tp: all map loads, then all scale loads, then the stores
+    int32_t qa[8], qb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = t + 1 + i * P.tp;
+      qa[i] = k <= mx && has[0] ? gmap[base[0] + k - 1] : -1;
+      qb[i] = k <= mx && has[1] ? gmap[base[1] + k - 1] : -1;
+    }
+    double da[8], db[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      da[i] = qa[i] >= 0 ? dscale[qa[i]] : 0.0;
+      db[i] = qb[i] >= 0 ? dscale[qb[i]] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = t + 1 + i * P.tp;
+      if (k <= mx) {
+        const C2<T> F = w[ZP(k)];
+        if (qa[i] >= 0) vout[qa[i]] = (double)F.x * da[i];
+        if (qb[i] >= 0) vout[qb[i]] = (double)F.y * db[i];
+      }
+    }
+  } else {
+    for (int k = t + 1; k <= mx; k += P.tp) {
+      const C2<T> F = w[ZP(k)];
       if (has[0]) G[base[0] + k - 1] = F.x;
       if (has[1]) G[base[1] + k - 1] = F.y;
     }
@@ -324,12 +396,13 @@ k_dst_x(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict_
 }
 
 // ---- y / z lines (strided): a block takes W = 2 * pairs adjacent x columns of one `outer` index, so every
-// global access is a run of W consecutive doubles.  AXIS = 1: lines along y (outer = z), AXIS = 2: lines
+// global access is a run of W consecutive values.  AXIS = 1: lines along y (outer = z), AXIS = 2: lines
 // along z (outer = y).  SOLVE (z only): forward transform, times scale / lambda, inverse transform, all in LDS.
-template <int AXIS, bool SOLVE>
+template <typename T, int AXIS, bool SOLVE>
 __global__ void __launch_bounds__(512)
-k_dst_s(BoxGrid g, DstPlan P, double *__restrict__ G) {
-  extern __shared__ double2 zs[];
+k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
+  extern __shared__ double2 zs_raw[];
+  C2<T> *zs = reinterpret_cast<C2<T> *>(zs_raw);
   const int pr = threadIdx.x / P.tp, t = threadIdx.x % P.tp;
   const int W = 2 * P.pairs, L = P.L;
   const int mx = g.m[0];
@@ -341,18 +414,21 @@ k_dst_s(BoxGrid g, DstPlan P, double *__restrict__ G) {
   const int64_t base = col0 + outer * (AXIS == 1 ? g.plane : g.pitch);
   const int ncols = min(W, mx - col0);
   const bool live = 2 * pr < ncols;
-  double2 *w = zs + (size_t)pr * ZLEN(L);
-  double2 *scr = zs + (size_t)P.pairs * ZLEN(L) + (size_t)pr * P.scr;
+  C2<T> *w = zs + (size_t)pr * ZLEN(L);
+  C2<T> *scr = zs + (size_t)P.pairs * ZLEN(L) + (size_t)pr * P.scr;
+  const C2<T> *tw;
+  const T *sn;
+  stage_tables<T>(zs, P, &tw, &sn);
   // cooperative tile load: thread -> fixed column, rows row0, row0 + rstep, ...  (blockDim = W tp / 2,
   // rstep = L / 16: 16 trips, all loads in flight before the first LDS write)
   const int tcol = threadIdx.x % W, row0 = threadIdx.x / W, rstep = blockDim.x / W;
-  double *wcol = reinterpret_cast<double *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
+  T *wcol = reinterpret_cast<T *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
   {
-    double vv[16];
+    T vv[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = row0 + i * rstep;
-      vv[i] = (row < len && tcol < ncols) ? G[base + row * estride + tcol] : 0.0;
+      vv[i] = (row < len && tcol < ncols) ? G[base + row * estride + tcol] : T(0);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -361,7 +437,7 @@ k_dst_s(BoxGrid g, DstPlan P, double *__restrict__ G) {
     }
   }
   __syncthreads();
-  dst_core(w, scr, P, t, live);
+  dst_core<T>(w, scr, P, t, live, tw, sn);
   if (SOLVE) {
     if (live) {
       const double *lx = g.lam[0], *ly = g.lam[1], *lz = g.lam[2];
@@ -369,16 +445,16 @@ k_dst_s(BoxGrid g, DstPlan P, double *__restrict__ G) {
       const double lxy0 = lx[kx] + ly[outer + 1];
       const double lxy1 = (kx + 1 < g.L[0] ? lx[kx + 1] : lx[kx]) + ly[outer + 1];
       for (int k = t + 1; k < L; k += P.tp) {
-        const double2 F = w[ZP(k)];
+        const C2<T> F = w[ZP(k)];
         const double lzk = lz[k];
-        w[ZP(k)] = make_double2(F.x * g.scale / (lxy0 + lzk), F.y * g.scale / (lxy1 + lzk));
+        w[ZP(k)] = mk<T>((T)((double)F.x * g.scale / (lxy0 + lzk)), (T)((double)F.y * g.scale / (lxy1 + lzk)));
       }
     }
     __syncthreads();
-    dst_core(w, scr, P, t, live);
+    dst_core<T>(w, scr, P, t, live, tw, sn);
   }
   if (tcol < ncols) {
-    const double *wc = reinterpret_cast<const double *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
+    const T *wc = reinterpret_cast<const T *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
     for (int row = row0; row < len; row += rstep) G[base + row * estride + tcol] = wc[2 * ZP(row + 1)];
   }
 }
@@ -387,7 +463,8 @@ k_dst_s(BoxGrid g, DstPlan P, double *__restrict__ G) {
 struct phx_box_precond {
   BoxGrid g;
   DstPlan plan[3];
-  double *G = nullptr;
+  void *G = nullptr;         // lattice array, f32 or f64
+  bool f32 = true;           // precision of the lattice array and the transforms
   int32_t *gmap = nullptr;   // [plane * m2] solver position of the u DoF, -1 none
   double *dscale = nullptr;  // [n] diag of A in solver order
   double *vec = nullptr;     // [2 n] preconditioned directions of the library-owned workspace
@@ -403,20 +480,27 @@ static void box_precond_free(phx_box_precond *bp) {
   delete bp;
 }
 
+template <typename T>
+static int dst_allow_lds_t() {
+  const int bytes = 96 * 1024;  // padded transform data + scan scratch may exceed the 64 KB default
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<T, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<T, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return PHX_OK;
+}
 static int dst_allow_lds() {
   static bool done = false;
   if (done) return PHX_OK;
-  const int bytes = 96 * 1024;  // 4096 padded complex doubles + scan scratch: above the 64 KB default
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<0>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_CHECK(dst_allow_lds_t<double>());
+  PHX_CHECK(dst_allow_lds_t<float>());
   done = true;
   return PHX_OK;
 }
 
-static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const double h[3]) {
+static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const double h[3], bool f32) {
+  bp->f32 = f32;
   PHX_CHECK(dst_allow_lds());
   BoxGrid &g = bp->g;
   for (int a = 0; a < 3; ++a) {
@@ -436,50 +520,51 @@ static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const
     PHX_HIP(hipMemcpy(bp->lam[a], lam.data(), sizeof(double) * (size_t)L[a], hipMemcpyHostToDevice));
     g.lam[a] = bp->lam[a];
   }
-  PHX_HIP(phx_malloc(&bp->G, sizeof(double) * (size_t)(g.plane * g.m[2])));
+  PHX_HIP(phx_malloc(&bp->G, (f32 ? sizeof(float) : sizeof(double)) * (size_t)(g.plane * g.m[2])));
   return PHX_OK;
 }
 
 // the three middle passes (y, z with the spectral solve, y) on G
-static int box_solve_middle(phx_box_precond *bp, hipStream_t st, phx_system *prof = nullptr) {
+template <typename T>
+static int box_solve_middle_t(phx_box_precond *bp, hipStream_t st, phx_system *prof) {
   const BoxGrid &g = bp->g;
   const DstPlan &py = bp->plan[1], &pz = bp->plan[2];
-  {
-    const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
-    const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.tp));
-    const size_t lds = (size_t)py.lds;
-    if (prof) PHX_CHECK(prof_begin(prof, 1));
-    k_dst_s<1, false><<<grid, block, lds, st>>>(g, py, bp->G);
-    if (prof) PHX_CHECK(prof_end(prof, 1));
-  }
-  {
-    const int W = 2 * pz.pairs, ncb = (g.m[0] + W - 1) / W;
-    const dim3 grid((unsigned)((int64_t)ncb * g.m[1])), block((unsigned)(pz.pairs * pz.tp));
-    const size_t lds = (size_t)pz.lds;
-    k_dst_s<2, true><<<grid, block, lds, st>>>(g, pz, bp->G);
-  }
-  {
-    const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
-    const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.tp));
-    const size_t lds = (size_t)py.lds;
-    if (prof) PHX_CHECK(prof_begin(prof, 1));
-    k_dst_s<1, false><<<grid, block, lds, st>>>(g, py, bp->G);
-    if (prof) PHX_CHECK(prof_end(prof, 1));
+  T *G = static_cast<T *>(bp->G);
+  const size_t el = sizeof(T) * 2;  // LDS bytes per complex value
+  for (int pass = 0; pass < 3; ++pass) {
+    if (pass == 1) {
+      const int W = 2 * pz.pairs, ncb = (g.m[0] + W - 1) / W;
+      const dim3 grid((unsigned)((int64_t)ncb * g.m[1])), block((unsigned)(pz.pairs * pz.tp));
+      k_dst_s<T, 2, true><<<grid, block, (size_t)pz.lds_elems * el, st>>>(g, pz, G);
+    } else {
+      const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
+      const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.tp));
+      if (prof) PHX_CHECK(prof_begin(prof, 1));
+      k_dst_s<T, 1, false><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
+      if (prof) PHX_CHECK(prof_end(prof, 1));
+    }
   }
   PHX_HIP(hipGetLastError());
   return PHX_OK;
 }
+static int box_solve_middle(phx_box_precond *bp, hipStream_t st, phx_system *prof = nullptr) {
+  return bp->f32 ? box_solve_middle_t<float>(bp, st, prof) : box_solve_middle_t<double>(bp, st, prof);
+}
 
-template <int IO>
-static int box_pass_x(phx_box_precond *bp, hipStream_t st, const double *vin, double *vout) {
+template <typename T, int IO>
+static int box_pass_x_t(phx_box_precond *bp, hipStream_t st, const double *vin, double *vout) {
   const BoxGrid &g = bp->g;
   const DstPlan &px = bp->plan[0];
   const int64_t npairs = ((int64_t)g.m[1] * g.m[2] + 1) / 2;
   const dim3 grid((unsigned)phx_div_up(npairs, px.pairs)), block((unsigned)(px.pairs * px.tp));
-  const size_t lds = (size_t)px.lds;
-  k_dst_x<IO><<<grid, block, lds, st>>>(g, px, bp->G, bp->gmap, vin, vout, bp->dscale);
+  k_dst_x<T, IO><<<grid, block, (size_t)px.lds_elems * sizeof(T) * 2, st>>>(
+      g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, bp->dscale);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
+}
+template <int IO>
+static int box_pass_x(phx_box_precond *bp, hipStream_t st, const double *vin, double *vout) {
+  return bp->f32 ? box_pass_x_t<float, IO>(bp, st, vin, vout) : box_pass_x_t<double, IO>(bp, st, vin, vout);
 }
 
 void phx_box_precond_destroy(phx_box_precond *bp) { box_precond_free(bp); }
@@ -566,7 +651,7 @@ static int box_precond_setup(phx_system *s) {
     lo[a] = hbb[a] - 1 - (L[a] - 1 - extent) / 2;
   }
   phx_box_precond *bp = new phx_box_precond();
-  int rc = box_grid_setup(bp, m->device, L, m->box_h);
+  int rc = box_grid_setup(bp, m->device, L, m->box_h, m->precond == 1);
   if (rc != PHX_OK) { box_precond_free(bp); return rc; }
   for (int a = 0; a < 3; ++a) bp->lo[a] = lo[a];
   const int64_t tot = bp->g.plane * bp->g.m[2];
@@ -598,31 +683,38 @@ static int box_precond_apply(phx_system *s, const double *vin, double *vout) {
 }
 
 // Test / inspection entry: solve K_box u = f on an (L0-1) x (L1-1) x (L2-1) interior lattice with spacings h
-// (x fastest, no padding in `f`); u overwrites f.
-extern "C" int phx_box_poisson_solve(int device, const int *L, const double *h, double *f_host) {
+// (x fastest, no padding in `f`) in f64 (f32 = 0) or f32 transforms; u overwrites f.
+extern "C" int phx_box_poisson_solve(int device, const int *L, const double *h, int f32, double *f_host) {
   PHX_HIP(hipSetDevice(device));
   for (int a = 0; a < 3; ++a)
     PHX_REQUIRE(dst_pick_length(L[a]) == L[a], PHX_ERR_VALUE, "L[%d] = %d is not a supported transform length", a, L[a]);
   phx_box_precond *bp = new phx_box_precond();
-  int rc = box_grid_setup(bp, device, L, h);
+  int rc = box_grid_setup(bp, device, L, h, f32 != 0);
   if (rc != PHX_OK) { box_precond_free(bp); return rc; }
   const BoxGrid &g = bp->g;
-  const size_t bytes = sizeof(double) * (size_t)(g.plane * g.m[2]);
-  std::vector<double> tmp((size_t)(g.plane * g.m[2]), 0.0);
+  const size_t tot = (size_t)(g.plane * g.m[2]);
+  std::vector<double> tmp(tot, 0.0);
   for (int64_t z = 0; z < g.m[2]; ++z)
     for (int64_t y = 0; y < g.m[1]; ++y)
       memcpy(&tmp[z * g.plane + y * g.pitch], &f_host[(z * g.m[1] + y) * g.m[0]], sizeof(double) * (size_t)g.m[0]);
+  std::vector<float> tmpf;
+  if (f32) { tmpf.resize(tot); for (size_t i = 0; i < tot; ++i) tmpf[i] = (float)tmp[i]; }
+  const void *src = f32 ? (const void *)tmpf.data() : (const void *)tmp.data();
+  const size_t bytes = (f32 ? sizeof(float) : sizeof(double)) * tot;
   hipStream_t st = nullptr;
-  if (hipMemcpy(bp->G, tmp.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+  if (hipMemcpy(bp->G, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
   rc = box_pass_x<0>(bp, st, nullptr, nullptr);
   if (rc == PHX_OK) rc = box_solve_middle(bp, st);
   if (rc == PHX_OK) rc = box_pass_x<0>(bp, st, nullptr, nullptr);
   if (rc == PHX_OK && hipDeviceSynchronize() != hipSuccess) rc = PHX_ERR_HIP;
-  if (rc == PHX_OK && hipMemcpy(tmp.data(), bp->G, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = PHX_ERR_HIP;
-  if (rc == PHX_OK)
+  void *dst = f32 ? (void *)tmpf.data() : (void *)tmp.data();
+  if (rc == PHX_OK && hipMemcpy(dst, bp->G, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = PHX_ERR_HIP;
+  if (rc == PHX_OK) {
+    if (f32) for (size_t i = 0; i < tot; ++i) tmp[i] = (double)tmpf[i];
     for (int64_t z = 0; z < g.m[2]; ++z)
       for (int64_t y = 0; y < g.m[1]; ++y)
         memcpy(&f_host[(z * g.m[1] + y) * g.m[0]], &tmp[z * g.plane + y * g.pitch], sizeof(double) * (size_t)g.m[0]);
+  }
   box_precond_free(bp);
   return rc;
 }

@@ -808,7 +808,7 @@ extern "C" int phx_krylov_profile(phx_system *s, int reset, double *avg_seconds,
 }
 
 // out[8] = {preconditioner active (0/1), transform lengths L0, L1, L2, stored lattice points of the box,
-//           sampled average seconds of a y-pass launch, launches sampled, y-pass launches per application (2)}
+//           sampled average seconds of a y-pass launch, launches sampled, bytes per lattice value (4 / 8)}
 extern "C" int phx_precond_info(phx_system *s, double *out) {
   for (int i = 0; i < 8; ++i) out[i] = 0.0;
   if (s->precond_state != 1) return PHX_OK;
@@ -821,7 +821,7 @@ extern "C" int phx_precond_info(phx_system *s, double *out) {
   PHX_CHECK(prof_collect(s, &avg, &cnt, 1));
   out[5] = avg;
   out[6] = (double)cnt;
-  out[7] = 2.0;
+  out[7] = s->precond->f32 ? 4.0 : 8.0;
   return PHX_OK;
 }
 
@@ -832,10 +832,12 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
   PHX_REQUIRE(method == PHX_BICGSTAB_JACOBI, PHX_ERR_NOT_IMPLEMENTED, "unknown method %d", method);
   hipStream_t st = m->stream;
   double *S = kr_scal(s);
-  const int check_every = 8;
   PHX_CHECK(prof_reset(s));
   PHX_CHECK(phx_begin_timing(m));
   PHX_CHECK(kr_phase(s, 0, 0, 0));
+  // the host looks at the residual every 8th iteration (one ~50 us round trip), every 2nd when the
+  // iterations are few and expensive
+  const int check_every = s->precond_state == 1 ? 2 : 8;
   PHX_CHECK(kr_phase(s, 1, 0, 0));
   PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
   PHX_HIP(hipStreamSynchronize(st));

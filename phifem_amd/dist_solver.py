@@ -215,6 +215,7 @@ class DistributedSolver:
         # with a rank-local block preconditioner the SpMV inputs are phat = P p, shat = P s
         pc = getattr(b, "precond_active", lambda: False)()
         vp, vs = (self.phat, self.shat) if pc else (self.p, self.s)
+        check_every = 2 if pc else self.check_every
         while bb != 0.0 and it < self.max_iter:
             if pc:
                 b.phase(7)
@@ -230,7 +231,7 @@ class DistributedSolver:
             b.phase(5)
             self._allreduce(R_RHO, R_RR + 1)
             it += 1
-            if it % self.check_every == 0 or it == self.max_iter:
+            if it % check_every == 0 or it == self.max_iter:
                 rr = float(self.scal[R_OFF + R_RR].item())
                 relres = (rr / bb) ** 0.5
                 if not np.isfinite(rr):

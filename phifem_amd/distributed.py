@@ -98,7 +98,8 @@ class SlabProblem:
             # sine-transform y pass of the preconditioner: reads and writes every lattice point once
             "precond": pc["precond"], "precond_L": pc["precond_L"],
             "dst_avg_s": pc["dst_avg_s"], "dst_count": pc["dst_timed"],
-            "dst_algorithmic_bytes": 16.0 * pc["precond_points"],
+            "dst_algorithmic_bytes": 2.0 * pc["precond_value_bytes"] * pc["precond_points"],
+            "precond_value_bytes": pc["precond_value_bytes"],
         }
 
 
@@ -168,5 +169,6 @@ class ElasticitySlabProblem(SlabProblem):
             # sine-transform y pass of the preconditioner: reads and writes every lattice point once
             "precond": pc["precond"], "precond_L": pc["precond_L"],
             "dst_avg_s": pc["dst_avg_s"], "dst_count": pc["dst_timed"],
-            "dst_algorithmic_bytes": 16.0 * pc["precond_points"],
+            "dst_algorithmic_bytes": 2.0 * pc["precond_value_bytes"] * pc["precond_points"],
+            "precond_value_bytes": pc["precond_value_bytes"],
         }

@@ -123,7 +123,8 @@ class PhiFEMSolver:
         o = (C.c_double * 8)()
         L.check(L.lib.phx_precond_info(self._sys, o))
         return {"precond": "box-dst" if o[0] else "jacobi", "precond_L": [int(o[1]), int(o[2]), int(o[3])],
-                "precond_points": int(o[4]), "dst_avg_s": o[5], "dst_timed": int(o[6])}
+                "precond_points": int(o[4]), "dst_avg_s": o[5], "dst_timed": int(o[6]),
+                "precond_value_bytes": int(o[7])}
 
     def spmv(self, x):
         y = np.empty_like(x)
