@@ -35,7 +35,7 @@ struct DstPlan {
   float *sintab_f = nullptr;
 };
 
-static std::map<std::pair<int, int>, DstPlan> g_dst_plans;  // (device, L) -> plan
+static std::map<std::pair<int, int>, DstPlan> g_dst_plans;  // (device, L or -L for f32 tiles) -> plan
 
 // L = 2^a 3^b, b <= 1, 64 <= L <= 1024
 static int dst_pick_length(int64_t need) {
@@ -50,8 +50,8 @@ static int dst_pick_length(int64_t need) {
 #define ZP(n) ((n) + ((n) >> 3))
 #define ZLEN(N) ((N) + ((N) >> 3) + 1)
 
-static int dst_get_plan(int device, int L, DstPlan *out) {
-  auto key = std::make_pair(device, L);
+static int dst_get_plan(int device, int L, bool f32, DstPlan *out) {
+  auto key = std::make_pair(device, f32 ? -L : L);
   auto it = g_dst_plans.find(key);
   if (it != g_dst_plans.end()) { *out = it->second; return PHX_OK; }
   DstPlan P;
@@ -72,13 +72,14 @@ static int dst_get_plan(int device, int L, DstPlan *out) {
     pp *= P.radix[st];
   }
   P.tp = L / 8;
-  // pairs per block: a power of two (W = 2 pairs adjacent columns per strided tile), at most 512 threads
+  // pairs per block: a power of two (W = 2 pairs adjacent columns per strided tile), at most 512 threads (1024 for the long transforms)
   // and ~40 KB of LDS so that four blocks share a CU (measured at L = 192: 16 pairs 41.7 ms per solve,
   // 8 pairs 37.1, 4 pairs 41.3); the long transforms get 80 KB to keep W >= 8
-  int budget = (L >= 768 ? 80 : 40) * 1024;
+  int budget = (L >= 768 ? 80 : (f32 ? 20 : 40)) * 1024;  // f32, L = 192: 8 pairs 28.3 ms per solve, 16 pairs 29.7
   if (const char *e = getenv("PHX_DST_LDS_KB")) budget = atoi(e) > 0 ? atoi(e) * 1024 : budget;  // tuning aid
   P.pairs = 1;
-  while ((2 * P.pairs * ZLEN(L) + 2 * L) * (int)sizeof(double2) <= budget && 2 * P.pairs * P.tp <= 512) P.pairs *= 2;
+  const int el = f32 ? (int)sizeof(float2) : (int)sizeof(double2);
+  while ((2 * P.pairs * ZLEN(L) + 2 * L) * el <= budget && 2 * P.pairs * P.tp <= (L >= 768 ? 1024 : 512)) P.pairs *= 2;
   P.scr = P.tp + (P.tp + 7) / 8 + 1;
   P.tab_off = P.pairs * (ZLEN(L) + P.scr);            // LDS copies of the tables: twiddles, then sines
   P.lds_elems = P.tab_off + L + (L / 2 + 2 + 1) / 2;
@@ -305,7 +306,7 @@ struct BoxGrid {
 // lattice point, -1: none); IO = 2: the result is scattered out the same way, times dscale.
 // T: precision of the lattice array and of the transform (the Krylov vectors stay f64).
 template <typename T, int IO>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(1024)
 k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gmap,
         const double *__restrict__ vin, double *__restrict__ vout, const double *__restrict__ dscale) {
   extern __shared__ double2 zs_raw[];
@@ -399,7 +400,7 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
 // global access is a run of W consecutive values.  AXIS = 1: lines along y (outer = z), AXIS = 2: lines
 // along z (outer = y).  SOLVE (z only): forward transform, times scale / lambda, inverse transform, all in LDS.
 template <typename T, int AXIS, bool SOLVE>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(1024)
 k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
   extern __shared__ double2 zs_raw[];
   C2<T> *zs = reinterpret_cast<C2<T> *>(zs_raw);
@@ -506,7 +507,7 @@ static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const
   for (int a = 0; a < 3; ++a) {
     g.L[a] = L[a];
     g.m[a] = L[a] - 1;
-    PHX_CHECK(dst_get_plan(device, L[a], &bp->plan[a]));
+    PHX_CHECK(dst_get_plan(device, L[a], f32, &bp->plan[a]));
   }
   g.pitch = L[0];
   g.plane = g.pitch * g.m[1];
