@@ -470,6 +470,8 @@ struct phx_box_precond {
   double *dscale = nullptr;  // [n] diag of A in solver order
   double *vec = nullptr;     // [2 n] preconditioned directions of the library-owned workspace
   const uint8_t *own_ptr = nullptr;  // ownership mask the maps were built for
+  int32_t *rest = nullptr;   // solver positions of the rows outside the u block (identity part of P)
+  int64_t nrest = 0;
   double *lam[3] = {nullptr, nullptr, nullptr};
   int lo[3] = {0, 0, 0};     // lattice index of the lower Dirichlet face
 };
@@ -477,6 +479,7 @@ struct phx_box_precond {
 static void box_precond_free(phx_box_precond *bp) {
   if (!bp) return;
   (void)phx_free(bp->G); (void)phx_free(bp->gmap); (void)phx_free(bp->dscale); (void)phx_free(bp->vec);
+  (void)phx_free(bp->rest);
   for (int a = 0; a < 3; ++a) (void)phx_free(bp->lam[a]);
   delete bp;
 }
@@ -621,6 +624,14 @@ __global__ void k_box_gmap(BoxGrid g, int lo0, int lo1, int lo2, int64_t n0, int
   gmap[e] = q;
 }
 
+struct SelNotU { const int32_t *perm; int32_t nu; __host__ __device__ bool operator()(const int32_t &i) const { return perm[i] >= nu; } };
+
+__global__ void k_copy_list(int64_t n, const int32_t *__restrict__ list, const double *__restrict__ vin,
+                            double *__restrict__ vout) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) { const int32_t q = list[i]; vout[q] = vin[q]; }
+}
+
 __global__ void k_dscale(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ diag,
                          double *__restrict__ dscale) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -666,6 +677,11 @@ static int box_precond_setup(phx_system *s) {
       bp->g, lo[0], lo[1], lo[2], n0, n1, n2, s->dof_of_vertex_u, s->iperm, s->own, bp->gmap);
   k_dscale<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(s->n, s->perm, s->diag, bp->dscale);
   if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+  // rows outside the u block (active rows are numbered u first): P is the identity there.  The other
+  // entries of phat / shat (u rows this rank does not own) are never written and stay zero.
+  rc = phx_select_indices(st, s->n, SelNotU{s->perm, (int32_t)s->nu}, &bp->rest, &bp->nrest);
+  if (rc != PHX_OK) { box_precond_free(bp); return rc; }
+  if (hipMemsetAsync(bp->vec, 0, sizeof(double) * (size_t)s->n * 2, st) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
   bp->own_ptr = s->own;
   s->precond = bp;
   s->precond_state = 1;
@@ -676,7 +692,8 @@ static int box_precond_setup(phx_system *s) {
 static int box_precond_apply(phx_system *s, const double *vin, double *vout) {
   phx_box_precond *bp = s->precond;
   hipStream_t st = s->mesh->stream;
-  PHX_HIP(hipMemcpyAsync(vout, vin, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToDevice, st));
+  if (bp->nrest > 0)
+    k_copy_list<<<dim3((unsigned)phx_div_up(bp->nrest, 256)), dim3(256), 0, st>>>(bp->nrest, bp->rest, vin, vout);
   PHX_CHECK(box_pass_x<1>(bp, st, vin, nullptr));
   PHX_CHECK(box_solve_middle(bp, st, s));
   PHX_CHECK(box_pass_x<2>(bp, st, nullptr, vout));

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "phx_common.h"
+#include "phx_select.h"
 
 #define SELL_C 64
 // Rows per length-sorting window.  Measured on the 256^3 system (2.9 M rows): no sort 180 us,
