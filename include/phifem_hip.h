@@ -149,6 +149,9 @@ int phx_set_option(phx_mesh *m, int option, int64_t value);
  * L_a in {64, 96, 128, 192, 256, 384, 512, 768, 1024}.  u overwrites f (host).
  * This is the kernel sequence of the fictitious-domain preconditioner (PHX_OPT_PRECOND), exposed for tests. */
 int phx_box_poisson_solve(int device, const int *L, const double *h, int f32, double *f_host);
+/* Timing aid: average microseconds of the x, y and z (forward + divide + inverse) transform passes on an
+ * (L0-1) x (L1-1) x (L2-1) lattice (tools/dst_bench.py). */
+int phx_box_dst_bench(int device, const int *L, int f32, int reps, double *out_us3);
 /* Mean elapsed time of an empty HIP event pair on the mesh stream: the cost the bracketing of
  * PHX_OPT_PROFILE_SPMV adds to each timed launch (measurement aid of bench.py). */
 int phx_event_pair_overhead(phx_mesh *m, double *seconds);

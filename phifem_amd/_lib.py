@@ -59,6 +59,7 @@ SIGNATURES = {
     "phx_set_option": ([_vp, _i, _i64], _i),
     "phx_event_pair_overhead": ([_vp, _pd], _i),
     "phx_box_poisson_solve": ([_i, _pi, _pd, _i, _vp], _i),
+    "phx_box_dst_bench": ([_i, _pi, _i, _i, _pd], _i),
     "phx_mesh_tag_histogram": ([_vp, _pi64, _pi64], _i),
     "phx_krylov_precond_active": ([_vp, _pi], _i),
     "phx_precond_info": ([_vp, _pd], _i),

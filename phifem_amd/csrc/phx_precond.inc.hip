@@ -27,6 +27,7 @@ struct DstPlan {
   int L = 0, nstage = 0, pairs = 0, tp = 0;  // pairs per block, threads per pair (L / 8)
   int radix[8], pw[8], tws[8];  // per stage: radix R, sub-transform size p so far (a power of two), L / (p R)
   int scr = 0;                  // scan scratch per pair (complex doubles)
+  int dbg = 0;                  // tuning aid (PHX_DST_DEBUG): 1 skips the transforms, 2 the global loads / stores
   int tab_off = 0;              // offset (complex values) of the table copies in LDS
   int lds_elems = 0;            // complex values of dynamic LDS per block
   double2 *tw = nullptr;        // device, exp(-2 pi i j / L), j < L
@@ -80,6 +81,7 @@ static int dst_get_plan(int device, int L, bool f32, DstPlan *out) {
   P.pairs = 1;
   const int el = f32 ? (int)sizeof(float2) : (int)sizeof(double2);
   while ((2 * P.pairs * ZLEN(L) + 2 * L) * el <= budget && 2 * P.pairs * P.tp <= (L >= 768 ? 1024 : 512)) P.pairs *= 2;
+  if (const char *e = getenv("PHX_DST_DEBUG")) P.dbg = atoi(e);
   P.scr = P.tp + (P.tp + 7) / 8 + 1;
   P.tab_off = P.pairs * (ZLEN(L) + P.scr);            // LDS copies of the tables: twiddles, then sines
   P.lds_elems = P.tab_off + L + (L / 2 + 2 + 1) / 2;
@@ -429,7 +431,7 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = row0 + i * rstep;
-      vv[i] = (row < len && tcol < ncols) ? G[base + row * estride + tcol] : T(0);
+      vv[i] = (row < len && tcol < ncols && P.dbg != 2) ? G[base + row * estride + tcol] : T(0);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -438,8 +440,8 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
     }
   }
   __syncthreads();
-  dst_core<T>(w, scr, P, t, live, tw, sn);
-  if (SOLVE) {
+  if (P.dbg != 1) dst_core<T>(w, scr, P, t, live, tw, sn);
+  if (SOLVE && P.dbg != 1) {
     if (live) {
       const double *lx = g.lam[0], *ly = g.lam[1], *lz = g.lam[2];
       const int kx = col0 + 2 * pr + 1;
@@ -456,7 +458,8 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
   }
   if (tcol < ncols) {
     const T *wc = reinterpret_cast<const T *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
-    for (int row = row0; row < len; row += rstep) G[base + row * estride + tcol] = wc[2 * ZP(row + 1)];
+    if (P.dbg != 2 || wc[0] == T(12345))
+      for (int row = row0; row < len; row += rstep) G[base + row * estride + tcol] = wc[2 * ZP(row + 1)];
   }
 }
 
@@ -733,6 +736,51 @@ extern "C" int phx_box_poisson_solve(int device, const int *L, const double *h, 
       for (int64_t y = 0; y < g.m[1]; ++y)
         memcpy(&f_host[(z * g.m[1] + y) * g.m[0]], &tmp[z * g.plane + y * g.pitch], sizeof(double) * (size_t)g.m[0]);
   }
+  box_precond_free(bp);
+  return rc;
+}
+
+// Timing aid (tools/dst_bench.py): average microseconds of the x, y, z (solve) passes on a zero lattice.
+extern "C" int phx_box_dst_bench(int device, const int *L, int f32, int reps, double *out_us3) {
+  PHX_HIP(hipSetDevice(device));
+  for (int a = 0; a < 3; ++a)
+    PHX_REQUIRE(dst_pick_length(L[a]) == L[a], PHX_ERR_VALUE, "L[%d] = %d is not a supported transform length", a, L[a]);
+  phx_box_precond *bp = new phx_box_precond();
+  const double h[3] = {1.0, 1.0, 1.0};
+  int rc = box_grid_setup(bp, device, L, h, f32 != 0);
+  if (rc != PHX_OK) { box_precond_free(bp); return rc; }
+  const BoxGrid &g = bp->g;
+  const size_t bytes = (f32 ? sizeof(float) : sizeof(double)) * (size_t)(g.plane * g.m[2]);
+  (void)hipMemset(bp->G, 0, bytes);
+  hipStream_t st = nullptr;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int which = 0; which < 3 && rc == PHX_OK; ++which) {
+    auto run = [&]() -> int {
+      if (which == 0) return box_pass_x<0>(bp, st, nullptr, nullptr);
+      const DstPlan &P = bp->plan[which];
+      const int W = 2 * P.pairs, ncb = (g.m[0] + W - 1) / W;
+      const dim3 grid((unsigned)((int64_t)ncb * g.m[which == 1 ? 2 : 1])), block((unsigned)(P.pairs * P.tp));
+      const size_t lds = (size_t)P.lds_elems * (f32 ? sizeof(float2) : sizeof(double2));
+      if (f32) {
+        if (which == 1) k_dst_s<float, 1, false><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
+        else k_dst_s<float, 2, true><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
+      } else {
+        if (which == 1) k_dst_s<double, 1, false><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
+        else k_dst_s<double, 2, true><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
+      }
+      return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_HIP;
+    };
+    for (int i = 0; i < 3 && rc == PHX_OK; ++i) rc = run();
+    (void)hipEventRecord(e0, st);
+    for (int i = 0; i < reps && rc == PHX_OK; ++i) rc = run();
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    out_us3[which] = 1e3 * ms / reps;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   box_precond_free(bp);
   return rc;
 }
