@@ -25,6 +25,8 @@
 
 struct DstPlan {
   int L = 0, nstage = 0, pairs = 0, tp = 0;  // pairs per block, threads per pair (L / 8)
+  int slot = 0;                 // lanes reserved per pair: tp, or 32 / 64 when the pair lives inside one wave
+  int wave = 0;                 // 1: pairs never straddle a wavefront (wave-local synchronisation)
   int radix[8], pw[8], tws[8];  // per stage: radix R, sub-transform size p so far (a power of two), L / (p R)
   int scr = 0;                  // scan scratch per pair (complex doubles)
   int dbg = 0;                  // tuning aid (PHX_DST_DEBUG): 1 skips the transforms, 2 the global loads / stores
@@ -73,14 +75,25 @@ static int dst_get_plan(int device, int L, bool f32, DstPlan *out) {
     pp *= P.radix[st];
   }
   P.tp = L / 8;
-  // pairs per block: a power of two (W = 2 pairs adjacent columns per strided tile), at most 512 threads (1024 for the long transforms)
-  // and ~40 KB of LDS so that four blocks share a CU (measured at L = 192: 16 pairs 41.7 ms per solve,
-  // 8 pairs 37.1, 4 pairs 41.3); the long transforms get 80 KB to keep W >= 8
-  int budget = (L >= 768 ? 80 : (f32 ? 20 : 40)) * 1024;  // f32, L = 192: 8 pairs 28.3 ms per solve, 16 pairs 29.7
-  if (const char *e = getenv("PHX_DST_LDS_KB")) budget = atoi(e) > 0 ? atoi(e) * 1024 : budget;  // tuning aid
-  P.pairs = 1;
+  // A pair whose L / 8 threads fill a 32- or 64-lane slot of one wavefront synchronises wave-locally inside
+  // a transform, and the block can then be as wide as the memory system likes: W = 2 pairs adjacent columns
+  // per strided tile (memory phase alone at 192^3, f32: 32-byte rows 31 us, 64-byte 18.9, 128-byte 12.6).
+  // Measured, block -> wave mode (x / y / z pass, us): L = 256: 42/66/88 -> 38/43/70; 512x512x128 (y): 263 -> 86.
+  // Only where no lane idles (L = 256, 512): at L = 192 / 384 / 128 the 25-50 % empty slot lanes cost as
+  // much issue time as the barriers save (the transforms are VALU/LDS-issue bound).
+  P.wave = (P.tp == 32 || P.tp == 64) ? 1 : 0;
+  if (const char *e = getenv("PHX_DST_WAVE")) P.wave = (P.tp <= 64) && atoi(e) != 0;  // tuning aid
+  P.slot = P.wave ? (P.tp <= 32 ? 32 : 64) : P.tp;
   const int el = f32 ? (int)sizeof(float2) : (int)sizeof(double2);
-  while ((2 * P.pairs * ZLEN(L) + 2 * L) * el <= budget && 2 * P.pairs * P.tp <= (L >= 768 ? 1024 : 512)) P.pairs *= 2;
+  int budget = (P.wave ? 64 : (L >= 768 ? 80 : (f32 ? 20 : 40))) * 1024;
+  int max_threads = P.wave ? 1024 : (L >= 768 ? 1024 : 512);
+  int max_pairs = P.wave ? (f32 ? 16 : 8) : 1024;
+  if (const char *e = getenv("PHX_DST_LDS_KB")) budget = atoi(e) > 0 ? atoi(e) * 1024 : budget;  // tuning aids
+  if (const char *e = getenv("PHX_DST_PAIRS")) max_pairs = atoi(e) > 0 ? atoi(e) : max_pairs;
+  P.pairs = 1;
+  while ((2 * P.pairs * ZLEN(L) + 2 * L) * el <= budget && 2 * P.pairs * P.slot <= max_threads &&
+         2 * P.pairs <= max_pairs)
+    P.pairs *= 2;
   if (const char *e = getenv("PHX_DST_DEBUG")) P.dbg = atoi(e);
   P.scr = P.tp + (P.tp + 7) / 8 + 1;
   P.tab_off = P.pairs * (ZLEN(L) + P.scr);            // LDS copies of the tables: twiddles, then sines
@@ -157,9 +170,21 @@ template <> struct PlanTab<float> {
   static __device__ __forceinline__ const float *sn(const DstPlan &P) { return P.sintab_f; }
 };
 
+// Synchronisation among the threads of ONE pair.  WAVE: the pair's threads sit inside a single wavefront
+// (plan.slot = 32 or 64 lanes per pair), LDS operations of a wave execute in order, so a compiler fence is
+// all that is needed; otherwise the pair spans wavefronts and the whole block meets at a barrier.
+template <bool WAVE> __device__ __forceinline__ void psync() {
+  if (WAVE) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
+
 // one Stockham stage of radix R on the L-point sequence `z` of this pair: `t` = thread within the pair.
 // All inputs are read into registers, the block synchronises, then the outputs are written in place.
-template <typename T, int R>
+template <typename T, int R, bool WAVE>
 __device__ __forceinline__ void fft_stage(C2<T> *z, int nb, int tp, int t, int p, int tws,
                                           const C2<T> *__restrict__ tw) {
   constexpr int MAXB = (8 + R - 1) / R;
@@ -182,7 +207,7 @@ __device__ __forceinline__ void fft_stage(C2<T> *z, int nb, int tp, int t, int p
       else dft2(u[b]);
     }
   }
-  __syncthreads();
+  psync<WAVE>();
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
     const int i = t + b * tp;
@@ -193,27 +218,27 @@ __device__ __forceinline__ void fft_stage(C2<T> *z, int nb, int tp, int t, int p
       for (int q = 0; q < R; ++q) z[ZP(j + q * p)] = u[b][q];
     }
   }
-  __syncthreads();
+  psync<WAVE>();
 }
 
 // forward complex FFT of this pair's sequence `z` in LDS.  Every thread of the block must call it (block
 // barriers inside); threads of an idle pair slot pass live = false and do no work.
-template <typename T>
+template <typename T, bool WAVE>
 __device__ __forceinline__ void fft_pairs(C2<T> *z, const DstPlan &P, int t, bool live, const C2<T> *tw) {
   const int tt = live ? t : P.L;  // empty butterfly range
   for (int s = 0; s < P.nstage; ++s) {
     const int R = P.radix[s], p = P.pw[s], tws = P.tws[s];
-    if (R == 8) fft_stage<T, 8>(z, P.L >> 3, P.tp, tt, p, tws, tw);
-    else if (R == 4) fft_stage<T, 4>(z, P.L >> 2, P.tp, tt, p, tws, tw);
-    else if (R == 3) fft_stage<T, 3>(z, tws * p, P.tp, tt, p, tws, tw);  // L / 3 butterflies
-    else fft_stage<T, 2>(z, P.L >> 1, P.tp, tt, p, tws, tw);
+    if (R == 8) fft_stage<T, 8, WAVE>(z, P.L >> 3, P.tp, tt, p, tws, tw);
+    else if (R == 4) fft_stage<T, 4, WAVE>(z, P.L >> 2, P.tp, tt, p, tws, tw);
+    else if (R == 3) fft_stage<T, 3, WAVE>(z, tws * p, P.tp, tt, p, tws, tw);  // L / 3 butterflies
+    else fft_stage<T, 2, WAVE>(z, P.L >> 1, P.tp, tt, p, tws, tw);
   }
 }
 
 // In:  w[ZP(j)] = (a_j, b_j), j = 1 .. L-1 (w[0] arbitrary).   Out: w[ZP(k)] = (F^a_k, F^b_k), k = 1 .. L-1,
 // F_k = sum_j x_j sin(pi j k / L).  `scr`: tp + tp/8 + 1 complex values of scan scratch of this pair.
 // Block-wide barriers inside: every thread of the block calls it.
-template <typename T>
+template <typename T, bool WAVE>
 __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P, int t, bool live,
                                          const C2<T> *tw, const T *sn) {
   const int L = P.L, tp = P.tp, H = L >> 1;
@@ -233,8 +258,8 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
       w[ZP(H)] = mk<T>(X.x + X.x, X.y + X.y);
     }
   }
-  __syncthreads();
-  fft_pairs<T>(w, P, t, live, tw);
+  psync<WAVE>();
+  fft_pairs<T, WAVE>(w, P, t, live, tw);
   // thread t owns k = 4 t .. 4 t + 3  (k < L / 2)
   C2<T> Wk[4], Wm[4], c[4];
   if (live) {
@@ -245,7 +270,7 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
       Wm[i] = w[ZP(k == 0 ? 0 : L - k)];
     }
   }
-  __syncthreads();
+  psync<WAVE>();
   C2<T> *tot = scr, *gt = scr + tp;
   if (live) {
     C2<T> run = mk<T>(T(0), T(0));
@@ -264,13 +289,13 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
     }
     tot[t] = run;
   }
-  __syncthreads();
+  psync<WAVE>();
   if (live && t < (tp + 7) / 8) {
     C2<T> g = mk<T>(T(0), T(0));
     for (int q = 8 * t; q < min(8 * t + 8, tp); ++q) g = cadd(g, tot[q]);
     gt[t] = g;
   }
-  __syncthreads();
+  psync<WAVE>();
   if (live) {
     C2<T> E = mk<T>(T(0), T(0));
     for (int g = 0; g < (t >> 3); ++g) E = cadd(E, gt[g]);
@@ -278,7 +303,7 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
 #pragma unroll
     for (int i = 0; i < 4; ++i) w[ZP(2 * (4 * t + i) + 1)] = cadd(E, c[i]);
   }
-  __syncthreads();
+  psync<WAVE>();
 }
 
 // copies the twiddle and sine tables of the plan into LDS (the stage loops read them with LDS latency
@@ -307,16 +332,16 @@ struct BoxGrid {
 // IO = 1: the input is gathered from the Krylov vector through gmap (solver position of the u DoF at the
 // lattice point, -1: none); IO = 2: the result is scattered out the same way, times dscale.
 // T: precision of the lattice array and of the transform (the Krylov vectors stay f64).
-template <typename T, int IO>
+template <typename T, int IO, bool WAVE>
 __global__ void __launch_bounds__(1024)
 k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gmap,
         const double *__restrict__ vin, double *__restrict__ vout, const double *__restrict__ dscale) {
   extern __shared__ double2 zs_raw[];
   C2<T> *zs = reinterpret_cast<C2<T> *>(zs_raw);
-  const int pr = threadIdx.x / P.tp, t = threadIdx.x % P.tp;
+  const int pr = threadIdx.x / P.slot, t = threadIdx.x % P.slot;  // slot >= tp lanes per pair
   const int64_t nlines = (int64_t)g.m[1] * g.m[2];
   const int64_t line0 = ((int64_t)blockIdx.x * P.pairs + pr) * 2;
-  const bool live = line0 < nlines;
+  const bool live = line0 < nlines && t < P.tp;
   C2<T> *w = zs + (size_t)pr * ZLEN(P.L);
   C2<T> *scr = zs + (size_t)P.pairs * ZLEN(P.L) + (size_t)pr * P.scr;
   const int mx = g.m[0], L = P.L;
@@ -363,7 +388,7 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
     }
   }
   __syncthreads();
-  dst_core<T>(w, scr, P, t, live, tw, sn);
+  dst_core<T, WAVE>(w, scr, P, t, live, tw, sn);
   if (!live) return;
   if (IO == 2) {
     // k = t + 1 + i tp: all map loads, then all scale loads, then the stores
@@ -401,12 +426,12 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
 // ---- y / z lines (strided): a block takes W = 2 * pairs adjacent x columns of one `outer` index, so every
 // global access is a run of W consecutive values.  AXIS = 1: lines along y (outer = z), AXIS = 2: lines
 // along z (outer = y).  SOLVE (z only): forward transform, times scale / lambda, inverse transform, all in LDS.
-template <typename T, int AXIS, bool SOLVE>
+template <typename T, int AXIS, bool SOLVE, bool WAVE>
 __global__ void __launch_bounds__(1024)
 k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
   extern __shared__ double2 zs_raw[];
   C2<T> *zs = reinterpret_cast<C2<T> *>(zs_raw);
-  const int pr = threadIdx.x / P.tp, t = threadIdx.x % P.tp;
+  const int pr = threadIdx.x / P.slot, t = threadIdx.x % P.slot;  // slot >= tp lanes per pair
   const int W = 2 * P.pairs, L = P.L;
   const int mx = g.m[0];
   const int ncb = (mx + W - 1) / W;                 // column blocks
@@ -416,7 +441,7 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
   const int64_t estride = AXIS == 1 ? g.pitch : g.plane;
   const int64_t base = col0 + outer * (AXIS == 1 ? g.plane : g.pitch);
   const int ncols = min(W, mx - col0);
-  const bool live = 2 * pr < ncols;
+  const bool live = 2 * pr < ncols && t < P.tp;
   C2<T> *w = zs + (size_t)pr * ZLEN(L);
   C2<T> *scr = zs + (size_t)P.pairs * ZLEN(L) + (size_t)pr * P.scr;
   const C2<T> *tw;
@@ -440,22 +465,25 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
     }
   }
   __syncthreads();
-  if (P.dbg != 1) dst_core<T>(w, scr, P, t, live, tw, sn);
+  if (P.dbg != 1) dst_core<T, WAVE>(w, scr, P, t, live, tw, sn);
   if (SOLVE && P.dbg != 1) {
     if (live) {
       const double *lx = g.lam[0], *ly = g.lam[1], *lz = g.lam[2];
       const int kx = col0 + 2 * pr + 1;
       const double lxy0 = lx[kx] + ly[outer + 1];
       const double lxy1 = (kx + 1 < g.L[0] ? lx[kx + 1] : lx[kx]) + ly[outer + 1];
+      // the divide runs in the precision of the transform (an f64 division costs ~10x an f32 one)
+      const T sc = (T)g.scale, l0 = (T)lxy0, l1 = (T)lxy1;
       for (int k = t + 1; k < L; k += P.tp) {
         const C2<T> F = w[ZP(k)];
-        const double lzk = lz[k];
-        w[ZP(k)] = mk<T>((T)((double)F.x * g.scale / (lxy0 + lzk)), (T)((double)F.y * g.scale / (lxy1 + lzk)));
+        const T lzk = (T)lz[k];
+        w[ZP(k)] = mk<T>(F.x * sc / (l0 + lzk), F.y * sc / (l1 + lzk));
       }
     }
-    __syncthreads();
-    dst_core<T>(w, scr, P, t, live, tw, sn);
+    psync<WAVE>();
+    dst_core<T, WAVE>(w, scr, P, t, live, tw, sn);
   }
+  __syncthreads();
   if (tcol < ncols) {
     const T *wc = reinterpret_cast<const T *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
     if (P.dbg != 2 || wc[0] == T(12345))
@@ -487,21 +515,23 @@ static void box_precond_free(phx_box_precond *bp) {
   delete bp;
 }
 
-template <typename T>
+template <typename T, bool WAVE>
 static int dst_allow_lds_t() {
   const int bytes = 96 * 1024;  // padded transform data + scan scratch may exceed the 64 KB default
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<T, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<T, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 0, WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 1, WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 2, WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<T, 1, false, WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<T, 2, true, WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   return PHX_OK;
 }
 static int dst_allow_lds() {
   static bool done = false;
   if (done) return PHX_OK;
-  PHX_CHECK(dst_allow_lds_t<double>());
-  PHX_CHECK(dst_allow_lds_t<float>());
+  PHX_CHECK((dst_allow_lds_t<double, true>()));
+  PHX_CHECK((dst_allow_lds_t<double, false>()));
+  PHX_CHECK((dst_allow_lds_t<float, true>()));
+  PHX_CHECK((dst_allow_lds_t<float, false>()));
   done = true;
   return PHX_OK;
 }
@@ -541,13 +571,15 @@ static int box_solve_middle_t(phx_box_precond *bp, hipStream_t st, phx_system *p
   for (int pass = 0; pass < 3; ++pass) {
     if (pass == 1) {
       const int W = 2 * pz.pairs, ncb = (g.m[0] + W - 1) / W;
-      const dim3 grid((unsigned)((int64_t)ncb * g.m[1])), block((unsigned)(pz.pairs * pz.tp));
-      k_dst_s<T, 2, true><<<grid, block, (size_t)pz.lds_elems * el, st>>>(g, pz, G);
+      const dim3 grid((unsigned)((int64_t)ncb * g.m[1])), block((unsigned)(pz.pairs * pz.slot));
+      if (pz.wave) k_dst_s<T, 2, true, true><<<grid, block, (size_t)pz.lds_elems * el, st>>>(g, pz, G);
+      else k_dst_s<T, 2, true, false><<<grid, block, (size_t)pz.lds_elems * el, st>>>(g, pz, G);
     } else {
       const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
-      const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.tp));
+      const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.slot));
       if (prof) PHX_CHECK(prof_begin(prof, 1));
-      k_dst_s<T, 1, false><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
+      if (py.wave) k_dst_s<T, 1, false, true><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
+      else k_dst_s<T, 1, false, false><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
       if (prof) PHX_CHECK(prof_end(prof, 1));
     }
   }
@@ -563,9 +595,13 @@ static int box_pass_x_t(phx_box_precond *bp, hipStream_t st, const double *vin, 
   const BoxGrid &g = bp->g;
   const DstPlan &px = bp->plan[0];
   const int64_t npairs = ((int64_t)g.m[1] * g.m[2] + 1) / 2;
-  const dim3 grid((unsigned)phx_div_up(npairs, px.pairs)), block((unsigned)(px.pairs * px.tp));
-  k_dst_x<T, IO><<<grid, block, (size_t)px.lds_elems * sizeof(T) * 2, st>>>(
-      g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, bp->dscale);
+  const dim3 grid((unsigned)phx_div_up(npairs, px.pairs)), block((unsigned)(px.pairs * px.slot));
+  if (px.wave)
+    k_dst_x<T, IO, true><<<grid, block, (size_t)px.lds_elems * sizeof(T) * 2, st>>>(
+        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, bp->dscale);
+  else
+    k_dst_x<T, IO, false><<<grid, block, (size_t)px.lds_elems * sizeof(T) * 2, st>>>(
+        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, bp->dscale);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
 }
@@ -760,14 +796,18 @@ extern "C" int phx_box_dst_bench(int device, const int *L, int f32, int reps, do
       if (which == 0) return box_pass_x<0>(bp, st, nullptr, nullptr);
       const DstPlan &P = bp->plan[which];
       const int W = 2 * P.pairs, ncb = (g.m[0] + W - 1) / W;
-      const dim3 grid((unsigned)((int64_t)ncb * g.m[which == 1 ? 2 : 1])), block((unsigned)(P.pairs * P.tp));
+      const dim3 grid((unsigned)((int64_t)ncb * g.m[which == 1 ? 2 : 1])), block((unsigned)(P.pairs * P.slot));
       const size_t lds = (size_t)P.lds_elems * (f32 ? sizeof(float2) : sizeof(double2));
       if (f32) {
-        if (which == 1) k_dst_s<float, 1, false><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
-        else k_dst_s<float, 2, true><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
+        if (which == 1 && P.wave) k_dst_s<float, 1, false, true><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
+        else if (which == 1) k_dst_s<float, 1, false, false><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
+        else if (P.wave) k_dst_s<float, 2, true, true><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
+        else k_dst_s<float, 2, true, false><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
       } else {
-        if (which == 1) k_dst_s<double, 1, false><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
-        else k_dst_s<double, 2, true><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
+        if (which == 1 && P.wave) k_dst_s<double, 1, false, true><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
+        else if (which == 1) k_dst_s<double, 1, false, false><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
+        else if (P.wave) k_dst_s<double, 2, true, true><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
+        else k_dst_s<double, 2, true, false><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
       }
       return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_HIP;
     };
