@@ -146,7 +146,7 @@ int phx_set_option(phx_mesh *m, int option, int64_t value);
 /* Direct solve of the 7-point lattice Laplacian K = sum_a (h_b h_c / h_a) tridiag(-1, 2, -1)_a with
  * homogeneous Dirichlet faces on an (L0-1) x (L1-1) x (L2-1) interior lattice (x fastest), by type-I sine
  * transforms on the device (f32 != 0: lattice array and transforms in single precision);
- * L_a in {64, 96, 128, 192, 256, 384, 512, 768, 1024}.  u overwrites f (host).
+ * L_a in {64, 128, 192, 256, 384, 512, 768, 1024}.  u overwrites f (host).
  * This is the kernel sequence of the fictitious-domain preconditioner (PHX_OPT_PRECOND), exposed for tests. */
 int phx_box_poisson_solve(int device, const int *L, const double *h, int f32, double *f_host);
 /* Timing aid: average microseconds of the x, y and z (forward + divide + inverse) transform passes on an

@@ -40,9 +40,9 @@ struct DstPlan {
 
 static std::map<std::pair<int, int>, DstPlan> g_dst_plans;  // (device, L or -L for f32 tiles) -> plan
 
-// L = 2^a 3^b, b <= 1, 64 <= L <= 1024
+// L = 2^a 3^b, b <= 1, 64 <= L <= 1024, 64 | L
 static int dst_pick_length(int64_t need) {
-  const int cand[] = {64, 96, 128, 192, 256, 384, 512, 768, 1024};
+  const int cand[] = {64, 128, 192, 256, 384, 512, 768, 1024};  // L / R is a multiple of 8 in every stage
   for (int c : cand)
     if (c >= need) return c;
   return -1;
@@ -189,17 +189,26 @@ __device__ __forceinline__ void fft_stage(C2<T> *z, int nb, int tp, int t, int p
                                           const C2<T> *__restrict__ tw) {
   constexpr int MAXB = (8 + R - 1) / R;
   C2<T> u[MAXB][R];
+  // padded LDS indices are linear in q: nb and p (p > 1) are multiples of 8, the first stage (p = 1) has
+  // radix 8, so ZP(i + q nb) = ZP(i) + q ZP'(nb) and ZP(j + q p) = ZP(j) + q ZP'(p)   (ZP'(n) = n + n / 8)
+  const int nbp = nb + (nb >> 3);
+  const int pp = p == 1 ? 1 : p + (p >> 3);
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
     const int i = t + b * tp;
     if (i < nb) {
       const int k = i & (p - 1);
       const int step = tws * k;  // twiddle exponent of q = 1; q * step < L for q < R
+      // running indices: integer multiplies are quarter rate, the transforms are issue bound
+      const C2<T> *zr = z + ZP(i);
+      const C2<T> *twq = tw;
 #pragma unroll
       for (int q = 0; q < R; ++q) {
-        C2<T> w = z[ZP(i + q * nb)];
-        if (q > 0 && k > 0) w = cmul(w, tw[q * step]);
+        C2<T> w = *zr;
+        if (q > 0 && k > 0) w = cmul(w, *twq);
         u[b][q] = w;
+        zr += nbp;
+        twq += step;
       }
       if constexpr (R == 8) dft8(u[b]);
       else if constexpr (R == 4) dft4(u[b]);
@@ -214,8 +223,9 @@ __device__ __forceinline__ void fft_stage(C2<T> *z, int nb, int tp, int t, int p
     if (i < nb) {
       const int k = i & (p - 1);
       const int j = (i - k) * R + k;
+      C2<T> *zw = z + ZP(j);
 #pragma unroll
-      for (int q = 0; q < R; ++q) z[ZP(j + q * p)] = u[b][q];
+      for (int q = 0; q < R; ++q) { *zw = u[b][q]; zw += pp; }
     }
   }
   psync<WAVE>();
@@ -453,15 +463,21 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
   T *wcol = reinterpret_cast<T *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
   {
     T vv[16];
+    const T *gp = G + (base + (int64_t)row0 * estride + tcol);
+    const int64_t gstep = (int64_t)rstep * estride;
+    const bool colok = tcol < ncols && P.dbg != 2;
+    int row = row0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int row = row0 + i * rstep;
-      vv[i] = (row < len && tcol < ncols && P.dbg != 2) ? G[base + row * estride + tcol] : T(0);
+      vv[i] = (row < len && colok) ? *gp : T(0);
+      gp += gstep;
+      row += rstep;
     }
+    row = row0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int row = row0 + i * rstep;
       if (row < L - 1) wcol[2 * ZP(row + 1)] = vv[i];
+      row += rstep;
     }
   }
   __syncthreads();
@@ -486,8 +502,11 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
   __syncthreads();
   if (tcol < ncols) {
     const T *wc = reinterpret_cast<const T *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
-    if (P.dbg != 2 || wc[0] == T(12345))
-      for (int row = row0; row < len; row += rstep) G[base + row * estride + tcol] = wc[2 * ZP(row + 1)];
+    if (P.dbg != 2 || wc[0] == T(12345)) {
+      T *gp = G + (base + (int64_t)row0 * estride + tcol);
+      const int64_t gstep = (int64_t)rstep * estride;
+      for (int row = row0; row < len; row += rstep) { *gp = wc[2 * ZP(row + 1)]; gp += gstep; }
+    }
   }
 }
 
