@@ -61,6 +61,9 @@ struct Slots {
   double *vals;
   int W;
   int *overflow;
+  // clean[row] = c > 0: the row has one writer (the gather kernel) that stored its c entries at slots
+  // 0 .. c-1 in ascending column order: no hashing, no sort at compaction.  nullptr: no such rows.
+  uint8_t *clean = nullptr;
 };
 
 __device__ __forceinline__ void slot_add(const Slots &s, int32_t row, int32_t col, double v) {
@@ -153,6 +156,7 @@ __device__ __forceinline__ void load_cell(const int32_t *__restrict__ cells,
 // connectivity; the compaction kernel translates them to active rows (one dof-map lookup per
 // stored entry instead of one per contribution).
 struct AsmArgs {
+  const uint8_t *touched = nullptr;  // [nv] vertex gets contributions from the scattering kernels (nullptr: all do)
   int32_t nv;
   const int32_t *cells;
   const double *x;
@@ -375,14 +379,54 @@ k_assemble_rows_box(int64_t nv, BoxDims bd, AsmArgs A) {
     }
   }
   A.rhs[row] = rhs;
+  // a row no scattering kernel will touch is stored densely and already sorted (codes ascend with the
+  // vertex index, hence with the column): it skips the hash table and the sort of the compaction
+  const bool clean = A.slots.clean && A.touched && !A.touched[vtx];
+  int cnt = 0;
 #pragma unroll
   for (int code = 0; code < NCODE; ++code) {
     if (!seen[code]) continue;
     int64_t w = vtx;
     w += (code % 3 - 1) * vstride[0] + ((code / 3) % 3 - 1) * vstride[1];
     if (D == 3) w += (code / 9 - 1) * vstride[2];
-    slot_add_owned(A.slots, row, (int32_t)w, acc[code]);
+    if (clean) {
+      A.slots.cols[(int64_t)row * A.slots.W + cnt] = (int32_t)w;
+      A.slots.vals[(int64_t)row * A.slots.W + cnt] = acc[code];
+      ++cnt;
+    } else {
+      slot_add_owned(A.slots, row, (int32_t)w, acc[code]);
+    }
   }
+  if (clean) A.slots.clean[row] = (uint8_t)cnt;
+}
+
+// vertices whose rows the scattering kernels (cut cells, one-sided boundary term, ghost penalty) add to
+template <int N>
+__global__ void k_mark_cells(int64_t n, const int32_t *__restrict__ list, const int32_t *__restrict__ cells,
+                             uint8_t *__restrict__ touched) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = list[i];
+  for (int k = 0; k < N; ++k) touched[cells[c * N + k]] = 1;
+}
+template <int N>
+__global__ void k_mark_facet_cells(int64_t n, const int32_t *__restrict__ list, const int32_t *__restrict__ f2c,
+                                   const int32_t *__restrict__ cells, uint8_t *__restrict__ touched) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int side = 0; side < 2; ++side) {
+    const int64_t c = f2c[2 * (int64_t)list[i] + side];
+    if (c < 0) continue;
+    for (int k = 0; k < N; ++k) touched[cells[c * N + k]] = 1;
+  }
+}
+template <int N>
+__global__ void k_mark_entity_cells(int64_t n, const int64_t *__restrict__ ent_packed, const int32_t *__restrict__ cells,
+                                    uint8_t *__restrict__ touched) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = ent_packed[2 * i + 1] >> 8;
+  for (int k = 0; k < N; ++k) touched[cells[c * N + k]] = 1;
 }
 
 // --- cut cells, main.py:115-122,144-149 (penalisation): 64 lanes per cell, lane = (a, b) of the mixed
@@ -532,11 +576,15 @@ static int build_list(phx_mesh *m, int64_t n, Pred pred, int32_t **list, int64_t
 // compaction: one wave per row; lanes hold the slots, sorted by column with a bitonic network
 // ---------------------------------------------------------------------------------------------
 __global__ void k_row_counts(int64_t n, int W, const int32_t *__restrict__ cols,
-                             int64_t *__restrict__ counts) {
+                             const uint8_t *__restrict__ clean, int64_t *__restrict__ counts) {
   // a wavefront walks many rows: a wave per row (2.9 M of them at 256^3) is launch-bound
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; row < n; row += nwaves) {
+    if (clean && clean[row]) {
+      if (lane == 0) counts[row] = clean[row];
+      continue;
+    }
     int cnt = 0;
     for (int k = lane; k < W; k += 64) cnt += cols[row * W + k] != -1;
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
@@ -545,7 +593,8 @@ __global__ void k_row_counts(int64_t n, int W, const int32_t *__restrict__ cols,
 }
 
 __global__ void k_row_fill(int64_t n, int W, const int32_t *__restrict__ cols,
-                           const double *__restrict__ vals, const int64_t *__restrict__ rowptr,
+                           const double *__restrict__ vals, const uint8_t *__restrict__ clean,
+                           const int64_t *__restrict__ rowptr,
                            int32_t nv, const int32_t *__restrict__ du,
                            const int32_t *__restrict__ dp, int32_t *__restrict__ ocol,
                            double *__restrict__ oval, double *__restrict__ diag) {
@@ -554,11 +603,13 @@ __global__ void k_row_fill(int64_t n, int W, const int32_t *__restrict__ cols,
   for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; row < n; row += nwaves) {
     int32_t c = 0x7fffffff;
     double v = 0.0;
-    if (lane < W) {
+    const int nclean = clean ? clean[row] : 0;  // dense, sorted row: translate and copy
+    if (lane < (nclean ? nclean : W)) {
       const int32_t cc = cols[row * W + lane];
       if (cc != -1) { c = cc < nv ? du[cc] : dp[cc - nv]; v = vals[row * W + lane]; }
     }
     if (c == (int32_t)row) diag[row] = v;
+    if (!nclean)
     for (int k = 2; k <= 64; k <<= 1)
       for (int j = k >> 1; j > 0; j >>= 1) {
         const int32_t oc = __shfl_xor(c, j);
@@ -669,7 +720,7 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(hipMemcpyAsync(&overflow, sl.overflow, sizeof(int), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
   if (overflow) {
-    PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow));
+    PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow)); PHX_HIP(phx_free(sl.clean));
     phx_set_error("row-slot capacity %d exceeded", W);
     return PHX_ERR_CAPACITY;
   }
@@ -679,7 +730,7 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(phx_malloc(&s->rowptr, sizeof(int64_t) * (size_t)(s->n + 1)));
   // 8 waves per SIMD x 4 SIMDs x 256 CUs, each walking rows with a wave stride
   const dim3 growave((unsigned)std::min<int64_t>(phx_div_up(s->n * 64, 256), 2048));
-  k_row_counts<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, counts);
+  k_row_counts<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, sl.clean, counts);
   PHX_CHECK(exclusive_sum<int64_t>(m, counts, s->rowptr, s->n + 1));
   int64_t nnz = 0;
   PHX_HIP(hipMemcpy(&nnz, s->rowptr + s->n, sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -689,7 +740,7 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(phx_malloc(&s->diag, sizeof(double) * (size_t)s->n));
   PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
   if (W <= 64)  // one wave per row here: the wave-stride variant was slower (2.23 vs 1.89 ms), the sort hides nothing
-    k_row_fill<<<dim3((unsigned)phx_div_up(s->n * 64, 256)), block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, s->rowptr, nent,
+    k_row_fill<<<dim3((unsigned)phx_div_up(s->n * 64, 256)), block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, sl.clean, s->rowptr, nent,
                                                   s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
   else if (W == 128)
     k_row_fill_block<128><<<dim3((unsigned)s->n), dim3(128), 0, m->stream>>>(
@@ -710,7 +761,7 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(counts));
-  PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow));
+  PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow)); PHX_HIP(phx_free(sl.clean));
   return phx_system_build_sell(s);
 }
 
@@ -772,6 +823,33 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   int64_t n_cut = 0, n_fac = 0;
   PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut));
   PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac));
+  uint8_t *touched = nullptr;
+  if (m->is_box && !m->is_submesh) {
+    // rows of vertices no scattering kernel reaches are written dense and sorted by the gather kernel
+    PHX_CHECK(phx_collect_entities(m));
+    PHX_HIP(phx_malloc(&touched, (size_t)m->nv));
+    PHX_HIP(phx_malloc(&sl.clean, (size_t)s->n));
+    PHX_HIP(hipMemsetAsync(touched, 0, (size_t)m->nv, m->stream));
+    PHX_HIP(hipMemsetAsync(sl.clean, 0, (size_t)s->n, m->stream));
+    constexpr int TB = 256;
+    if (n_cut > 0) {
+      const dim3 g((unsigned)phx_div_up(n_cut, TB));
+      if (D == 2) k_mark_cells<3><<<g, dim3(TB), 0, m->stream>>>(n_cut, l_cut, m->cells, touched);
+      else k_mark_cells<4><<<g, dim3(TB), 0, m->stream>>>(n_cut, l_cut, m->cells, touched);
+    }
+    if (n_fac > 0) {
+      const dim3 g((unsigned)phx_div_up(n_fac, TB));
+      if (D == 2) k_mark_facet_cells<3><<<g, dim3(TB), 0, m->stream>>>(n_fac, l_fac, m->f2c, m->cells, touched);
+      else k_mark_facet_cells<4><<<g, dim3(TB), 0, m->stream>>>(n_fac, l_fac, m->f2c, m->cells, touched);
+    }
+    if (m->ent_count[0] > 0) {
+      const dim3 g((unsigned)phx_div_up(m->ent_count[0], TB));
+      if (D == 2) k_mark_entity_cells<3><<<g, dim3(TB), 0, m->stream>>>(m->ent_count[0], m->ent_buf[0], m->cells, touched);
+      else k_mark_entity_cells<4><<<g, dim3(TB), 0, m->stream>>>(m->ent_count[0], m->ent_buf[0], m->cells, touched);
+    }
+    A.touched = touched;
+    A.slots = sl;
+  }
   {
     if (m->is_box) {
       const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}, {m->box_h[0], m->box_h[1], m->box_h[2]}};
@@ -814,6 +892,7 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_fac));
+  if (touched) PHX_HIP(phx_free(touched));
   {
     const int rc = phx_finish_system(s, sl, (int32_t)m->nv);
     if (rc != PHX_OK) { phx_system_destroy(s); return rc; }
