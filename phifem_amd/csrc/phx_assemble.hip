@@ -486,57 +486,6 @@ __global__ void __launch_bounds__(256) k_assemble_cut(int64_t nlist, const int32
   // main.py:123-128,150: div(grad(.)) of a P1 function is identically zero.
 }
 
-// One lane per cut cell (same terms as k_assemble_cut): geometry and phi sums once per cell, then the
-// lane walks the (2N)^2 tensor entries and the 2N right-hand-side entries.
-template <int D>
-__global__ void __launch_bounds__(256) k_assemble_cut_lane(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
-  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e >= nlist) return;
-  constexpr int N = D + 1;
-  const int64_t c = list[e];
-  int32_t v[N];
-  double X[N][D];
-  load_cell<D>(A.cells, A.x, c, v, X);
-  Geo<D> G;
-  simplex_geometry<D>(X, G);
-  constexpr double c2 = D == 3 ? 1.0 / 20.0 : 1.0 / 12.0;
-  constexpr double c3 = D == 3 ? 1.0 / 120.0 : 1.0 / 60.0;
-  constexpr double c4 = D == 3 ? 1.0 / 840.0 : 1.0 / 360.0;
-  double ph[N], ud[N], sp = 0.0, sud = 0.0;
-  int32_t ru[N], rp[N];
-#pragma unroll
-  for (int q = 0; q < N; ++q) {
-    ph[q] = A.phi[v[q]]; sp += ph[q];
-    ud[q] = A.ud[v[q]]; sud += ud[q];
-    ru[q] = A.du[v[q]]; rp[q] = A.dp[v[q]];
-  }
-  const double h1 = 1.0 / G.h;
-  const double gam = A.gamma * G.vol;
-  const double kuu = gam * h1 * h1 * c2, kup = -gam * h1 * h1 * h1 * c3, kpp = gam * h1 * h1 * h1 * h1 * c4;
-#pragma unroll
-  for (int i = 0; i < N; ++i) {
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-      const double dij = i == j ? 2.0 : 1.0;
-      const double mix = kup * dij * (sp + ph[i] + ph[j]);
-      double m4 = 0.0;
-#pragma unroll
-      for (int k = 0; k < N; ++k)
-#pragma unroll
-        for (int l = 0; l < N; ++l) m4 += mult4(i, j, k, l) * ph[k] * ph[l];
-      slot_add(A.slots, ru[i], v[j], kuu * dij);           // (u,v)
-      slot_add(A.slots, ru[i], A.nv + v[j], mix);          // (p,v): row u_i, column p_j
-      slot_add(A.slots, rp[i], v[j], mix);                 // (u,q): row p_i, column u_j
-      slot_add(A.slots, rp[i], A.nv + v[j], kpp * m4);     // (p,q)
-    }
-    double bq = 0.0;
-#pragma unroll
-    for (int q = 0; q < N; ++q) bq += ud[q] * (i == q ? 2.0 : 1.0) * (sp + ph[i] + ph[q]);
-    if (ru[i] >= 0) unsafeAtomicAdd(&A.rhs[ru[i]], kuu * (sud + ud[i]));
-    if (rp[i] >= 0) unsafeAtomicAdd(&A.rhs[rp[i]], kup * bq);
-  }
-}
-
 // --- one-sided boundary term, main.py:114:  -int_F (grad u . n) v  over (cell, local facet) ---
 // With n = -g_lf/|g_lf|, |F| = D |K| |g_lf| and int_F N_i = |F|/D (i on F) the entry is
 // |K| (g_j . g_lf) for every row i != lf and every column j.  16 lanes per entity.
@@ -982,18 +931,12 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
     }
   }
   if (n_cut > 0) {
-    // measured at 256^3 (1.1e6 cut cells): 64 lanes per cell 2.1 ms, one lane per cell 2.7 ms (64 dependent
-    // hash probes per lane) -- unlike the ghost-penalty facets, where one lane per facet wins (2.8 -> 1.5 ms)
-    static const bool lane_per_cell = getenv("PHX_CUT_LANE") != nullptr;  // tuning aid
-    if (lane_per_cell) {
-      const dim3 g((unsigned)phx_div_up(n_cut, 256));
-      if (D == 2) k_assemble_cut_lane<2><<<g, block, 0, m->stream>>>(n_cut, l_cut, A);
-      else k_assemble_cut_lane<3><<<g, block, 0, m->stream>>>(n_cut, l_cut, A);
-    } else {
-      const dim3 g((unsigned)phx_div_up(n_cut * 64, 256));
-      if (D == 2) k_assemble_cut<2><<<g, block, 0, m->stream>>>(n_cut, l_cut, A);
-      else k_assemble_cut<3><<<g, block, 0, m->stream>>>(n_cut, l_cut, A);
-    }
+    // 64 lanes per cut cell.  Measured at 256^3 (1.1e6 cut cells): 64 lanes per cell 2.1 ms, 8 lanes (one
+    // tensor row each) 2.6 ms, one lane per cell 2.7 ms -- the dependent hash probes of a lane serialise;
+    // the ghost-penalty facets behave the other way round (one lane per facet: 2.8 -> 1.5 ms).
+    const dim3 g((unsigned)phx_div_up(n_cut * 64, 256));
+    if (D == 2) k_assemble_cut<2><<<g, block, 0, m->stream>>>(n_cut, l_cut, A);
+    else k_assemble_cut<3><<<g, block, 0, m->stream>>>(n_cut, l_cut, A);
   }
   PHX_HIP(hipGetLastError());
   if (m->is_submesh) {
