@@ -515,63 +515,13 @@ __global__ void k_assemble_ds(int64_t nent, const int64_t *__restrict__ ent_pack
 
 // --- ghost penalty, main.py:129-134:  sigma avg(h) int_F [grad u . n][grad v . n] on dS((2,3)) ---
 // The two cells share the D vertices of F, so the macro-element has D+2 distinct vertices: the
-// jump coefficient of a shared vertex is the sum of its two one-sided ones.  One 64-lane group per
-// facet, lane = (a, b) over the D+2 distinct vertices: 25 (16) atomics per facet, not 64 (36).
+// jump coefficient of a shared vertex is the sum of its two one-sided ones: 25 (16) atomics per facet,
+// not 64 (36).
+// One lane per facet: the geometry of the two cells is evaluated once per facet, then the lane walks the
+// (D+2)^2 entries.  Measured at 256^3 (2e6 facets): 32 lanes per facet (one entry each, every load issued
+// once per TWO facets of a wavefront) 2.8 ms, 8 lanes per facet (one tensor row each) 1.8 ms, this 1.5 ms.
 template <int D>
 __global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
-  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t e = gid >> 5;
-  if (e >= nlist) return;
-  constexpr int N = D + 1, M = D + 2;
-  const int a = (int)(gid & 31) / M, b = (int)(gid & 31) % M;
-  if (a >= M) return;
-  const int64_t f = list[e];
-  // distinct vertices: 0..D = the "+" cell's, D+1 = the "-" cell's vertex opposite F
-  int32_t vp[N], vm[N];
-  double Jp[N], Jm[N], hsum = 0.0, area = 0.0;
-  int lfm = 0;
-  for (int side = 0; side < 2; ++side) {
-    const int64_t c = A.f2c[2 * f + side];
-    int32_t *v = side == 0 ? vp : vm;
-    double *J = side == 0 ? Jp : Jm;
-    double X[N][D];
-    load_cell<D>(A.cells, A.x, c, v, X);
-    Geo<D> G;
-    simplex_geometry<D>(X, G);
-    int lf = 0;
-    for (int k = 0; k < N; ++k)
-      if (A.c2f[c * N + k] == (int32_t)f) lf = k;
-    if (side == 1) lfm = lf;
-    double gn = 0.0;
-    for (int d = 0; d < D; ++d) gn += G.g[lf][d] * G.g[lf][d];
-    gn = sqrt(gn);
-    if (side == 0) area = D * G.vol * gn;
-    hsum += G.h;
-    for (int j = 0; j < N; ++j) {
-      double s = 0.0;
-      for (int d = 0; d < D; ++d) s += G.g[j][d] * G.g[lf][d];
-      J[j] = -s / gn;  // grad N_j . n, n outward from this side's cell
-    }
-  }
-  // combined jump coefficients on the distinct vertices
-  int32_t vd[M];
-  double Jd[M];
-  for (int j = 0; j < N; ++j) { vd[j] = vp[j]; Jd[j] = Jp[j]; }
-  vd[N] = vm[lfm];
-  Jd[N] = Jm[lfm];
-  for (int j = 0; j < N; ++j) {
-    if (j == lfm) continue;
-    for (int q = 0; q < N; ++q)
-      if (vp[q] == vm[j]) Jd[q] += Jm[j];
-  }
-  slot_add(A.slots, A.du[vd[a]], vd[b], A.sigma * 0.5 * hsum * area * Jd[a] * Jd[b]);
-}
-
-// One lane per facet: the geometry is evaluated once per facet (the 32-lanes-per-facet kernel above
-// issues every load of the two cells once per TWO facets of a wavefront), then the lane walks the
-// (D+2)^2 entries; the adds of one lane are independent of each other.
-template <int D>
-__global__ void __launch_bounds__(256) k_assemble_facets_lane(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
   const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e >= nlist) return;
   constexpr int N = D + 1, M = D + 2;
@@ -956,16 +906,9 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   }
   PHX_HIP(hipGetLastError());
   if (n_fac > 0) {
-    static const bool lane_per_facet = getenv("PHX_FACETS_WIDE") == nullptr;  // tuning aid: the 32-lane variant
-    if (lane_per_facet) {
-      const dim3 g((unsigned)phx_div_up(n_fac, 256));
-      if (D == 2) k_assemble_facets_lane<2><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
-      else k_assemble_facets_lane<3><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
-    } else {
-      const dim3 g((unsigned)phx_div_up(n_fac * 32, 256));
-      if (D == 2) k_assemble_facets<2><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
-      else k_assemble_facets<3><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
-    }
+    const dim3 g((unsigned)phx_div_up(n_fac, 256));
+    if (D == 2) k_assemble_facets<2><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
+    else k_assemble_facets<3><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
   }
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
