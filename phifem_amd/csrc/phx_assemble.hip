@@ -615,7 +615,8 @@ __global__ void k_row_fill(int64_t n, int W, const int32_t *__restrict__ cols,
                            const int64_t *__restrict__ rowptr,
                            int32_t nv, const int32_t *__restrict__ du,
                            const int32_t *__restrict__ dp, int32_t *__restrict__ ocol,
-                           double *__restrict__ oval, double *__restrict__ diag) {
+                           double *__restrict__ oval, double *__restrict__ diag,
+                           int32_t *__restrict__ row_nz) {
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; row < n; row += nwaves) {
@@ -640,6 +641,9 @@ __global__ void k_row_fill(int64_t n, int W, const int32_t *__restrict__ cols,
     const int64_t base = rowptr[row];
     const int64_t cnt = rowptr[row + 1] - base;
     if (lane < cnt) { ocol[base + lane] = c; oval[base + lane] = v; }
+    // what the SELL copy will keep of this row (explicit zeros dropped, the diagonal always kept)
+    const unsigned long long keep = __ballot(lane < cnt && (v != 0.0 || c == (int32_t)row));
+    if (lane == 0) row_nz[row] = __popcll(keep);
   }
 }
 
@@ -720,7 +724,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active, s->rowptr, s->col,
                   s->val, s->rhs, s->diag, s->slice_ptr, s->sell_col, s->sell_val,
-                  s->sell_val_raw, s->sell_kind, s->perm, s->iperm, s->work, s->scal};
+                  s->sell_val_raw, s->sell_kind, s->perm, s->iperm, s->work, s->scal, s->row_nz};
   for (void *p : ptrs) (void)phx_free(p);
   phx_box_precond_destroy(s->precond);
   if (s->scal_h) (void)hipHostFree(s->scal_h);
@@ -757,9 +761,10 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(phx_malloc(&s->val, sizeof(double) * (size_t)nnz));
   PHX_HIP(phx_malloc(&s->diag, sizeof(double) * (size_t)s->n));
   PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
+  if (W <= 64) PHX_HIP(phx_malloc(&s->row_nz, sizeof(int32_t) * (size_t)s->n));
   if (W <= 64)  // one wave per row here: the wave-stride variant was slower (2.23 vs 1.89 ms), the sort hides nothing
     k_row_fill<<<dim3((unsigned)phx_div_up(s->n * 64, 256)), block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, sl.clean, s->rowptr, nent,
-                                                  s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
+                                                  s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag, s->row_nz);
   else if (W == 128)
     k_row_fill_block<128><<<dim3((unsigned)s->n), dim3(128), 0, m->stream>>>(
         s->n, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);

@@ -127,6 +127,7 @@ struct phx_system {
   double *val = nullptr;               // [nnz]
   double *rhs = nullptr;               // [n]
   double *diag = nullptr;              // [n]
+  int32_t *row_nz = nullptr;           // [n] stored entries per row with explicit zeros dropped (from the compaction; may be null)
   // SELL-64 in solver ordering (rows permuted by window-sorted length)
   int64_t nslices = 0, sell_nnz = 0, sell_true_nnz = 0;
   int64_t *slice_ptr = nullptr;  // [nslices+1] offsets in units of entries

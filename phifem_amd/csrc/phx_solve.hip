@@ -44,13 +44,18 @@ static int64_t g_sell_window = (int64_t)1 << 40;
 // ---------------------------------------------------------------------------------------------
 __global__ void k_row_lengths(int64_t n, const int64_t *__restrict__ rowptr,
                               const int32_t *__restrict__ col, const double *__restrict__ val,
-                              uint32_t *__restrict__ keys, int32_t *__restrict__ rows,
-                              unsigned long long *__restrict__ total, int64_t window) {
+                              const int32_t *__restrict__ row_nz, uint32_t *__restrict__ keys,
+                              int32_t *__restrict__ rows, unsigned long long *__restrict__ total,
+                              int64_t window) {
   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int len = 0;
   if (r < n) {
-    for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
-      if (val[k] != 0.0 || col[k] == (int32_t)r) ++len;
+    if (row_nz) {  // counted by the compaction kernel while the row sat in a wavefront
+      len = row_nz[r];
+    } else {
+      for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k)
+        if (val[k] != 0.0 || col[k] == (int32_t)r) ++len;
+    }
     if (len > 1023) len = 1023;
   }
   int wsum = len;
@@ -209,7 +214,7 @@ int phx_system_build_sell(phx_system *s) {
   unsigned long long *dtotal = nullptr;
   PHX_HIP(phx_malloc(&dtotal, sizeof(unsigned long long)));
   PHX_HIP(hipMemsetAsync(dtotal, 0, sizeof(unsigned long long), m->stream));
-  k_row_lengths<<<grid, block, 0, m->stream>>>(n, s->rowptr, s->col, s->val, keys, rows, dtotal, g_sell_window);
+  k_row_lengths<<<grid, block, 0, m->stream>>>(n, s->rowptr, s->col, s->val, s->row_nz, keys, rows, dtotal, g_sell_window);
   unsigned long long htotal = 0;
   PHX_HIP(hipMemcpyAsync(&htotal, dtotal, sizeof(htotal), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
