@@ -133,7 +133,7 @@ enum phx_option {
                                reduced it over all slabs                                        */
   PHX_OPT_SPMV_XCD_GROUP = 3, /* G > 0: SpMV blocks are regrouped so that each XCD (blockIdx % 8)
                                walks runs of G consecutive blocks; 0: plain order (default)      */
-  PHX_OPT_PRECOND = 5, /* 1 (default): P1 Poisson systems on 3-D Kuhn boxes are preconditioned with the
+  PHX_OPT_PRECOND = 5, /* 1 (default): P1 Poisson systems on Kuhn boxes (2-D, 3-D) are preconditioned with the
                                lattice Laplacian of a box around the active vertices, inverted by sine
                                transforms in f32 (u block; p block: Jacobi) -- an approximate inverse by
                                construction, the Krylov vectors, SpMV and residual stay f64;

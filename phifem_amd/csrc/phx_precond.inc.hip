@@ -555,7 +555,8 @@ static int dst_allow_lds() {
   return PHX_OK;
 }
 
-static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const double h[3], bool f32) {
+// c[a]: coefficient of tridiag(-1, 2, -1) along axis a (3-D: h_b h_c / h_a; 2-D: h_y / h_x, h_x / h_y, 0)
+static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const double c[3], bool f32) {
   bp->f32 = f32;
   PHX_CHECK(dst_allow_lds());
   BoxGrid &g = bp->g;
@@ -567,7 +568,6 @@ static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const
   g.pitch = L[0];
   g.plane = g.pitch * g.m[1];
   g.scale = (2.0 / L[0]) * (2.0 / L[1]) * (2.0 / L[2]);
-  const double c[3] = {h[1] * h[2] / h[0], h[0] * h[2] / h[1], h[0] * h[1] / h[2]};
   for (int a = 0; a < 3; ++a) {
     std::vector<double> lam((size_t)L[a]);
     for (int k = 0; k < L[a]; ++k)
@@ -701,9 +701,9 @@ __global__ void k_dscale(int64_t n, const int32_t *__restrict__ perm, const doub
 static int box_precond_setup(phx_system *s) {
   phx_mesh *m = s->mesh;
   s->precond_state = -1;
-  if (!m->precond || !m->is_box || m->gdim != 3 || !s->u_vertex_block) return PHX_OK;
+  if (!m->precond || !m->is_box || !s->u_vertex_block) return PHX_OK;
   hipStream_t st = m->stream;
-  const int64_t n0 = m->box_n[0] + 1, n1 = m->box_n[1] + 1, n2 = m->box_n[2] + 1;
+  const int64_t n0 = m->box_n[0] + 1, n1 = m->box_n[1] + 1, n2 = m->gdim == 3 ? m->box_n[2] + 1 : 1;
   int *dbb = nullptr, hbb[6] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1};
   PHX_HIP(phx_malloc(&dbb, sizeof(hbb)));
   PHX_HIP(hipMemcpyAsync(dbb, hbb, sizeof(hbb), hipMemcpyHostToDevice, st));
@@ -721,7 +721,11 @@ static int box_precond_setup(phx_system *s) {
     lo[a] = hbb[a] - 1 - (L[a] - 1 - extent) / 2;
   }
   phx_box_precond *bp = new phx_box_precond();
-  int rc = box_grid_setup(bp, m->device, L, m->box_h, m->precond == 1);
+  // 2-D: the lattice gets a dummy third axis with coefficient 0 (one real plane; the z passes are the identity)
+  const double *h = m->box_h;
+  const double c3[3] = {h[1] * h[2] / h[0], h[0] * h[2] / h[1], h[0] * h[1] / h[2]};
+  const double c2[3] = {h[1] / h[0], h[0] / h[1], 0.0};
+  int rc = box_grid_setup(bp, m->device, L, m->gdim == 3 ? c3 : c2, m->precond == 1);
   if (rc != PHX_OK) { box_precond_free(bp); return rc; }
   for (int a = 0; a < 3; ++a) bp->lo[a] = lo[a];
   const int64_t tot = bp->g.plane * bp->g.m[2];
@@ -765,7 +769,8 @@ extern "C" int phx_box_poisson_solve(int device, const int *L, const double *h, 
   for (int a = 0; a < 3; ++a)
     PHX_REQUIRE(dst_pick_length(L[a]) == L[a], PHX_ERR_VALUE, "L[%d] = %d is not a supported transform length", a, L[a]);
   phx_box_precond *bp = new phx_box_precond();
-  int rc = box_grid_setup(bp, device, L, h, f32 != 0);
+  const double c[3] = {h[1] * h[2] / h[0], h[0] * h[2] / h[1], h[0] * h[1] / h[2]};
+  int rc = box_grid_setup(bp, device, L, c, f32 != 0);
   if (rc != PHX_OK) { box_precond_free(bp); return rc; }
   const BoxGrid &g = bp->g;
   const size_t tot = (size_t)(g.plane * g.m[2]);
@@ -801,8 +806,8 @@ extern "C" int phx_box_dst_bench(int device, const int *L, int f32, int reps, do
   for (int a = 0; a < 3; ++a)
     PHX_REQUIRE(dst_pick_length(L[a]) == L[a], PHX_ERR_VALUE, "L[%d] = %d is not a supported transform length", a, L[a]);
   phx_box_precond *bp = new phx_box_precond();
-  const double h[3] = {1.0, 1.0, 1.0};
-  int rc = box_grid_setup(bp, device, L, h, f32 != 0);
+  const double c[3] = {1.0, 1.0, 1.0};
+  int rc = box_grid_setup(bp, device, L, c, f32 != 0);
   if (rc != PHX_OK) { box_precond_free(bp); return rc; }
   const BoxGrid &g = bp->g;
   const size_t bytes = (f32 ? sizeof(float) : sizeof(double)) * (size_t)(g.plane * g.m[2]);

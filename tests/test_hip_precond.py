@@ -95,3 +95,27 @@ def test_preconditioned_solve_equals_jacobi_solve(P, name, precond):
     inside = phi < -0.1
     assert inside.sum() > 100
     assert np.abs(w_p[:uex.size][inside] - uex[inside]).max() < 5e-2   # sanity: discretisation error at n = 48 (0.03 on the sphere)
+
+
+def test_preconditioner_in_2d(P):
+    """2-D boxes: the lattice gets a dummy third axis with coefficient 0; same solution as with Jacobi."""
+    import warnings
+    from phifem_amd import _lib as L_
+    from phifem_amd.mesh_scripts import NodalFunction
+    res = {}
+    for pc in (0, 1):
+        mesh = P.create_box([-1.5, -1.5], [1.5, 1.5], [160, 160])
+        L_.check(L_.lib.phx_set_option(mesh._h, L_.OPT_PRECOND, pc))
+        x = mesh.x
+        phi = (x ** 2).sum(axis=1) - 1.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            P.compute_tags_measures(mesh, NodalFunction(phi), 1, box_mode=True, single_layer_cut=True)
+        uex = np.prod(np.sin(x), axis=1)
+        s = P.PhiFEMSolver(mesh)
+        s.assemble(phi, 2.0 * uex, uex)
+        res[pc] = (s.solve(rtol=1e-9, max_iter=20000), dict(s.stats))
+    assert res[0][1]["precond"] == "jacobi" and res[1][1]["precond"] == "box-dst"
+    assert res[1][1]["relres"] <= 1e-9
+    assert res[1][1]["iterations"] < 0.6 * res[0][1]["iterations"]
+    assert np.abs(res[1][0] - res[0][0]).max() <= 1e-6 * np.abs(res[0][0]).max()
