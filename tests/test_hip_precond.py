@@ -77,6 +77,8 @@ LEVELSETS = {
     "two_balls": lambda x: np.minimum(((x - [0.65, 0.1, 0.0]) ** 2).sum(axis=1) - 0.36,
                                       ((x + [0.65, 0.0, 0.2]) ** 2).sum(axis=1) - 0.30),
     "torus": lambda x: (np.sqrt(x[:, 0] ** 2 + x[:, 1] ** 2) - 0.8) ** 2 + x[:, 2] ** 2 - 0.16,
+    # crosses the x = 1.5 face of the background box: one-sided boundary terms, lattice box past the mesh
+    "boundary_crossing": lambda x: ((x - [0.9, 0.2, 0.0]) ** 2).sum(axis=1) - 1.0,
 }
 
 
