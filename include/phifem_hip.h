@@ -134,10 +134,11 @@ enum phx_option {
   PHX_OPT_SPMV_XCD_GROUP = 3, /* G > 0: SpMV blocks are regrouped so that each XCD (blockIdx % 8)
                                walks runs of G consecutive blocks; 0: plain order (default)      */
   PHX_OPT_PRECOND = 5, /* 1 (default): P1 Poisson systems on Kuhn boxes (2-D, 3-D) are preconditioned with the
-                               lattice Laplacian of a box around the active vertices, inverted by sine
-                               transforms in f32 (u block; p block: Jacobi) -- an approximate inverse by
-                               construction, the Krylov vectors, SpMV and residual stay f64;
-                               2: the same with f64 transforms; 0: Jacobi everywhere                    */
+                               lattice Laplacian of a box around the active vertices, inverted by f64 sine
+                               transforms (u block; p block: Jacobi); 2: the same with f32 transforms -- 25 %
+                               faster per application, but the half-length sine transform amplifies rounding
+                               by O(L) and BiCGStab is not a flexible method: erratic on some problems
+                               (2-D flower: 100-580 iterations against 38); 0: Jacobi everywhere          */
   PHX_OPT_SPMV_VALUE_INDEX = 4 /* 1 (default): systems assembled from now on store SELL slices whose
                                values take <= 64 distinct doubles as dictionary + byte codes
                                (bit-identical products, 5 instead of 12 bytes per entry); 0: raw */

@@ -64,17 +64,29 @@ struct Slots {
   // clean[row] = c > 0: the row has one writer (the gather kernel) that stored its c entries at slots
   // 0 .. c-1 in ascending column order: no hashing, no sort at compaction.  nullptr: no such rows.
   uint8_t *clean = nullptr;
+  // per-row capacities (interface elasticity: 64 slots for the bulk rows, 256+ for the rows of cut-cell
+  // vertices): row r owns slots [off[r], off[r] + (1 << wlog[r])).  nullptr: every row has W slots.
+  const int64_t *off = nullptr;
+  const uint8_t *wlog = nullptr;
 };
+
+__device__ __forceinline__ int64_t slot_base(const Slots &s, int32_t row, int *W) {
+  if (s.off) { *W = 1 << s.wlog[row]; return s.off[row]; }
+  *W = s.W;
+  return (int64_t)row * s.W;
+}
 
 __device__ __forceinline__ void slot_add(const Slots &s, int32_t row, int32_t col, double v) {
   if (row < 0 || col < 0) return;  // inactive DoF (only reachable through user-overwritten tags)
-  int32_t *rc = s.cols + (int64_t)row * s.W;
-  double *rv = s.vals + (int64_t)row * s.W;
+  int W;
+  const int64_t base = slot_base(s, row, &W);
+  int32_t *rc = s.cols + base;
+  double *rv = s.vals + base;
   // open addressing inside the row: start at a hash of the column (W is a power of two), so a
   // lookup costs ~1-2 probes instead of a walk over the row's whole prefix
-  const int mask = s.W - 1;
+  const int mask = W - 1;
   int k = (int)(((uint32_t)col * 2654435761u) >> 16) & mask;
-  for (int t = 0; t < s.W; ++t, k = (k + 1) & mask) {
+  for (int t = 0; t < W; ++t, k = (k + 1) & mask) {
     int32_t cur = __hip_atomic_load(&rc[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (cur == -1) {
       cur = atomicCAS(&rc[k], -1, col);
@@ -213,11 +225,13 @@ __global__ void k_v2c_fill(int64_t nc, int nvpc, const int32_t *__restrict__ cel
 
 // plain (non-atomic) insert into a row this thread owns exclusively; same hash as slot_add
 __device__ __forceinline__ void slot_add_owned(const Slots &s, int32_t row, int32_t col, double v) {
-  int32_t *rc = s.cols + (int64_t)row * s.W;
-  double *rv = s.vals + (int64_t)row * s.W;
-  const int mask = s.W - 1;
+  int W;
+  const int64_t base = slot_base(s, row, &W);
+  int32_t *rc = s.cols + base;
+  double *rv = s.vals + base;
+  const int mask = W - 1;
   int k = (int)(((uint32_t)col * 2654435761u) >> 16) & mask;
-  for (int t = 0; t < s.W; ++t, k = (k + 1) & mask) {
+  for (int t = 0; t < W; ++t, k = (k + 1) & mask) {
     const int32_t cur = rc[k];
     if (cur == -1) { rc[k] = col; rv[k] = v; return; }
     if (cur == col) { rv[k] += v; return; }
@@ -684,6 +698,100 @@ k_row_fill_block(int64_t n, const int32_t *__restrict__ cols, const double *__re
   if (t < cnt) { ocol[base + t] = sc[t]; oval[base + t] = sv[t]; }
 }
 
+// ---- compaction of slot tables with per-row capacities (Slots::off / wlog)
+__global__ void k_row_counts_var(int64_t n, const int64_t *__restrict__ off, const uint8_t *__restrict__ wlog,
+                                 const int32_t *__restrict__ cols, int64_t *__restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; row < n; row += nwaves) {
+    const int W = 1 << wlog[row];
+    const int32_t *rc = cols + off[row];
+    int cnt = 0;
+    for (int k = lane; k < W; k += 64) cnt += rc[k] != -1;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) counts[row] = cnt;
+  }
+}
+
+// rows of up to 64 slots: one wave per row (as k_row_fill); wider rows are left to k_row_fill_list
+__global__ void k_row_fill_var(int64_t n, const int64_t *__restrict__ off, const uint8_t *__restrict__ wlog,
+                               const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                               const int64_t *__restrict__ rowptr, int32_t nent, const int32_t *__restrict__ du,
+                               const int32_t *__restrict__ dp, int32_t *__restrict__ ocol,
+                               double *__restrict__ oval, double *__restrict__ diag, int32_t *__restrict__ row_nz) {
+  const int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (row >= n || wlog[row] > 6) return;
+  const int W = 1 << wlog[row];
+  const int64_t sb = off[row];
+  int32_t c = 0x7fffffff;
+  double v = 0.0;
+  if (lane < W) {
+    const int32_t cc = cols[sb + lane];
+    if (cc != -1) { c = cc < nent ? du[cc] : dp[cc - nent]; v = vals[sb + lane]; }
+  }
+  if (c == (int32_t)row) diag[row] = v;
+  for (int k = 2; k <= 64; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int32_t oc = __shfl_xor(c, j);
+      const double ov = __shfl_xor(v, j);
+      const bool up = ((lane & k) == 0);
+      const bool lower = ((lane & j) == 0);
+      const bool take = (lower == up) ? (oc < c) : (oc > c);
+      if (take) { c = oc; v = ov; }
+    }
+  const int64_t base = rowptr[row];
+  const int64_t cnt = rowptr[row + 1] - base;
+  if (lane < cnt) { ocol[base + lane] = c; oval[base + lane] = v; }
+  const unsigned long long keep = __ballot(lane < cnt && (v != 0.0 || c == (int32_t)row));
+  if (lane == 0) row_nz[row] = __popcll(keep);
+}
+
+struct SelWideRow { const uint8_t *wlog; __host__ __device__ bool operator()(const int32_t &r) const { return wlog[r] > 6; } };
+
+// wide rows (capacity W > 64) from a list: one block of W threads per row, bitonic sort in LDS
+template <int W>
+__global__ void __launch_bounds__(W)
+k_row_fill_list(int64_t nlist, const int32_t *__restrict__ list, const int64_t *__restrict__ off,
+                const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                const int64_t *__restrict__ rowptr, int32_t nent, const int32_t *__restrict__ du,
+                const int32_t *__restrict__ dp, int32_t *__restrict__ ocol, double *__restrict__ oval,
+                double *__restrict__ diag, int32_t *__restrict__ row_nz) {
+  __shared__ int32_t sc[W];
+  __shared__ double sv[W];
+  __shared__ int nz;
+  const int64_t row = list[blockIdx.x];
+  const int t = threadIdx.x;
+  if (t == 0) nz = 0;
+  int32_t c = 0x7fffffff;
+  double v = 0.0;
+  const int64_t sb = off[row];
+  const int32_t cc = cols[sb + t];
+  if (cc != -1) { c = cc < nent ? du[cc] : dp[cc - nent]; v = vals[sb + t]; }
+  if (c == (int32_t)row) diag[row] = v;
+  sc[t] = c;
+  sv[t] = v;
+  __syncthreads();
+  if (c != 0x7fffffff && (v != 0.0 || c == (int32_t)row)) atomicAdd(&nz, 1);
+  for (int k = 2; k <= W; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int p = t ^ j;
+      if (p > t) {
+        const bool up = ((t & k) == 0);
+        const int32_t a = sc[t], b = sc[p];
+        if ((a > b) == up) {
+          sc[t] = b; sc[p] = a;
+          const double x = sv[t]; sv[t] = sv[p]; sv[p] = x;
+        }
+      }
+      __syncthreads();
+    }
+  const int64_t base = rowptr[row];
+  const int64_t cnt = rowptr[row + 1] - base;
+  if (t < cnt) { ocol[base + t] = sc[t]; oval[base + t] = sv[t]; }
+  if (t == 0) row_nz[row] = nz;
+}
+
 template <typename T>
 static int exclusive_sum(phx_mesh *m, const T *in, T *out, int64_t n) {
   size_t bytes = 0;
@@ -743,6 +851,7 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(hipStreamSynchronize(m->stream));
   if (overflow) {
     PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow)); PHX_HIP(phx_free(sl.clean));
+    PHX_HIP(phx_free((void *)sl.off)); PHX_HIP(phx_free((void *)sl.wlog));
     phx_set_error("row-slot capacity %d exceeded", W);
     return PHX_ERR_CAPACITY;
   }
@@ -752,7 +861,8 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(phx_malloc(&s->rowptr, sizeof(int64_t) * (size_t)(s->n + 1)));
   // 8 waves per SIMD x 4 SIMDs x 256 CUs, each walking rows with a wave stride
   const dim3 growave((unsigned)std::min<int64_t>(phx_div_up(s->n * 64, 256), 2048));
-  k_row_counts<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, sl.clean, counts);
+  if (sl.off) k_row_counts_var<<<growave, block, 0, m->stream>>>(s->n, sl.off, sl.wlog, sl.cols, counts);
+  else k_row_counts<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, sl.clean, counts);
   PHX_CHECK(exclusive_sum<int64_t>(m, counts, s->rowptr, s->n + 1));
   int64_t nnz = 0;
   PHX_HIP(hipMemcpy(&nnz, s->rowptr + s->n, sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -761,8 +871,27 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(phx_malloc(&s->val, sizeof(double) * (size_t)nnz));
   PHX_HIP(phx_malloc(&s->diag, sizeof(double) * (size_t)s->n));
   PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
-  if (W <= 64) PHX_HIP(phx_malloc(&s->row_nz, sizeof(int32_t) * (size_t)s->n));
-  if (W <= 64)  // one wave per row here: the wave-stride variant was slower (2.23 vs 1.89 ms), the sort hides nothing
+  if (W <= 64 || sl.off) PHX_HIP(phx_malloc(&s->row_nz, sizeof(int32_t) * (size_t)s->n));
+  if (sl.off) {
+    // per-row capacities: narrow rows one wave each, the wide ones (list) one block of W threads each
+    k_row_fill_var<<<dim3((unsigned)phx_div_up(s->n * 64, 256)), block, 0, m->stream>>>(
+        s->n, sl.off, sl.wlog, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p,
+        s->col, s->val, s->diag, s->row_nz);
+    int32_t *wide = nullptr;
+    int64_t nwide = 0;
+    PHX_CHECK(phx_select_indices(m->stream, s->n, SelWideRow{sl.wlog}, &wide, &nwide));
+    if (nwide > 0) {
+      const dim3 g((unsigned)nwide);
+      if (W == 128) k_row_fill_list<128><<<g, dim3(128), 0, m->stream>>>(nwide, wide, sl.off, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag, s->row_nz);
+      else if (W == 256) k_row_fill_list<256><<<g, dim3(256), 0, m->stream>>>(nwide, wide, sl.off, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag, s->row_nz);
+      else if (W == 512) k_row_fill_list<512><<<g, dim3(512), 0, m->stream>>>(nwide, wide, sl.off, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag, s->row_nz);
+      else if (W == 1024) k_row_fill_list<1024><<<g, dim3(1024), 0, m->stream>>>(nwide, wide, sl.off, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag, s->row_nz);
+      else { phx_set_error("unsupported wide-row capacity %d", W); return PHX_ERR_VALUE; }
+    }
+    PHX_HIP(hipGetLastError());
+    PHX_HIP(hipStreamSynchronize(m->stream));
+    PHX_HIP(phx_free(wide));
+  } else if (W <= 64)  // one wave per row here: the wave-stride variant was slower (2.23 vs 1.89 ms), the sort hides nothing
     k_row_fill<<<dim3((unsigned)phx_div_up(s->n * 64, 256)), block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, sl.clean, s->rowptr, nent,
                                                   s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag, s->row_nz);
   else if (W == 128)
@@ -785,6 +914,7 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(counts));
   PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow)); PHX_HIP(phx_free(sl.clean));
+  PHX_HIP(phx_free((void *)sl.off)); PHX_HIP(phx_free((void *)sl.wlog));
   return phx_system_build_sell(s);
 }
 

@@ -108,7 +108,7 @@ struct phx_mesh {
   int profile_spmv = 0;
   int spmv_xcd_group = 0;          // PHX_OPT_SPMV_XCD_GROUP
   int spmv_value_index = 1;        // PHX_OPT_SPMV_VALUE_INDEX
-  int precond = 1;                 // PHX_OPT_PRECOND: 0 Jacobi, 1 / 2 box sine transforms in f32 / f64 where applicable
+  int precond = 1;                 // PHX_OPT_PRECOND: 0 Jacobi, 1 / 2 box sine transforms in f64 / f32 where applicable
   int has_exterior_override = -1;  // -1: decide from the local tags; 0/1: imposed (multi-GPU)
 };
 

@@ -51,7 +51,7 @@ static int dst_pick_length(int64_t need) {
 // LDS index padding: one extra 16-byte element after every 8, so that the stride-8 / stride-64 write
 // patterns of the first Stockham stages spread over the banks (unpadded: up to 32-way conflicts)
 #define ZP(n) ((n) + ((n) >> 3))
-#define ZLEN(N) ((N) + ((N) >> 3) + 1)
+#define ZLEN(N) ((N) + ((N) >> 3) + 2)  // even: the scan scratch behind it holds doubles
 
 static int dst_get_plan(int device, int L, bool f32, DstPlan *out) {
   auto key = std::make_pair(device, f32 ? -L : L);
@@ -95,7 +95,7 @@ static int dst_get_plan(int device, int L, bool f32, DstPlan *out) {
          2 * P.pairs <= max_pairs)
     P.pairs *= 2;
   if (const char *e = getenv("PHX_DST_DEBUG")) P.dbg = atoi(e);
-  P.scr = P.tp + (P.tp + 7) / 8 + 1;
+  P.scr = 2 * (P.tp + (P.tp + 7) / 8 + 1);  // in complex values of the transform type; the scan runs in f64
   P.tab_off = P.pairs * (ZLEN(L) + P.scr);            // LDS copies of the tables: twiddles, then sines
   P.lds_elems = P.tab_off + L + (L / 2 + 2 + 1) / 2;
   std::vector<double2> tw((size_t)L);
@@ -271,7 +271,11 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
   psync<WAVE>();
   fft_pairs<T, WAVE>(w, P, t, live, tw);
   // thread t owns k = 4 t .. 4 t + 3  (k < L / 2)
-  C2<T> Wk[4], Wm[4], c[4];
+  // The running sums are kept in f64 whatever the transform precision: in f32 they are what turns the
+  // O(eps log L) error of the FFT into O(eps L) (2-D flower problem: 114-582 erratic iterations and
+  // occasional breakdowns with f32 sums against 38 with f64 transforms).
+  C2<T> Wk[4], Wm[4];
+  C2<double> c[4];
   if (live) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -281,9 +285,9 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
     }
   }
   psync<WAVE>();
-  C2<T> *tot = scr, *gt = scr + tp;
+  C2<double> *tot = reinterpret_cast<C2<double> *>(scr), *gt = tot + tp;
   if (live) {
-    C2<T> run = mk<T>(T(0), T(0));
+    C2<double> run = mk<double>(0.0, 0.0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = 4 * t + i;
@@ -294,24 +298,27 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
         R = mk<T>(hf * (Wk[i].x + Wm[i].x), hf * (Wk[i].y + Wm[i].y));
         w[ZP(2 * k)] = mk<T>(-hf * (Wk[i].y - Wm[i].y), hf * (Wk[i].x - Wm[i].x));
       }
-      run = cadd(run, R);
+      run = cadd(run, mk<double>((double)R.x, (double)R.y));
       c[i] = run;
     }
     tot[t] = run;
   }
   psync<WAVE>();
   if (live && t < (tp + 7) / 8) {
-    C2<T> g = mk<T>(T(0), T(0));
+    C2<double> g = mk<double>(0.0, 0.0);
     for (int q = 8 * t; q < min(8 * t + 8, tp); ++q) g = cadd(g, tot[q]);
     gt[t] = g;
   }
   psync<WAVE>();
   if (live) {
-    C2<T> E = mk<T>(T(0), T(0));
+    C2<double> E = mk<double>(0.0, 0.0);
     for (int g = 0; g < (t >> 3); ++g) E = cadd(E, gt[g]);
     for (int q = t & ~7; q < t; ++q) E = cadd(E, tot[q]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[ZP(2 * (4 * t + i) + 1)] = cadd(E, c[i]);
+    for (int i = 0; i < 4; ++i) {
+      const C2<double> F = cadd(E, c[i]);
+      w[ZP(2 * (4 * t + i) + 1)] = mk<T>((T)F.x, (T)F.y);
+    }
   }
   psync<WAVE>();
 }
@@ -725,7 +732,7 @@ static int box_precond_setup(phx_system *s) {
   const double *h = m->box_h;
   const double c3[3] = {h[1] * h[2] / h[0], h[0] * h[2] / h[1], h[0] * h[1] / h[2]};
   const double c2[3] = {h[1] / h[0], h[0] / h[1], 0.0};
-  int rc = box_grid_setup(bp, m->device, L, m->gdim == 3 ? c3 : c2, m->precond == 1);
+  int rc = box_grid_setup(bp, m->device, L, m->gdim == 3 ? c3 : c2, m->precond == 2);
   if (rc != PHX_OK) { box_precond_free(bp); return rc; }
   for (int a = 0; a < 3; ++a) bp->lo[a] = lo[a];
   const int64_t tot = bp->g.plane * bp->g.m[2];

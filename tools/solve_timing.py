@@ -1,5 +1,5 @@
 """Wall-clock of repeated solves of the bench system per preconditioner (0 Jacobi, 1 box sine transforms
-in f32, 2 in f64) -- development aid.  usage: solve_timing.py [cubes] [precond ...]"""
+in f64, 2 in f32) -- development aid.  usage: solve_timing.py [cubes] [precond ...]"""
 import os
 import sys
 import time
