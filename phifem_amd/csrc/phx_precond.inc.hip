@@ -85,7 +85,9 @@ static int dst_get_plan(int device, int L, bool f32, DstPlan *out) {
   if (const char *e = getenv("PHX_DST_WAVE")) P.wave = (P.tp <= 64) && atoi(e) != 0;  // tuning aid
   P.slot = P.wave ? (P.tp <= 32 ? 32 : 64) : P.tp;
   const int el = f32 ? (int)sizeof(float2) : (int)sizeof(double2);
-  int budget = (P.wave ? 64 : (L >= 768 ? 80 : (f32 ? 20 : 40))) * 1024;
+  // long f64 transforms take (almost) a whole CU's LDS per block to reach 128-byte tile rows
+  // (768 x 768 x 192 lattice, y pass: 80 KB 1057 us, 156 KB 669 us)
+  int budget = (P.wave ? 64 : (L >= 768 ? (f32 ? 80 : 156) : (f32 ? 20 : 40))) * 1024;
   int max_threads = P.wave ? 1024 : (L >= 768 ? 1024 : 512);
   int max_pairs = P.wave ? (f32 ? 16 : 8) : 1024;
   if (const char *e = getenv("PHX_DST_LDS_KB")) budget = atoi(e) > 0 ? atoi(e) * 1024 : budget;  // tuning aids
@@ -543,7 +545,7 @@ static void box_precond_free(phx_box_precond *bp) {
 
 template <typename T, bool WAVE>
 static int dst_allow_lds_t() {
-  const int bytes = 96 * 1024;  // padded transform data + scan scratch may exceed the 64 KB default
+  const int bytes = 160 * 1024;  // padded transform data + scan scratch may exceed the 64 KB default
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 0, WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 1, WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<T, 2, WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
