@@ -700,10 +700,15 @@ k_row_fill_block(int64_t n, const int32_t *__restrict__ cols, const double *__re
 
 // ---- compaction of slot tables with per-row capacities (Slots::off / wlog)
 __global__ void k_row_counts_var(int64_t n, const int64_t *__restrict__ off, const uint8_t *__restrict__ wlog,
-                                 const int32_t *__restrict__ cols, int64_t *__restrict__ counts) {
+                                 const int32_t *__restrict__ cols, const uint8_t *__restrict__ clean,
+                                 int64_t *__restrict__ counts) {
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6; row < n; row += nwaves) {
+    if (clean && clean[row]) {
+      if (lane == 0) counts[row] = clean[row];
+      continue;
+    }
     const int W = 1 << wlog[row];
     const int32_t *rc = cols + off[row];
     int cnt = 0;
@@ -716,6 +721,7 @@ __global__ void k_row_counts_var(int64_t n, const int64_t *__restrict__ off, con
 // rows of up to 64 slots: one wave per row (as k_row_fill); wider rows are left to k_row_fill_list
 __global__ void k_row_fill_var(int64_t n, const int64_t *__restrict__ off, const uint8_t *__restrict__ wlog,
                                const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                               const uint8_t *__restrict__ clean,
                                const int64_t *__restrict__ rowptr, int32_t nent, const int32_t *__restrict__ du,
                                const int32_t *__restrict__ dp, int32_t *__restrict__ ocol,
                                double *__restrict__ oval, double *__restrict__ diag, int32_t *__restrict__ row_nz) {
@@ -724,13 +730,15 @@ __global__ void k_row_fill_var(int64_t n, const int64_t *__restrict__ off, const
   if (row >= n || wlog[row] > 6) return;
   const int W = 1 << wlog[row];
   const int64_t sb = off[row];
+  const int nclean = clean ? clean[row] : 0;  // dense, sorted row: translate and copy
   int32_t c = 0x7fffffff;
   double v = 0.0;
-  if (lane < W) {
+  if (lane < (nclean ? nclean : W)) {
     const int32_t cc = cols[sb + lane];
     if (cc != -1) { c = cc < nent ? du[cc] : dp[cc - nent]; v = vals[sb + lane]; }
   }
   if (c == (int32_t)row) diag[row] = v;
+  if (!nclean)
   for (int k = 2; k <= 64; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       const int32_t oc = __shfl_xor(c, j);
@@ -861,7 +869,7 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(phx_malloc(&s->rowptr, sizeof(int64_t) * (size_t)(s->n + 1)));
   // 8 waves per SIMD x 4 SIMDs x 256 CUs, each walking rows with a wave stride
   const dim3 growave((unsigned)std::min<int64_t>(phx_div_up(s->n * 64, 256), 2048));
-  if (sl.off) k_row_counts_var<<<growave, block, 0, m->stream>>>(s->n, sl.off, sl.wlog, sl.cols, counts);
+  if (sl.off) k_row_counts_var<<<growave, block, 0, m->stream>>>(s->n, sl.off, sl.wlog, sl.cols, sl.clean, counts);
   else k_row_counts<<<growave, block, 0, m->stream>>>(s->n, W, sl.cols, sl.clean, counts);
   PHX_CHECK(exclusive_sum<int64_t>(m, counts, s->rowptr, s->n + 1));
   int64_t nnz = 0;
@@ -875,7 +883,7 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   if (sl.off) {
     // per-row capacities: narrow rows one wave each, the wide ones (list) one block of W threads each
     k_row_fill_var<<<dim3((unsigned)phx_div_up(s->n * 64, 256)), block, 0, m->stream>>>(
-        s->n, sl.off, sl.wlog, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p,
+        s->n, sl.off, sl.wlog, sl.cols, sl.vals, sl.clean, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p,
         s->col, s->val, s->diag, s->row_nz);
     int32_t *wide = nullptr;
     int64_t nwide = 0;

@@ -135,6 +135,127 @@ __global__ void __launch_bounds__(256) k_el_bulk(int64_t nc, ElArgs A) {
   }
 }
 
+// --- the same bulk terms on a Kuhn box, gathered per row: one thread per (vertex, side, component a) walks
+// the closed-form star of the vertex (k_assemble_rows_box) and accumulates the 15 neighbours x D components of
+// row u_side[a] in registers.  No atomics; rows no scattering kernel reaches are stored dense and sorted
+// (component-major, then vertex: the order of the active numbering).  The one-block-per-cell scatter above
+// (144 atomics per cell and side) took 172 of the 294 ms of a 256 x 256 x 40 slab.
+template <int D>
+__global__ void __launch_bounds__(256)
+k_el_bulk_box(int64_t nthreads, BoxDims bd, const uint8_t *__restrict__ touched, ElArgs A) {
+  using B = ElB<D>;
+  constexpr int N = D + 1, NPERM = D == 3 ? 6 : 2, NCODE = D == 3 ? 27 : 9;
+  constexpr int P[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+  constexpr int P2[2][3] = {{0, 1, 0}, {1, 0, 0}};
+  constexpr int POW3[3] = {1, 3, 9};
+  constexpr double c2 = D == 3 ? 1.0 / 20.0 : 1.0 / 12.0;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (tid >= nthreads) return;
+  const int64_t vtx = tid % A.nv;
+  const int sa = (int)(tid / A.nv);
+  const int side = sa / D, a = sa % D;
+  const int32_t row_full = (int32_t)(B::ublk(side, a) * (int64_t)A.nv + vtx);
+  const int32_t row = A.dofmap[row_full];
+  if (row < 0) return;
+  if (side == 0 && A.bc[vtx]) return;  // Dirichlet row: k_el_bc_rows writes it
+  const int64_t n0 = bd.n[0] + 1, n1 = bd.n[1] + 1;
+  int64_t idx[3] = {vtx % n0, D == 3 ? (vtx / n0) % n1 : vtx / n0, D == 3 ? vtx / (n0 * n1) : 0};
+  const int64_t vstride[3] = {1, n0, n0 * n1};
+  const int64_t cstride[3] = {1, bd.n[0], bd.n[0] * bd.n[1]};
+  const double lam = A.lam[side], mu = A.mu[side];
+  double acc[NCODE][D], nf[NCODE];
+  bool seen[NCODE];
+#pragma unroll
+  for (int code = 0; code < NCODE; ++code) {
+    int d[3] = {code % 3 - 1, (code / 3) % 3 - 1, D == 3 ? code / 9 - 1 : 0};
+    bool pos = false, neg = false;
+    for (int q = 0; q < D; ++q) { pos |= d[q] > 0; neg |= d[q] < 0; }
+    for (int q = 0; q < D; ++q) acc[code][q] = 0.0;
+    seen[code] = false;
+    nf[code] = 0.0;
+    if (pos && neg) continue;
+    bool in = true;
+    int64_t w = vtx;
+    for (int q = 0; q < D; ++q) {
+      const int64_t z = idx[q] + d[q];
+      in = in && z >= 0 && z <= bd.n[q];
+      w += d[q] * vstride[q];
+    }
+    if (in) nf[code] = A.f[(int64_t)a * A.nv + w];
+  }
+  constexpr int SELF = D == 3 ? 13 : 4;
+  double rhs = 0.0;
+#pragma unroll
+  for (int t = 0; t < NPERM; ++t) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+      int dd[3] = {0, 0, 0};
+      for (int q = 0; q < m; ++q) dd[D == 3 ? P[t][q] : P2[t][q]] -= 1;
+      bool in = true;
+      int64_t cube = 0;
+      for (int q = 0; q < D; ++q) {
+        const int64_t o = idx[q] + dd[q];
+        in = in && o >= 0 && o < bd.n[q];
+        cube += o * cstride[q];
+      }
+      if (!in) continue;
+      const int tag = A.ctags[cube * NPERM + t] & PHX_TAG_MASK;
+      if (side == 0 ? !(tag == 1 || tag == 2) : !(tag == 2 || tag == 3)) continue;
+      int code[N];
+      double X[N][D];
+      double sf = 0.0;
+      for (int q = 0; q < N; ++q) {
+        code[q] = 0;
+        for (int r = 0; r < D; ++r) code[q] += (dd[r] + 1) * POW3[r];
+        for (int r = 0; r < D; ++r) X[q][r] = (double)dd[r] * bd.h[r];
+        sf += nf[code[q]];
+        if (q < D) dd[D == 3 ? P[t][q] : P2[t][q]] += 1;
+      }
+      Geo<D> G;
+      simplex_geometry<D>(X, G);
+      // eps(N_m e_a) : sigma(N_j e_c) = sigma(N_j e_c)[a][:] . g_m
+      for (int j = 0; j < N; ++j) {
+        for (int cc = 0; cc < D; ++cc) {
+          double k = 0.0;
+          for (int q = 0; q < D; ++q) k += sig_pq<D>(G, lam, mu, j, cc, a, q) * G.g[m][q];
+          acc[code[j]][cc] += k * G.vol;
+        }
+        seen[code[j]] = true;
+      }
+      rhs += G.vol * c2 * (sf + nf[SELF]);
+    }
+  }
+  const bool clean = A.slots.clean && touched && !touched[vtx];
+  int W;
+  const int64_t sbase = slot_base(A.slots, row, &W);
+  int cnt = 0;
+  // component-major, then vertex: ascending active column
+#pragma unroll
+  for (int cc = 0; cc < D; ++cc) {
+#pragma unroll
+    for (int code = 0; code < NCODE; ++code) {
+      if (!seen[code]) continue;
+      int64_t w = vtx;
+      w += (code % 3 - 1) * vstride[0] + ((code / 3) % 3 - 1) * vstride[1];
+      if (D == 3) w += (code / 9 - 1) * vstride[2];
+      const int32_t col_full = (int32_t)(B::ublk(side, cc) * (int64_t)A.nv + w);
+      if (side == 0 && A.bc[w]) {       // prescribed column: lifting (apply_lifting, main.py:271-274)
+        rhs -= acc[code][cc] * A.ud[col_full];
+        continue;
+      }
+      if (clean) {
+        A.slots.cols[sbase + cnt] = col_full;
+        A.slots.vals[sbase + cnt] = acc[code][cc];
+        ++cnt;
+      } else {
+        slot_add_owned(A.slots, row, col_full, acc[code][cc]);
+      }
+    }
+  }
+  if (clean) A.slots.clean[row] = (uint8_t)cnt;
+  A.rhs[row] += rhs;
+}
+
 // --- cut cells: penalization main.py:188-203, cell stabilisation :211-217, rhs :255-260 ------------
 template <int D>
 __global__ void __launch_bounds__(256) k_el_cut(int64_t nlist, const int32_t *__restrict__ list, ElArgs A) {
@@ -407,15 +528,42 @@ static int assemble_el_with_capacity(phx_mesh *m, const double *params, const do
   PHX_CHECK(build_list(m, m->nf, SelFacetTagInterior{m->facet_tags, m->f2c, 3}, &l_f3, &n_f3));
   PHX_CHECK(build_list(m, m->nf, SelFacetTagInterior{m->facet_tags, m->f2c, 4}, &l_f4, &n_f4));
   PHX_CHECK(phx_collect_entities(m));
+  uint8_t *touched = nullptr;
+  if (m->is_box) {
+    // rows of vertices no scattering kernel reaches are written dense and sorted by the gather kernel
+    PHX_HIP(phx_malloc(&touched, (size_t)m->nv));
+    PHX_HIP(phx_malloc(&sl.clean, (size_t)n));
+    PHX_HIP(hipMemsetAsync(touched, 0, (size_t)m->nv, m->stream));
+    PHX_HIP(hipMemsetAsync(sl.clean, 0, (size_t)n, m->stream));
+    const dim3 gb(256);
+#define PHX_MARK(NN)                                                                                             \
+    do {                                                                                                          \
+      if (n_cut) k_mark_cells<NN><<<dim3((unsigned)phx_div_up(n_cut, 256)), gb, 0, m->stream>>>(n_cut, l_cut, m->cells, touched); \
+      if (n_f3) k_mark_facet_cells<NN><<<dim3((unsigned)phx_div_up(n_f3, 256)), gb, 0, m->stream>>>(n_f3, l_f3, m->f2c, m->cells, touched); \
+      if (n_f4) k_mark_facet_cells<NN><<<dim3((unsigned)phx_div_up(n_f4, 256)), gb, 0, m->stream>>>(n_f4, l_f4, m->f2c, m->cells, touched); \
+      for (int sd = 0; sd < 2; ++sd)                                                                              \
+        if (m->ent_count[sd])                                                                                     \
+          k_mark_entity_cells<NN><<<dim3((unsigned)phx_div_up(m->ent_count[sd], 256)), gb, 0, m->stream>>>(       \
+              m->ent_count[sd], m->ent_buf[sd], m->cells, touched);                                               \
+    } while (0)
+    if (D == 2) PHX_MARK(3); else PHX_MARK(4);
+#undef PHX_MARK
+    A.slots = sl;
+    const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}, {m->box_h[0], m->box_h[1], m->box_h[2]}};
+    const int64_t nthreads = 2 * (int64_t)D * m->nv;
+    const dim3 g((unsigned)phx_div_up(nthreads, 256));
+    if (D == 2) k_el_bulk_box<2><<<g, block, 0, m->stream>>>(nthreads, bd, touched, A);
+    else k_el_bulk_box<3><<<g, block, 0, m->stream>>>(nthreads, bd, touched, A);
+  }
   if (D == 2) {
-    k_el_bulk<2><<<dim3((unsigned)m->nc), block, 0, m->stream>>>(m->nc, A);
+    if (!m->is_box) k_el_bulk<2><<<dim3((unsigned)m->nc), block, 0, m->stream>>>(m->nc, A);
     if (n_cut) k_el_cut<2><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, A);
     for (int sd = 0; sd < 2; ++sd)
       if (m->ent_count[sd]) k_el_ds<2><<<dim3((unsigned)m->ent_count[sd]), block, 0, m->stream>>>(m->ent_count[sd], m->ent_buf[sd], sd, A);
     if (n_f3) k_el_facets<2><<<dim3((unsigned)n_f3), block, 0, m->stream>>>(n_f3, l_f3, 0, A);
     if (n_f4) k_el_facets<2><<<dim3((unsigned)n_f4), block, 0, m->stream>>>(n_f4, l_f4, 1, A);
   } else {
-    k_el_bulk<3><<<dim3((unsigned)m->nc), block, 0, m->stream>>>(m->nc, A);
+    if (!m->is_box) k_el_bulk<3><<<dim3((unsigned)m->nc), block, 0, m->stream>>>(m->nc, A);
     if (n_cut) k_el_cut<3><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, A);
     for (int sd = 0; sd < 2; ++sd)
       if (m->ent_count[sd]) k_el_ds<3><<<dim3((unsigned)m->ent_count[sd]), block, 0, m->stream>>>(m->ent_count[sd], m->ent_buf[sd], sd, A);
@@ -427,6 +575,7 @@ static int assemble_el_with_capacity(phx_mesh *m, const double *params, const do
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_f3)); PHX_HIP(phx_free(l_f4)); PHX_HIP(phx_free(bc));
+  PHX_HIP(phx_free(touched));
   const int rc = phx_finish_system(s, sl, (int32_t)nent);
   if (rc != PHX_OK) { phx_system_destroy(s); return rc; }
   *out = s;

@@ -19,7 +19,7 @@ warnings.simplefilter("ignore")
 p = ElasticitySlabProblem(nxy, nz, rank=3, world=8, device=0)
 p.setup()
 torch.cuda.synchronize()
-for rep in range(2):
+for rep in range(5):
     t0 = time.perf_counter()
     staged = _tag_cells(p.mesh, NodalFunction(p.phi), 1, single_layer_cut=False)
     _tag_facets(p.mesh, staged, 1)
