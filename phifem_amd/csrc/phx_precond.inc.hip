@@ -17,7 +17,9 @@
 // every sub-transform size is a power of two), twiddles from a table.  x lines are contiguous; y and z lines
 // are walked as tiles of W adjacent columns so that every global access is a contiguous run of W doubles.
 // Five passes over the lattice per application: x (gather from the Krylov vector), y, z (forward +
-// 1/lambda + inverse fused in LDS), y, x (scatter).
+// 1/lambda + inverse fused in LDS), y, x (scatter).  Templated on the precision of lattice and transforms:
+// f64 is the default; f32 is an opt-in (faster, but BiCGStab is not a flexible method and the half-length
+// transform amplifies rounding by O(L): erratic on some problems).
 #include <limits.h>
 #include <math.h>
 
@@ -524,7 +526,7 @@ struct phx_box_precond {
   BoxGrid g;
   DstPlan plan[3];
   void *G = nullptr;         // lattice array, f32 or f64
-  bool f32 = true;           // precision of the lattice array and the transforms
+  bool f32 = false;          // precision of the lattice array and the transforms
   int32_t *gmap = nullptr;   // [plane * m2] solver position of the u DoF, -1 none
   double *dscale = nullptr;  // [n] diag of A in solver order
   double *vec = nullptr;     // [2 n] preconditioned directions of the library-owned workspace
