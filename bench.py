@@ -6,8 +6,9 @@ One "step" = one full pass of the hot path over one synthetic problem already re
 Workload at N=1: BASELINE.json configs[1] -- spherical level-set, P1 x P1, 256^3 Kuhn box
 (100 663 296 tetrahedra, 16 974 593 vertices) on [-1.5,1.5]^3, manufactured f / u_D,
 gamma = sigma = 1, detection degree 1, single-layer cut, box mode.
-N>1: weak scaling -- every rank owns a 256x256x256 slab of a 256x256x(256 N) box around the
-ellipsoid x^2 + y^2 + (z/N)^2 = 1 (same h, same per-GPU work), see phifem_amd/distributed.py.
+N>1: weak scaling -- every rank owns a 256x256x256 slab of a 256x256x(256 N) box around the capsule
+x^2 + y^2 + max(|z| - 1.5 (N - 1), 0)^2 = 1 (the sphere of N = 1 stretched by a cylinder of radius 1: same h,
+same work per unit length, full cross-sections at every slab interface), see phifem_amd/distributed.py.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 """
@@ -221,7 +222,10 @@ def main():
             workload = ("3D weak-Dirichlet Poisson phi-FEM, P1xP1, unit sphere, 1024x1024x128 Kuhn slab per GPU "
                         "(805306368 tets), box mode, single-layer cut, gamma=sigma=1")
         else:
-            workload = (f"3D weak-Dirichlet Poisson phi-FEM, P1xP1, spherical level-set, {n}^3 Kuhn box per GPU "
+            shape = "spherical level-set" if world == 1 else (
+                f"capsule level-set (radius 1, cylinder length {3 * (world - 1)}: the sphere stretched along z over "
+                f"the {world} slabs)")
+            workload = (f"3D weak-Dirichlet Poisson phi-FEM, P1xP1, {shape}, {n}^3 Kuhn box per GPU "
                         f"({6 * n ** 3} tets), box mode, single-layer cut, gamma=sigma=1")
         out = {
             "metric": ("assembled+solved DoF/s, 3D interface elasticity phi-FEM (tag+assemble+solve)" if args.config4

@@ -29,11 +29,15 @@ def slab_layout(n_per_rank, rank, world, ghost=GHOST_LAYERS):
 
 
 class SlabProblem:
-    """BASELINE configs[1] per GPU, weak-scaled: n^3 cubes per rank of an n x n x (n*world) box
-    on [-1.5,1.5]^2 x [-1.5*world, 1.5*world] around x^2 + y^2 + (z/world)^2 = 1."""
+    """BASELINE configs[1] per GPU, weak-scaled: n^3 cubes per rank of an n x n x (n*world) box on
+    [-1.5,1.5]^2 x [-1.5*world, 1.5*world] around the capsule  x^2 + y^2 + max(|z| - c, 0)^2 = 1,
+    c = 1.5 (world - 1): the unit sphere of configs[1] for one rank, a cylinder of radius 1 with
+    hemispherical caps for more -- one connected domain with full cross-sections at every slab interface
+    and the same work per unit length (an ellipsoid stretched with `world` gives the middle slabs 2.25 x
+    the DoFs of the sphere and leaves the end slabs empty)."""
 
     def __init__(self, n_per_rank, rank=0, world=1, device=0, rtol=1e-8, max_iter=20000, nxy=None):
-        """nxy = None: BASELINE configs[1] weak-scaled (n^3 cubes per rank, ellipsoid).
+        """nxy = None: BASELINE configs[1] weak-scaled (n^3 cubes per rank, capsule).
         nxy = 1024, n_per_rank = 128: BASELINE configs[4] -- the 1024^3 box of [-1.5,1.5]^3 cut into
         eight 1024 x 1024 x 128 slabs; with `world` < 8 ranks the z-range shrinks to [-1.5 world/8, 1.5 world/8], around the UNIT SPHERE (same h)."""
         self.n, self.rank, self.world, self.device = n_per_rank, rank, world, device
@@ -57,12 +61,12 @@ class SlabProblem:
         dev = torch.device("cuda", self.device)
         x = torch.empty((self.mesh.nv, 3), dtype=torch.float64, device=dev)
         L.check(L.lib.phx_mesh_get_array(self.mesh._h, L.ARR_COORDS, C.c_void_p(x.data_ptr()), L.DEVICE))
-        zs = x[:, 2] if self.config5 else x[:, 2] / float(w)
-        zscale = 1.0 if self.config5 else float(w)
-        self.phi = x[:, 0] ** 2 + x[:, 1] ** 2 + zs ** 2 - 1.0
-        # manufactured solution u = sin x sin y sin(z/s):  -Laplace(u) = (2 + 1/s^2) u
-        self.u_ex = torch.sin(x[:, 0]) * torch.sin(x[:, 1]) * torch.sin(zs)
-        self.f = (2.0 + 1.0 / (zscale * zscale)) * self.u_ex
+        cyl = 0.0 if self.config5 else 1.5 * (w - 1)   # half length of the cylindrical part
+        dz = torch.clamp(torch.abs(x[:, 2]) - cyl, min=0.0)
+        self.phi = x[:, 0] ** 2 + x[:, 1] ** 2 + dz ** 2 - 1.0
+        # manufactured solution u = sin x sin y sin z:  -Laplace(u) = 3 u
+        self.u_ex = torch.sin(x[:, 0]) * torch.sin(x[:, 1]) * torch.sin(x[:, 2])
+        self.f = 3.0 * self.u_ex
         self.out = torch.empty(2 * self.mesh.nv, dtype=torch.float64, device=dev)
         del x
         torch.cuda.synchronize()

@@ -16,11 +16,12 @@ S_RHO, S_ALPHA, S_OMEGA, S_BB, S_RR = 0, 1, 2, 3, 4
 R_RV, R_TS, R_TT, R_RHO, R_RR = 0, 1, 2, 4, 5
 
 
-def ellipsoid_data(x, world):
-    zs = x[:, 2] / float(world)
-    phi = x[:, 0] ** 2 + x[:, 1] ** 2 + zs ** 2 - 1.0
-    uex = np.sin(x[:, 0]) * np.sin(x[:, 1]) * np.sin(zs)
-    f = (2.0 + 1.0 / float(world * world)) * uex
+def capsule_data(x, world):
+    """The weak-scaling problem of phifem_amd.distributed.SlabProblem: capsule of radius 1 along z."""
+    dz = np.maximum(np.abs(x[:, 2]) - 1.5 * (world - 1), 0.0)
+    phi = x[:, 0] ** 2 + x[:, 1] ** 2 + dz ** 2 - 1.0
+    uex = np.sin(x[:, 0]) * np.sin(x[:, 1]) * np.sin(x[:, 2])
+    f = 3.0 * uex
     return phi, f, uex
 
 
@@ -30,7 +31,7 @@ def assemble_local(n, world, k0, k1, has_exterior=None):
     x, cells = meshgen.create_box(lo, hi, [n, n, k1 - k0], offset=[0, 0, k0],
                                   n_global=[n, n, n * world])
     topo = Topology("tetrahedron", cells, x.shape[0])
-    phi, f, uex = ellipsoid_data(x, world)
+    phi, f, uex = capsule_data(x, world)
     ls = OT.NodalP1(phi)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -58,10 +58,10 @@ def test_slabs_on_one_gpu_match_single_mesh(world, tmp_path):
     # the same global problem on one mesh
     mesh = P.create_box([-1.5, -1.5, -1.5 * world], [1.5, 1.5, 1.5 * world], [n, n, n * world])
     x = mesh.x
-    zs = x[:, 2] / float(world)
-    phi = x[:, 0] ** 2 + x[:, 1] ** 2 + zs ** 2 - 1.0
-    uex = np.sin(x[:, 0]) * np.sin(x[:, 1]) * np.sin(zs)
-    f = (2.0 + 1.0 / float(world * world)) * uex
+    dz = np.maximum(np.abs(x[:, 2]) - 1.5 * (world - 1), 0.0)   # the capsule of SlabProblem
+    phi = x[:, 0] ** 2 + x[:, 1] ** 2 + dz ** 2 - 1.0
+    uex = np.sin(x[:, 0]) * np.sin(x[:, 1]) * np.sin(x[:, 2])
+    f = 3.0 * uex
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         P.compute_tags_measures(mesh, NodalFunction(phi), 1, box_mode=True, single_layer_cut=True)
