@@ -103,6 +103,11 @@ struct phx_mesh {
   // sub-mesh provenance
   bool is_submesh = false;
   int32_t *c_map_h = nullptr, *v_map_h = nullptr;
+  // sub-mesh of a Kuhn box: the lattice of the parent (box_n, box_h are copied) and the two vertex maps on
+  // the device, so that the box preconditioner applies to sub-mesh systems too
+  bool on_box_lattice = false;
+  int32_t *v2lat = nullptr;   // [nv]          sub-mesh vertex -> parent lattice vertex
+  int32_t *lat2v = nullptr;   // [parent nv]   parent lattice vertex -> sub-mesh vertex or -1
   double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   bool own_stream = true;
   int profile_spmv = 0;

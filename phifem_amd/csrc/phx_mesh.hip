@@ -761,6 +761,7 @@ extern "C" int phx_mesh_destroy(phx_mesh *m) {
                   m->edges, m->c2e_is_alias ? nullptr : (void *)m->c2e};
   for (void *p : ptrs) (void)phx_free(p);
   free(m->c_map_h); free(m->v_map_h);
+  (void)phx_free(m->v2lat); (void)phx_free(m->lat2v);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);

@@ -647,14 +647,15 @@ void phx_box_precond_destroy(phx_box_precond *bp) { box_precond_free(bp); }
 // wavefront serialise: the z maximum improves with almost every wave in index order, 3.7 ms at 256^3).
 __global__ void __launch_bounds__(256)
 k_active_bbox(int64_t nv, int64_t n0, int64_t n1, const int32_t *__restrict__ du,
-              const int32_t *__restrict__ iperm, const uint8_t *__restrict__ own, int *__restrict__ out) {
+              const int32_t *__restrict__ iperm, const uint8_t *__restrict__ own,
+              const int32_t *__restrict__ v2lat, int *__restrict__ out) {
   __shared__ int red[6][4];
   int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {-1, -1, -1};
   const uint32_t m0 = (uint32_t)n0, m1 = (uint32_t)n1;  // nv < 2^31
   for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nv; v += (int64_t)gridDim.x * blockDim.x) {
     const int32_t d = du[v];
     if (d >= 0 && (!own || own[iperm[d]])) {
-      const uint32_t w = (uint32_t)v, q = w / m0;
+      const uint32_t w = v2lat ? (uint32_t)v2lat[v] : (uint32_t)v, q = w / m0;
       const int idx[3] = {(int)(w - q * m0), (int)(q % m1), (int)(q / m1)};
       for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], idx[a]); hi[a] = max(hi[a], idx[a]); }
     }
@@ -677,14 +678,17 @@ k_active_bbox(int64_t nv, int64_t n0, int64_t n1, const int32_t *__restrict__ du
 
 __global__ void k_box_gmap(BoxGrid g, int lo0, int lo1, int lo2, int64_t n0, int64_t n1, int64_t n2,
                            const int32_t *__restrict__ du, const int32_t *__restrict__ iperm,
-                           const uint8_t *__restrict__ own, int32_t *__restrict__ gmap) {
+                           const uint8_t *__restrict__ own, const int32_t *__restrict__ lat2v,
+                           int32_t *__restrict__ gmap) {
   const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (e >= g.plane * g.m[2]) return;
   const int x = (int)(e % g.pitch), y = (int)((e / g.pitch) % g.m[1]), z = (int)(e / g.plane);
   int32_t q = -1;
   const int64_t i = lo0 + 1 + x, j = lo1 + 1 + y, k = lo2 + 1 + z;
   if (x < g.m[0] && i >= 0 && i < n0 && j >= 0 && j < n1 && k >= 0 && k < n2) {
-    const int32_t d = du[i + n0 * (j + n1 * k)];
+    int64_t v = i + n0 * (j + n1 * k);
+    if (lat2v) v = lat2v[v];  // sub-mesh of the box: its own vertex numbering (-1: not in the sub-mesh)
+    const int32_t d = v >= 0 ? du[v] : -1;
     if (d >= 0) {
       const int32_t pos = iperm[d];
       if (!own || own[pos]) q = pos;
@@ -712,14 +716,14 @@ __global__ void k_dscale(int64_t n, const int32_t *__restrict__ perm, const doub
 static int box_precond_setup(phx_system *s) {
   phx_mesh *m = s->mesh;
   s->precond_state = -1;
-  if (!m->precond || !m->is_box || !s->u_vertex_block) return PHX_OK;
+  if (!m->precond || !(m->is_box || m->on_box_lattice) || !s->u_vertex_block) return PHX_OK;
   hipStream_t st = m->stream;
   const int64_t n0 = m->box_n[0] + 1, n1 = m->box_n[1] + 1, n2 = m->gdim == 3 ? m->box_n[2] + 1 : 1;
   int *dbb = nullptr, hbb[6] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1};
   PHX_HIP(phx_malloc(&dbb, sizeof(hbb)));
   PHX_HIP(hipMemcpyAsync(dbb, hbb, sizeof(hbb), hipMemcpyHostToDevice, st));
   k_active_bbox<<<dim3((unsigned)std::min<int64_t>(phx_div_up(m->nv, 256), 1024)), dim3(256), 0, st>>>(
-      m->nv, n0, n1, s->dof_of_vertex_u, s->iperm, s->own, dbb);
+      m->nv, n0, n1, s->dof_of_vertex_u, s->iperm, s->own, m->v2lat, dbb);
   PHX_HIP(hipMemcpyAsync(hbb, dbb, sizeof(hbb), hipMemcpyDeviceToHost, st));
   PHX_HIP(hipStreamSynchronize(st));
   PHX_HIP(phx_free(dbb));
@@ -747,7 +751,7 @@ static int box_precond_setup(phx_system *s) {
     return PHX_ERR_HIP;
   }
   k_box_gmap<<<dim3((unsigned)phx_div_up(tot, 256)), dim3(256), 0, st>>>(
-      bp->g, lo[0], lo[1], lo[2], n0, n1, n2, s->dof_of_vertex_u, s->iperm, s->own, bp->gmap);
+      bp->g, lo[0], lo[1], lo[2], n0, n1, n2, s->dof_of_vertex_u, s->iperm, s->own, m->lat2v, bp->gmap);
   k_dscale<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(s->n, s->perm, s->diag, bp->dscale);
   if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
   // rows outside the u block (active rows are numbered u first): P is the identity there.  The other

@@ -59,6 +59,14 @@ extern "C" int phx_submesh_create(phx_mesh *m, phx_mesh **sub_out) {
   PHX_CHECK(phx_set_tags(s, 0, sct.data(), PHX_HOST));
   PHX_CHECK(phx_set_tags(s, 1, sft.data(), PHX_HOST));
   s->is_submesh = true;
+  if (m->is_box) {
+    s->on_box_lattice = true;
+    for (int a = 0; a < 3; ++a) { s->box_n[a] = m->box_n[a]; s->box_h[a] = m->box_h[a]; }
+    PHX_HIP(phx_malloc(&s->v2lat, sizeof(int32_t) * v_map.size()));
+    PHX_HIP(phx_malloc(&s->lat2v, sizeof(int32_t) * (size_t)m->nv));
+    PHX_HIP(hipMemcpy(s->v2lat, v_map.data(), sizeof(int32_t) * v_map.size(), hipMemcpyHostToDevice));
+    PHX_HIP(hipMemcpy(s->lat2v, renum.data(), sizeof(int32_t) * (size_t)m->nv, hipMemcpyHostToDevice));
+  }
   s->c_map_h = (int32_t *)malloc(sizeof(int32_t) * c_map.size());
   s->v_map_h = (int32_t *)malloc(sizeof(int32_t) * v_map.size());
   memcpy(s->c_map_h, c_map.data(), sizeof(int32_t) * c_map.size());

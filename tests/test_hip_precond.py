@@ -121,3 +121,31 @@ def test_preconditioner_in_2d(P):
     assert res[1][1]["relres"] <= 1e-9
     assert res[1][1]["iterations"] < 0.6 * res[0][1]["iterations"]
     assert np.abs(res[1][0] - res[0][0]).max() <= 1e-6 * np.abs(res[0][0]).max()
+
+
+@pytest.mark.parametrize("d,n", [(2, 128), (3, 40)])
+def test_preconditioner_on_submesh_of_a_box(P, d, n):
+    """box_mode=False: the sub-mesh of Omega_h keeps the parent's lattice, so the box preconditioner applies
+    (demo/weak-dirichlet/flower/main.py `sub`)."""
+    import warnings
+    from phifem_amd import _lib as L_
+    from phifem_amd.mesh_scripts import NodalFunction
+    res = {}
+    for pc in (0, 1):
+        mesh = P.create_box([-1.5] * d, [1.5] * d, [n] * d)
+        x = mesh.x
+        phi = (x ** 2).sum(axis=1) - 1.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, _, sub, _, _ = P.compute_tags_measures(mesh, NodalFunction(phi), 1, box_mode=False, single_layer_cut=True)
+        L_.check(L_.lib.phx_set_option(sub._h, L_.OPT_PRECOND, pc))
+        xs = sub.x
+        phis = (xs ** 2).sum(axis=1) - 1.0
+        uex = np.prod(np.sin(xs), axis=1)
+        s = P.PhiFEMSolver(sub)
+        s.assemble(phis, float(d) * uex, uex)
+        res[pc] = (s.solve(rtol=1e-9, max_iter=20000), dict(s.stats))
+    assert res[0][1]["precond"] == "jacobi" and res[1][1]["precond"] == "box-dst"
+    assert res[1][1]["relres"] <= 1e-9
+    assert res[1][1]["iterations"] < 0.6 * res[0][1]["iterations"]
+    assert np.abs(res[1][0] - res[0][0]).max() <= 1e-6 * np.abs(res[0][0]).max()
