@@ -31,7 +31,6 @@ struct DstPlan {
   int wave = 0;                 // 1: pairs never straddle a wavefront (wave-local synchronisation)
   int radix[8], pw[8], tws[8];  // per stage: radix R, sub-transform size p so far (a power of two), L / (p R)
   int scr = 0;                  // scan scratch per pair (complex doubles)
-  int dbg = 0;                  // tuning aid (PHX_DST_DEBUG): 1 skips the transforms, 2 the global loads / stores
   int tab_off = 0;              // offset (complex values) of the table copies in LDS
   int lds_elems = 0;            // complex values of dynamic LDS per block
   double2 *tw = nullptr;        // device, exp(-2 pi i j / L), j < L
@@ -98,7 +97,6 @@ static int dst_get_plan(int device, int L, bool f32, DstPlan *out) {
   while ((2 * P.pairs * ZLEN(L) + 2 * L) * el <= budget && 2 * P.pairs * P.slot <= max_threads &&
          2 * P.pairs <= max_pairs)
     P.pairs *= 2;
-  if (const char *e = getenv("PHX_DST_DEBUG")) P.dbg = atoi(e);
   P.scr = 2 * (P.tp + (P.tp + 7) / 8 + 1);  // in complex values of the transform type; the scan runs in f64
   P.tab_off = P.pairs * (ZLEN(L) + P.scr);            // LDS copies of the tables: twiddles, then sines
   P.lds_elems = P.tab_off + L + (L / 2 + 2 + 1) / 2;
@@ -476,7 +474,7 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
     T vv[16];
     const T *gp = G + (base + (int64_t)row0 * estride + tcol);
     const int64_t gstep = (int64_t)rstep * estride;
-    const bool colok = tcol < ncols && P.dbg != 2;
+    const bool colok = tcol < ncols;
     int row = row0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -492,8 +490,8 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
     }
   }
   __syncthreads();
-  if (P.dbg != 1) dst_core<T, WAVE>(w, scr, P, t, live, tw, sn);
-  if (SOLVE && P.dbg != 1) {
+  dst_core<T, WAVE>(w, scr, P, t, live, tw, sn);
+  if (SOLVE) {
     if (live) {
       const double *lx = g.lam[0], *ly = g.lam[1], *lz = g.lam[2];
       const int kx = col0 + 2 * pr + 1;
@@ -513,11 +511,9 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
   __syncthreads();
   if (tcol < ncols) {
     const T *wc = reinterpret_cast<const T *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
-    if (P.dbg != 2 || wc[0] == T(12345)) {
-      T *gp = G + (base + (int64_t)row0 * estride + tcol);
-      const int64_t gstep = (int64_t)rstep * estride;
-      for (int row = row0; row < len; row += rstep) { *gp = wc[2 * ZP(row + 1)]; gp += gstep; }
-    }
+    T *gp = G + (base + (int64_t)row0 * estride + tcol);
+    const int64_t gstep = (int64_t)rstep * estride;
+    for (int row = row0; row < len; row += rstep) { *gp = wc[2 * ZP(row + 1)]; gp += gstep; }
   }
 }
 
