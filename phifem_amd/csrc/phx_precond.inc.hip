@@ -82,7 +82,7 @@ static int dst_get_plan(int device, int L, bool f32, DstPlan *out) {
   // Measured, block -> wave mode (x / y / z pass, us): L = 256: 42/66/88 -> 38/43/70; 512x512x128 (y): 263 -> 86.
   // Only where no lane idles (L = 256, 512): at L = 192 / 384 / 128 the 25-50 % empty slot lanes cost as
   // much issue time as the barriers save (the transforms are VALU/LDS-issue bound).
-  P.wave = (P.tp == 32 || P.tp == 64) ? 1 : 0;
+  P.wave = (P.tp == 32 || P.tp == 64 || (!f32 && P.tp == 24)) ? 1 : 0;  // f64, L = 192: 190 -> 185 us per application
   if (const char *e = getenv("PHX_DST_WAVE")) P.wave = (P.tp <= 64) && atoi(e) != 0;  // tuning aid
   P.slot = P.wave ? (P.tp <= 32 ? 32 : 64) : P.tp;
   const int el = f32 ? (int)sizeof(float2) : (int)sizeof(double2);
