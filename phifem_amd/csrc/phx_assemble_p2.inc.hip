@@ -417,6 +417,7 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
   PHX_REQUIRE(2 * nent < INT32_MAX, PHX_ERR_VALUE, "too many P2 DoFs for 32-bit column keys");
   phx_system *s = new phx_system();
   s->mesh = m; s->device = m->device; s->nfull = 2 * nent; s->slot_cap = W; s->nent = nent;
+  s->u_p2_block = true;
   const dim3 block(256);
   std::vector<void *> keep;
   P2Args P;

@@ -153,6 +153,7 @@ struct phx_system {
   const uint8_t *own = nullptr;
   // fictitious-domain preconditioner (phx_precond.inc.hip): built on demand for P1 Poisson systems on 3-D boxes
   bool u_vertex_block = false;     // rows [0, nu) are one scalar u DoF per active vertex
+  bool u_p2_block = false;         // rows [0, nu): P2, one DoF per active vertex and edge (entities nv + ne)
   struct phx_box_precond *precond = nullptr;
   int precond_state = 0;           // 0 not tried, 1 built, -1 not applicable
   std::vector<hipEvent_t> prof_ev[2];  // event pairs of the sampled launches: [0] SpMV, [1] sine-transform y pass

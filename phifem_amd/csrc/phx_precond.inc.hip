@@ -672,6 +672,76 @@ k_active_bbox(int64_t nv, int64_t n0, int64_t n1, const int32_t *__restrict__ du
   }
 }
 
+// ---- P2: the DoFs (vertices and edge midpoints of the Kuhn box) are exactly the points of the lattice of
+// spacing h / 2 (every face and every cube holds one diagonal, so each face and cube centre carries one edge
+// DoF); P1 on that lattice is spectrally equivalent to P2 on the box.  Entity e < nv: vertex (2i, 2j, 2k);
+// e >= nv: midpoint of edges[e - nv] = sum of its endpoints' lattice coordinates.
+__device__ __forceinline__ void p2_lattice_point(int64_t e, int64_t nv, int64_t n0, int64_t n1,
+                                                 const int32_t *__restrict__ edges, int *q) {
+  const uint32_t m0 = (uint32_t)n0, m1 = (uint32_t)n1;
+  auto vert = [&](uint32_t w, int *o) {
+    const uint32_t r = w / m0;
+    o[0] = (int)(w - r * m0); o[1] = (int)(r % m1); o[2] = (int)(r / m1);
+  };
+  if (e < nv) {
+    vert((uint32_t)e, q);
+    for (int a = 0; a < 3; ++a) q[a] *= 2;
+  } else {
+    int a0[3], a1[3];
+    vert((uint32_t)edges[2 * (e - nv)], a0);
+    vert((uint32_t)edges[2 * (e - nv) + 1], a1);
+    for (int a = 0; a < 3; ++a) q[a] = a0[a] + a1[a];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_active_bbox_p2(int64_t nent, int64_t nv, int64_t n0, int64_t n1, const int32_t *__restrict__ edges,
+                 const int32_t *__restrict__ du, const int32_t *__restrict__ iperm,
+                 const uint8_t *__restrict__ own, int *__restrict__ out) {
+  __shared__ int red[6][4];
+  int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {-1, -1, -1};
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nent; e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t d = du[e];
+    if (d >= 0 && (!own || own[iperm[d]])) {
+      int q[3];
+      p2_lattice_point(e, nv, n0, n1, edges, q);
+      for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], q[a]); hi[a] = max(hi[a], q[a]); }
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    for (int o = 32; o > 0; o >>= 1) {
+      lo[a] = min(lo[a], __shfl_xor(lo[a], o));
+      hi[a] = max(hi[a], __shfl_xor(hi[a], o));
+    }
+    if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = lo[a]; red[3 + a][threadIdx.x >> 6] = hi[a]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int a = threadIdx.x;
+    const int l = min(min(red[a][0], red[a][1]), min(red[a][2], red[a][3]));
+    const int h = max(max(red[3 + a][0], red[3 + a][1]), max(red[3 + a][2], red[3 + a][3]));
+    if (h >= 0) { atomicMin(&out[a], l); atomicMax(&out[3 + a], h); }
+  }
+}
+
+// gmap (pre-set to -1) filled from the entities
+__global__ void k_box_gmap_p2(BoxGrid g, int lo0, int lo1, int lo2, int64_t nent, int64_t nv, int64_t n0, int64_t n1,
+                              const int32_t *__restrict__ edges, const int32_t *__restrict__ du,
+                              const int32_t *__restrict__ iperm, const uint8_t *__restrict__ own,
+                              int32_t *__restrict__ gmap) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= nent) return;
+  const int32_t d = du[e];
+  if (d < 0) return;
+  const int32_t pos = iperm[d];
+  if (own && !own[pos]) return;
+  int q[3];
+  p2_lattice_point(e, nv, n0, n1, edges, q);
+  const int x = q[0] - lo0 - 1, y = q[1] - lo1 - 1, z = q[2] - lo2 - 1;
+  if (x < 0 || x >= g.m[0] || y < 0 || y >= g.m[1] || z < 0 || z >= g.m[2]) return;
+  gmap[x + g.pitch * y + g.plane * z] = pos;
+}
+
 __global__ void k_box_gmap(BoxGrid g, int lo0, int lo1, int lo2, int64_t n0, int64_t n1, int64_t n2,
                            const int32_t *__restrict__ du, const int32_t *__restrict__ iperm,
                            const uint8_t *__restrict__ own, const int32_t *__restrict__ lat2v,
@@ -712,14 +782,20 @@ __global__ void k_dscale(int64_t n, const int32_t *__restrict__ perm, const doub
 static int box_precond_setup(phx_system *s) {
   phx_mesh *m = s->mesh;
   s->precond_state = -1;
-  if (!m->precond || !(m->is_box || m->on_box_lattice) || !s->u_vertex_block) return PHX_OK;
+  const bool p2 = s->u_p2_block && m->is_box && m->edges != nullptr;
+  const bool p1 = (m->is_box || m->on_box_lattice) && s->u_vertex_block;
+  if (!m->precond || (!p1 && !p2)) return PHX_OK;
   hipStream_t st = m->stream;
   const int64_t n0 = m->box_n[0] + 1, n1 = m->box_n[1] + 1, n2 = m->gdim == 3 ? m->box_n[2] + 1 : 1;
   int *dbb = nullptr, hbb[6] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1};
   PHX_HIP(phx_malloc(&dbb, sizeof(hbb)));
   PHX_HIP(hipMemcpyAsync(dbb, hbb, sizeof(hbb), hipMemcpyHostToDevice, st));
-  k_active_bbox<<<dim3((unsigned)std::min<int64_t>(phx_div_up(m->nv, 256), 1024)), dim3(256), 0, st>>>(
-      m->nv, n0, n1, s->dof_of_vertex_u, s->iperm, s->own, m->v2lat, dbb);
+  if (p2)
+    k_active_bbox_p2<<<dim3((unsigned)std::min<int64_t>(phx_div_up(s->nent, 256), 1024)), dim3(256), 0, st>>>(
+        s->nent, m->nv, n0, n1, m->edges, s->dof_of_vertex_u, s->iperm, s->own, dbb);
+  else
+    k_active_bbox<<<dim3((unsigned)std::min<int64_t>(phx_div_up(m->nv, 256), 1024)), dim3(256), 0, st>>>(
+        m->nv, n0, n1, s->dof_of_vertex_u, s->iperm, s->own, m->v2lat, dbb);
   PHX_HIP(hipMemcpyAsync(hbb, dbb, sizeof(hbb), hipMemcpyDeviceToHost, st));
   PHX_HIP(hipStreamSynchronize(st));
   PHX_HIP(phx_free(dbb));
@@ -733,7 +809,9 @@ static int box_precond_setup(phx_system *s) {
   }
   phx_box_precond *bp = new phx_box_precond();
   // 2-D: the lattice gets a dummy third axis with coefficient 0 (one real plane; the z passes are the identity)
-  const double *h = m->box_h;
+  // P2: the lattice has spacing h / 2
+  const double hs = p2 ? 0.5 : 1.0;
+  const double h[3] = {hs * m->box_h[0], hs * m->box_h[1], hs * m->box_h[2]};
   const double c3[3] = {h[1] * h[2] / h[0], h[0] * h[2] / h[1], h[0] * h[1] / h[2]};
   const double c2[3] = {h[1] / h[0], h[0] / h[1], 0.0};
   int rc = box_grid_setup(bp, m->device, L, m->gdim == 3 ? c3 : c2, m->precond == 2);
@@ -746,8 +824,14 @@ static int box_precond_setup(phx_system *s) {
     box_precond_free(bp);
     return PHX_ERR_HIP;
   }
-  k_box_gmap<<<dim3((unsigned)phx_div_up(tot, 256)), dim3(256), 0, st>>>(
-      bp->g, lo[0], lo[1], lo[2], n0, n1, n2, s->dof_of_vertex_u, s->iperm, s->own, m->lat2v, bp->gmap);
+  if (p2) {
+    if (hipMemsetAsync(bp->gmap, 0xff, sizeof(int32_t) * (size_t)tot, st) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+    k_box_gmap_p2<<<dim3((unsigned)phx_div_up(s->nent, 256)), dim3(256), 0, st>>>(
+        bp->g, lo[0], lo[1], lo[2], s->nent, m->nv, n0, n1, m->edges, s->dof_of_vertex_u, s->iperm, s->own, bp->gmap);
+  } else {
+    k_box_gmap<<<dim3((unsigned)phx_div_up(tot, 256)), dim3(256), 0, st>>>(
+        bp->g, lo[0], lo[1], lo[2], n0, n1, n2, s->dof_of_vertex_u, s->iperm, s->own, m->lat2v, bp->gmap);
+  }
   k_dscale<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(s->n, s->perm, s->diag, bp->dscale);
   if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
   // rows outside the u block (active rows are numbered u first): P is the identity there.  The other
