@@ -670,32 +670,36 @@ k_row_fill_block(int64_t n, const int32_t *__restrict__ cols, const double *__re
                  double *__restrict__ oval, double *__restrict__ diag) {
   __shared__ int32_t sc[W];
   __shared__ double sv[W];
-  const int64_t row = blockIdx.x;
   const int t = threadIdx.x;
-  int32_t c = 0x7fffffff;
-  double v = 0.0;
-  const int32_t cc = cols[row * W + t];
-  if (cc != -1) { c = cc < nent ? du[cc] : dp[cc - nent]; v = vals[row * W + t]; }
-  if (c == (int32_t)row) diag[row] = v;
-  sc[t] = c;
-  sv[t] = v;
-  __syncthreads();
-  for (int k = 2; k <= W; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const int p = t ^ j;
-      if (p > t) {
-        const bool up = ((t & k) == 0);
-        const int32_t a = sc[t], b = sc[p];
-        if ((a > b) == up) {
-          sc[t] = b; sc[p] = a;
-          const double x = sv[t]; sv[t] = sv[p]; sv[p] = x;
+  // a block walks rows with a grid stride: a HIP grid holds fewer than 2^32 threads, and 2.3e7 rows of a
+  // 256^3 P2 system times 256 threads is more (the launch then covers only part of the rows -- silently)
+  for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+    int32_t c = 0x7fffffff;
+    double v = 0.0;
+    const int32_t cc = cols[row * W + t];
+    if (cc != -1) { c = cc < nent ? du[cc] : dp[cc - nent]; v = vals[row * W + t]; }
+    if (c == (int32_t)row) diag[row] = v;
+    sc[t] = c;
+    sv[t] = v;
+    __syncthreads();
+    for (int k = 2; k <= W; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const int p = t ^ j;
+        if (p > t) {
+          const bool up = ((t & k) == 0);
+          const int32_t a = sc[t], b = sc[p];
+          if ((a > b) == up) {
+            sc[t] = b; sc[p] = a;
+            const double x = sv[t]; sv[t] = sv[p]; sv[p] = x;
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
-    }
-  const int64_t base = rowptr[row];
-  const int64_t cnt = rowptr[row + 1] - base;
-  if (t < cnt) { ocol[base + t] = sc[t]; oval[base + t] = sv[t]; }
+    const int64_t base = rowptr[row];
+    const int64_t cnt = rowptr[row + 1] - base;
+    if (t < cnt) { ocol[base + t] = sc[t]; oval[base + t] = sv[t]; }
+    __syncthreads();
+  }
 }
 
 // ---- compaction of slot tables with per-row capacities (Slots::off / wlog)
@@ -903,16 +907,16 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
     k_row_fill<<<dim3((unsigned)phx_div_up(s->n * 64, 256)), block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, sl.clean, s->rowptr, nent,
                                                   s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag, s->row_nz);
   else if (W == 128)
-    k_row_fill_block<128><<<dim3((unsigned)s->n), dim3(128), 0, m->stream>>>(
+    k_row_fill_block<128><<<dim3((unsigned)std::min<int64_t>(s->n, 1 << 21)), dim3(128), 0, m->stream>>>(
         s->n, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
   else if (W == 256)
-    k_row_fill_block<256><<<dim3((unsigned)s->n), dim3(256), 0, m->stream>>>(
+    k_row_fill_block<256><<<dim3((unsigned)std::min<int64_t>(s->n, 1 << 21)), dim3(256), 0, m->stream>>>(
         s->n, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
   else if (W == 512)
-    k_row_fill_block<512><<<dim3((unsigned)s->n), dim3(512), 0, m->stream>>>(
+    k_row_fill_block<512><<<dim3((unsigned)std::min<int64_t>(s->n, 1 << 21)), dim3(512), 0, m->stream>>>(
         s->n, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
   else if (W == 1024)
-    k_row_fill_block<1024><<<dim3((unsigned)s->n), dim3(1024), 0, m->stream>>>(
+    k_row_fill_block<1024><<<dim3((unsigned)std::min<int64_t>(s->n, 1 << 21)), dim3(1024), 0, m->stream>>>(
         s->n, sl.cols, sl.vals, s->rowptr, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag);
   else {
     phx_set_error("unsupported slot capacity %d", W);
