@@ -903,6 +903,9 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
     PHX_HIP(hipGetLastError());
     PHX_HIP(hipStreamSynchronize(m->stream));
     PHX_HIP(phx_free(wide));
+  } else if (W <= 64 && s->n * 64 >= ((int64_t)1 << 32)) {
+    phx_set_error("row compaction: %lld rows exceed one HIP grid -- partition the problem", (long long)s->n);
+    return PHX_ERR_VALUE;
   } else if (W <= 64)  // one wave per row here: the wave-stride variant was slower (2.23 vs 1.89 ms), the sort hides nothing
     k_row_fill<<<dim3((unsigned)phx_div_up(s->n * 64, 256)), block, 0, m->stream>>>(s->n, W, sl.cols, sl.vals, sl.clean, s->rowptr, nent,
                                                   s->dof_of_vertex_u, s->dof_of_vertex_p, s->col, s->val, s->diag, s->row_nz);
@@ -1031,6 +1034,7 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
     // 64 lanes per cut cell.  Measured at 256^3 (1.1e6 cut cells): 64 lanes per cell 2.1 ms, 8 lanes (one
     // tensor row each) 2.6 ms, one lane per cell 2.7 ms -- the dependent hash probes of a lane serialise;
     // the ghost-penalty facets behave the other way round (one lane per facet: 2.8 -> 1.5 ms).
+    PHX_REQUIRE_GRID(n_cut * 64, "cut-cell assembly");
     const dim3 g((unsigned)phx_div_up(n_cut * 64, 256));
     if (D == 2) k_assemble_cut<2><<<g, block, 0, m->stream>>>(n_cut, l_cut, A);
     else k_assemble_cut<3><<<g, block, 0, m->stream>>>(n_cut, l_cut, A);

@@ -555,6 +555,8 @@ static int assemble_el_with_capacity(phx_mesh *m, const double *params, const do
     if (D == 2) k_el_bulk_box<2><<<g, block, 0, m->stream>>>(nthreads, bd, touched, A);
     else k_el_bulk_box<3><<<g, block, 0, m->stream>>>(nthreads, bd, touched, A);
   }
+  if (!m->is_box) PHX_REQUIRE_GRID(m->nc * 256, "elasticity bulk assembly");
+  PHX_REQUIRE_GRID(n_cut * 256, "elasticity cut-cell assembly");
   if (D == 2) {
     if (!m->is_box) k_el_bulk<2><<<dim3((unsigned)m->nc), block, 0, m->stream>>>(m->nc, A);
     if (n_cut) k_el_cut<2><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, A);

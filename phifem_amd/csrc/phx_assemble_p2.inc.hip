@@ -468,6 +468,7 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
   PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut));
   PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac));
   if (n_om > 0) {
+    PHX_REQUIRE_GRID(n_om * (D == 2 ? 64 : 128), "P2 cell assembly");
     if (D == 2) k_p2_cells<2, 64><<<dim3((unsigned)phx_div_up(n_om * 64, 256)), block, 0, m->stream>>>(n_om, l_om, P);
     else k_p2_cells<3, 128><<<dim3((unsigned)phx_div_up(n_om * 128, 256)), block, 0, m->stream>>>(n_om, l_om, P);
   }

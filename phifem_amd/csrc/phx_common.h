@@ -49,6 +49,10 @@ static inline hipError_t phx_free(void *p) { return phx_pool_free(p); }
   } while (0)
 
 static inline int64_t phx_div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// A HIP grid holds fewer than 2^32 threads; a larger launch covers only part of the work without an error.
+#define PHX_REQUIRE_GRID(threads_total, what)                                                        \
+  PHX_REQUIRE((int64_t)(threads_total) < ((int64_t)1 << 32), PHX_ERR_VALUE,                           \
+              "%s: %lld threads exceed one HIP grid -- partition the problem", what, (long long)(threads_total))
 
 // Bits 0-6 of a cell-tag byte: 1 inside, 2 cut, 3 outside (or a user tag <= 127).  Bit 7: the
 // `ds` detection says the level-set changes sign over the cell's background-boundary facets.
