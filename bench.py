@@ -41,6 +41,10 @@ def parse():
                     help="BASELINE configs[3]: 3-D interface elasticity (5-field mixed, 27 components per "
                          "vertex) on a --cubes^3 box (256 in the config) split into z-slabs over the GPUs "
                          "(strong scaling); not the default workload")
+    ap.add_argument("--config3", action="store_true",
+                    help="BASELINE configs[2]: 3-D Poisson with P2 x P2 elements + stabilisation on a --cubes^3 box, "
+                         "one GPU (the 512^3 of the config does not fit one GPU in assembled form; 256^3 does); "
+                         "not the default workload")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE configs[4]: 1024 x 1024 x 128 cubes per GPU (805 306 368 tets), unit "
                          "sphere, 1024^3 box at 8 GPUs; not the default workload")
@@ -150,7 +154,11 @@ def main():
     from phifem_amd import distributed as D
 
     n = 128 if args.config5 else args.cubes
-    if args.config4:
+    if args.config3:
+        if world != 1:
+            raise SystemExit("--config3 runs on one GPU")
+        prob = D.P2Problem(n, device=local_rank, rtol=args.rtol)
+    elif args.config4:
         if n % world:
             raise SystemExit("--config4 needs --cubes divisible by the number of GPUs")
         prob = D.ElasticitySlabProblem(n, n // world, rank=rank, world=world, device=local_rank,
@@ -215,7 +223,10 @@ def main():
         dominant, other = spmv_roof, dst_roof
         if dst_roof and 4 * dst_s > 2 * spmv_s:
             dominant, other = dst_roof, spmv_roof
-        if args.config4:
+        if args.config3:
+            workload = (f"3D weak-Dirichlet Poisson phi-FEM, P2xP2 with div(grad) + ghost-penalty stabilisation, "
+                        f"P2 spherical level-set, {n}^3 Kuhn box ({6 * n ** 3} tets), box mode, single-layer cut")
+        elif args.config4:
             workload = (f"3D interface elasticity phi-FEM, 5-field mixed P1 (27 comps/vertex), E_in=1, E_out=1e-3, "
                         f"nu=0.3, {n}^3 Kuhn box in {world} z-slab(s), box mode")
         elif args.config5:

@@ -176,3 +176,52 @@ class ElasticitySlabProblem(SlabProblem):
             "dst_algorithmic_bytes": 2.0 * pc["precond_value_bytes"] * pc["precond_points"],
             "precond_value_bytes": pc["precond_value_bytes"],
         }
+
+
+class P2Problem:
+    """BASELINE configs[2] on one GPU: 3-D weak-Dirichlet Poisson, P2 x P2 with the div(grad) and ghost-penalty
+    stabilisation terms, level-set in P2, spherical domain, n^3 Kuhn box (the 512^3 of the config does not fit
+    one GPU in assembled form; 256^3 = 2.3e7 DoFs does)."""
+
+    def __init__(self, n, device=0, rtol=1e-8, max_iter=100000):
+        self.n, self.device, self.rtol, self.max_iter = n, device, rtol, max_iter
+        self.world, self.rank = 1, 0
+
+    def setup(self):
+        import torch
+        self.mesh = create_box([-1.5] * 3, [1.5] * 3, [self.n] * 3, device=self.device)
+        dev = torch.device("cuda", self.device)
+        x = torch.empty((self.mesh.nv, 3), dtype=torch.float64, device=dev)
+        L.check(L.lib.phx_mesh_get_array(self.mesh._h, L.ARR_COORDS, C.c_void_p(x.data_ptr()), L.DEVICE))
+        self.phi1 = (x ** 2).sum(dim=1) - 1.0            # P1 nodal values drive the tagging
+        self.solver = PhiFEMSolver(self.mesh, degree=2, levelset_degree=2)
+        ne = self.mesh.ne                                 # builds the edge numbering
+        e = torch.empty((ne, 2), dtype=torch.int32, device=dev)
+        L.check(L.lib.phx_mesh_get_array(self.mesh._h, L.ARR_EDGES, C.c_void_p(e.data_ptr()), L.DEVICE))
+        pts = torch.cat([x, 0.5 * (x[e[:, 0].long()] + x[e[:, 1].long()])], dim=0)   # vertices, then edge midpoints
+        self.phi = (pts ** 2).sum(dim=1) - 1.0
+        self.u_ex = torch.sin(pts[:, 0]) * torch.sin(pts[:, 1]) * torch.sin(pts[:, 2])
+        self.f = 3.0 * self.u_ex
+        self.out = torch.empty(2 * pts.shape[0], dtype=torch.float64, device=dev)
+        del x, e, pts
+        torch.cuda.synchronize()
+
+    def step(self, profile_spmv=False):
+        mesh = self.mesh
+        staged = _tag_cells(mesh, NodalFunction(self.phi1), 1, single_layer_cut=True)
+        _tag_facets(mesh, staged, 1)
+        info = self.solver.assemble(self.phi, self.f, self.u_ex)
+        self.solver.solve(rtol=self.rtol, max_iter=self.max_iter, out=self.out, profile_spmv=profile_spmv)
+        st = self.solver.stats
+        t = mesh.timings()
+        pc = self.solver.precond_info()
+        return {
+            "n_active_owned": info["n_active"], "iterations": st["iterations"], "relres": st["relres"],
+            "stage_s": {"tag": t["tag_cells"] + t["tag_facets"], "assemble": t["assemble"], "solve": st["seconds"]},
+            "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),
+            "spmv_algorithmic_bytes": 12.0 * info["sell_nnz"] + 20.0 * info["n_active"],
+            "precond": pc["precond"], "precond_L": pc["precond_L"],
+            "dst_avg_s": pc["dst_avg_s"], "dst_count": pc["dst_timed"],
+            "dst_algorithmic_bytes": 2.0 * pc["precond_value_bytes"] * pc["precond_points"],
+            "precond_value_bytes": pc["precond_value_bytes"],
+        }
