@@ -206,6 +206,15 @@ int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab_coef, cons
 int phx_assemble_poisson_wd_p2(phx_mesh *m, double pen_coef, double stab_coef, const double *phi_h,
                                int phi_degree, const double *f_h, const double *u_D, int loc,
                                phx_system **out);
+/* Strong-Dirichlet ("direct") phi-FEM Poisson, u_h = phi_h w_h, one scalar field w of Lagrange
+ * degree 1 or 2: bilinear form demo/strong-dirichlet/flower/main.py:104-117 + assemble_matrix
+ * :120-121, linear form :125-129, on the tags held by the mesh (dx((1,2)), dx(2), dS((2,3)), ds =
+ * ds_bdy(100) on the background mesh :60-65 or all exterior facets of a sub-mesh :70).  f_h: nodal
+ * array of the w space ([nv], or [nv + ne] at degree 2); phi_h: [nv] if phi_degree == 1, [nv + ne]
+ * if 2.  The system holds the active w DoFs only (n_active_u == n_active, n_full = DoFs of the
+ * space); the caller forms u_h = w_h phi_h at the nodes of its solution space (main.py:176-182). */
+int phx_assemble_poisson_sd(phx_mesh *m, double stab_coef, int degree, const double *phi_h,
+                            int phi_degree, const double *f_h, int loc, phx_system **out);
 /* Interface linear elasticity, 5-field mixed phi-FEM (u_in, u_out, y_in, y_out, p), all P1:
  * demo/interface-elasticity/main.py:179-235 (bilinear form) + assemble_matrix(bcs) :237-239, linear
  * form :255-269 + apply_lifting / bc.set :271-277, material law data.py:5-36, on the tags held by

@@ -82,6 +82,7 @@ SIGNATURES = {
     "phx_submesh_maps": ([_vp, _vp, _vp], _i),
     "phx_assemble_poisson_wd": ([_vp, _d, _d, _vp, _vp, _vp, _i, C.POINTER(_vp)], _i),
     "phx_assemble_poisson_wd_p2": ([_vp, _d, _d, _vp, _i, _vp, _vp, _i, C.POINTER(_vp)], _i),
+    "phx_assemble_poisson_sd": ([_vp, _d, _i, _vp, _i, _vp, _i, C.POINTER(_vp)], _i),
     "phx_assemble_elasticity_if": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, C.POINTER(_vp)], _i),
     "phx_system_destroy": ([_vp], _i),
     "phx_system_info": ([_vp, _pi64], _i),

@@ -138,6 +138,53 @@ class PhiFEMSolver:
         return {"ms": o[0], "algorithmic_bytes": o[1], "padded_bytes": o[2]}
 
 
+class StrongDirichletSolver(PhiFEMSolver):
+    """Direct ("strong Dirichlet") phi-FEM: u_h = phi_h w_h with one scalar unknown w_h -- the
+    assemble -> solve -> multiply sequence of demo/strong-dirichlet/flower/main.py:83-182 over the
+    C ABI (`phx_assemble_poisson_sd`).  `degree` is fe_degree (main.py:39), `levelset_degree` as
+    main.py:41; the mesh is the tagged background mesh (mesh_type "bg", main.py:60-65) or the
+    sub-mesh (mesh_type "sub", main.py:66-70)."""
+
+    def __init__(self, mesh, stab_coef=1.0, degree=1, levelset_degree=1):
+        if degree not in (1, 2) or levelset_degree not in (1, 2):
+            raise NotImplementedError("Lagrange degrees 1 and 2 are implemented")
+        self.degree, self.levelset_degree = degree, levelset_degree
+        self.mesh = mesh
+        self.stab_coef = float(stab_coef)
+        self._sys = None
+        self.stats = {}
+
+    def assemble(self, phi_h, f_h):
+        """Bilinear + linear form of main.py:104-129 (nodal data, numpy or device tensors)."""
+        self._free()
+        nphi = self.mesh.nv if self.levelset_degree == 1 else self.mesh.nv + self.mesh.ne
+        phi_h = self._arr(phi_h, nphi)
+        f_h = self._arr(f_h, self.ndofs)
+        locs = {L.ptr(a)[1] for a in (phi_h, f_h)}
+        if len(locs) != 1:
+            raise ValueError("phi_h and f_h must both live on the host or both on the device")
+        h = C.c_void_p()
+        L.check(L.lib.phx_assemble_poisson_sd(
+            self.mesh._h, self.stab_coef, self.degree, L.ptr(phi_h)[0], self.levelset_degree,
+            L.ptr(f_h)[0], locs.pop(), C.byref(h)))
+        self._sys = h
+        self._phi = phi_h
+        return self.info()
+
+    def split(self, w):
+        raise NotImplementedError("one scalar field: solve() returns w_h itself")
+
+    def solution(self, w, solution_degree=None):
+        """u_h = w_h phi_h at the nodes of the solution space (main.py:172-182: both factors are
+        interpolated into the space of degree `solution_degree`, then multiplied node by node).
+        Implemented for solution_degree = degree = levelset_degree, where both interpolations
+        are the identity."""
+        k = self.degree if solution_degree is None else solution_degree
+        if not (k == self.degree == self.levelset_degree):
+            raise NotImplementedError("solution_degree must equal degree and levelset_degree")
+        return w * self._phi
+
+
 class InterfaceElasticitySolver(PhiFEMSolver):
     """Two-material linear elasticity with a level-set interface, 5-field mixed phi-FEM
     (u_in, u_out, y_in, y_out, p), all first-order Lagrange: the assemble -> solve sequence of
