@@ -279,7 +279,10 @@ static int assemble_sd_impl(phx_mesh *m, double stab_coef, int kphi, const doubl
   phx_system *s = new phx_system();
   s->mesh = m; s->device = m->device; s->nfull = nent; s->slot_cap = W; s->nent = nent;
   s->u_vertex_block = K == 1;
-  s->u_p2_block = K == 2;
+  // K = 1: lattice preconditioner with the nodal weight of u = phi w folded in (phx_precond.inc.hip).  K = 2
+  // stays with Jacobi: the weight estimated from diag A is off by the vertex / edge difference of the P2
+  // diagonal and the refined-lattice solve does not pay (2-D 128^2: 424 vs 408 iterations).
+  s->u_weighted = true;
   const dim3 block(256);
   std::vector<void *> keep;
   SdArgs P;

@@ -157,6 +157,7 @@ struct phx_system {
   const uint8_t *own = nullptr;
   // fictitious-domain preconditioner (phx_precond.inc.hip): built on demand for P1 Poisson systems on 3-D boxes
   bool u_vertex_block = false;     // rows [0, nu) are one scalar u DoF per active vertex
+  bool u_weighted = false;         // u block ~ S K S with a nodal weight S (strong Dirichlet, S ~ |phi_h|)
   bool u_p2_block = false;         // rows [0, nu): P2, one DoF per active vertex and edge (entities nv + ne)
   struct phx_box_precond *precond = nullptr;
   int precond_state = 0;           // 0 not tried, 1 built, -1 not applicable

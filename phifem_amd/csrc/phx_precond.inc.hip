@@ -349,7 +349,8 @@ struct BoxGrid {
 
 // ---- x lines (contiguous): pair = two consecutive lines of the flattened (y, z) index.
 // IO = 1: the input is gathered from the Krylov vector through gmap (solver position of the u DoF at the
-// lattice point, -1: none); IO = 2: the result is scattered out the same way, times dscale.
+// lattice point, -1: none), times dscale when that is given; IO = 2: the result is scattered out the same
+// way, times dscale.
 // T: precision of the lattice array and of the transform (the Krylov vectors stay f64).
 template <typename T, int IO, bool WAVE>
 __global__ void __launch_bounds__(1024)
@@ -386,10 +387,18 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
         qa[i] = in && has[0] ? gmap[base[0] + j - 1] : -1;
         qb[i] = in && has[1] ? gmap[base[1] + j - 1] : -1;
       }
+      if (dscale) {  // weighted systems (u = phi w): the residual is scaled on the way in as well
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        va[i] = qa[i] >= 0 ? (T)vin[qa[i]] : T(0);
-        vb[i] = qb[i] >= 0 ? (T)vin[qb[i]] : T(0);
+        for (int i = 0; i < 8; ++i) {
+          va[i] = qa[i] >= 0 ? (T)(vin[qa[i]] * dscale[qa[i]]) : T(0);
+          vb[i] = qb[i] >= 0 ? (T)(vin[qb[i]] * dscale[qb[i]]) : T(0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          va[i] = qa[i] >= 0 ? (T)vin[qa[i]] : T(0);
+          vb[i] = qb[i] >= 0 ? (T)vin[qb[i]] : T(0);
+        }
       }
     } else {
 #pragma unroll
@@ -524,7 +533,8 @@ struct phx_box_precond {
   void *G = nullptr;         // lattice array, f32 or f64
   bool f32 = false;          // precision of the lattice array and the transforms
   int32_t *gmap = nullptr;   // [plane * m2] solver position of the u DoF, -1 none
-  double *dscale = nullptr;  // [n] diag of A in solver order
+  double *dscale = nullptr;  // [n] diag of A in solver order (weighted systems: sqrt(diag A * diag K_box))
+  double *iscale = nullptr;  // [n] weighted systems only: sqrt(diag K_box / diag A), applied to the input
   double *vec = nullptr;     // [2 n] preconditioned directions of the library-owned workspace
   const uint8_t *own_ptr = nullptr;  // ownership mask the maps were built for
   int32_t *rest = nullptr;   // solver positions of the rows outside the u block (identity part of P)
@@ -535,7 +545,7 @@ struct phx_box_precond {
 
 static void box_precond_free(phx_box_precond *bp) {
   if (!bp) return;
-  (void)phx_free(bp->G); (void)phx_free(bp->gmap); (void)phx_free(bp->dscale); (void)phx_free(bp->vec);
+  (void)phx_free(bp->G); (void)phx_free(bp->gmap); (void)phx_free(bp->dscale); (void)phx_free(bp->iscale); (void)phx_free(bp->vec);
   (void)phx_free(bp->rest);
   for (int a = 0; a < 3; ++a) (void)phx_free(bp->lam[a]);
   delete bp;
@@ -624,10 +634,10 @@ static int box_pass_x_t(phx_box_precond *bp, hipStream_t st, const double *vin, 
   const dim3 grid((unsigned)phx_div_up(npairs, px.pairs)), block((unsigned)(px.pairs * px.slot));
   if (px.wave)
     k_dst_x<T, IO, true><<<grid, block, (size_t)px.lds_elems * sizeof(T) * 2, st>>>(
-        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, bp->dscale);
+        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, IO == 1 ? bp->iscale : bp->dscale);
   else
     k_dst_x<T, IO, false><<<grid, block, (size_t)px.lds_elems * sizeof(T) * 2, st>>>(
-        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, bp->dscale);
+        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, IO == 1 ? bp->iscale : bp->dscale);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
 }
@@ -777,6 +787,17 @@ __global__ void k_dscale(int64_t n, const int32_t *__restrict__ perm, const doub
   if (i < n) dscale[i] = diag[perm[i]];
 }
 
+// Weighted systems A ~ S K S (strong Dirichlet: S ~ |phi_h|, regularised as S^2 = diag A / diag K_box):
+// M^-1 = S^-1 K_box^-1 S^-1, so P = D M^-1 scales by sqrt(kd / D) on the way in and sqrt(D kd) on the way out.
+__global__ void k_dscale_weighted(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ diag,
+                                  double kd, double *__restrict__ dscale, double *__restrict__ iscale) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double D = fabs(diag[perm[i]]);
+  dscale[i] = sqrt(D * kd);
+  iscale[i] = D > 0.0 ? sqrt(kd / D) : 0.0;
+}
+
 // Builds the preconditioner of system `s` (state 1) or marks it not applicable (state -1).
 #define PHX_PRECOND_MARGIN 4
 static int box_precond_setup(phx_system *s) {
@@ -832,7 +853,14 @@ static int box_precond_setup(phx_system *s) {
     k_box_gmap<<<dim3((unsigned)phx_div_up(tot, 256)), dim3(256), 0, st>>>(
         bp->g, lo[0], lo[1], lo[2], n0, n1, n2, s->dof_of_vertex_u, s->iperm, s->own, m->lat2v, bp->gmap);
   }
-  k_dscale<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(s->n, s->perm, s->diag, bp->dscale);
+  if (s->u_weighted) {
+    if (phx_malloc(&bp->iscale, sizeof(double) * (size_t)s->n) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+    const double *cc = m->gdim == 3 ? c3 : c2;
+    k_dscale_weighted<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(
+        s->n, s->perm, s->diag, 2.0 * (cc[0] + cc[1] + cc[2]), bp->dscale, bp->iscale);
+  } else {
+    k_dscale<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(s->n, s->perm, s->diag, bp->dscale);
+  }
   if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
   // rows outside the u block (active rows are numbered u first): P is the identity there.  The other
   // entries of phat / shat (u rows this rank does not own) are never written and stay zero.
