@@ -129,6 +129,43 @@ def test_weighted_lattice_preconditioner_cuts_iterations(P):
     assert np.abs(out[1][0] - out[0][0]).max() <= 1e-6 * np.abs(out[0][0]).max()
 
 
+@pytest.mark.parametrize("box", [True, False])
+def test_flower_demo_problem(P, box):
+    """The demo's own problem (demo/strong-dirichlet/flower/main.py:48-70 with the flower data, 128 x 128
+    squares): background-mesh and sub-mesh modes against the oracle, matrix and solution; both modes
+    give the same u_h on the shared vertices up to the solver tolerance."""
+    import flower_data as F
+    from phifem_amd.mesh_scripts import NodalFunction
+    n = 128
+    bg = P.create_rectangle([[-4.5, -4.5], [4.5, 4.5]], [n, n])
+    det = F.detection_levelset(bg.x.T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ct, ft, sub, meas, maps = P.compute_tags_measures(bg, NodalFunction(det), 1, box_mode=box)
+    work = bg if box else sub
+    x = work.x
+    topo = Topology("triangle", work.cells.astype(np.int64), work.nv)
+    topo.c2f, topo.f2c, topo.nf = work.c2f.astype(np.int64), work.f2c.astype(np.int64), work.nf
+    V = oracle_space(work, topo, 1)
+    phi, f = F.levelset(x.T), F.source_term(x.T)
+    ds = meas(100) if box else work.boundary_facets.reshape(-1)
+    A, b, act = SD.assemble_poisson_sd(topo, x, work.cell_tag_values(), work.facet_tag_values(), ds, V, V, phi, f)
+    s = P.StrongDirichletSolver(work)
+    s.assemble(phi, f)
+    rowptr, col, val, rhs, dof = s.export_csr()
+    idx = np.flatnonzero(act)
+    Ao = A[idx][:, idx].tocsr()
+    Ao.sort_indices()
+    assert np.array_equal(dof, idx) and np.array_equal(col, Ao.indices)
+    assert np.abs(val - Ao.data).max() <= 1e-11 * np.abs(Ao.data).max()
+    assert np.abs(rhs - b[idx]).max() <= 1e-11 * np.abs(b).max()
+    w = s.solve(rtol=1e-11, max_iter=100000)
+    wo = OA.solve_direct(A, b, act)
+    assert np.abs(w - wo).max() <= 1e-6 * np.abs(wo).max()
+    u = s.solution(w)
+    assert u.max() > 0.0          # f >= 0, u = 0 on the boundary: positive inside
+
+
 def test_errors(P):
     mesh = P.create_box([-1.5, -1.5], [1.5, 1.5], [8, 8])
     with pytest.raises(NotImplementedError):
