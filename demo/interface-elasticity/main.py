@@ -7,8 +7,8 @@ loop with relative error slopes).
     python main.py [--iterations 4] [--mesh-size 0.2]
 
 The reference refines with dolfinx.mesh.refine; the structured background mesh is simply
-regenerated with twice the cells.  Errors are measured at the mesh vertices against the exact
-solution (the reference interpolates into a P3 space and integrates).
+regenerated with twice the cells.  Errors as in the reference: u_h and the exact solution in the
+degree-3 Lagrange space, cell-wise H10 / L2 integrals (`phifem_amd.postprocess.cell_errors`).
 """
 import argparse
 import os
@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
 
 import phifem_amd as P  # noqa: E402
 from phifem_amd.mesh_scripts import NodalFunction  # noqa: E402
+from phifem_amd.postprocess import cell_errors  # noqa: E402
 
 E_in, nu_in, E_out, nu_out = 1.0, 0.3, 1.0e-3, 0.3
 
@@ -63,7 +64,7 @@ def main():
     args = ap.parse_args()
     f = source()
     n = int(round(3.0 / args.mesh_size))
-    dofs, errs = [], []
+    dofs, h10s, l2s = [], [], []
     for it in range(args.iterations):
         mesh = P.create_rectangle([[-1.5, -1.5], [1.5, 1.5]], [n, n])
         x = mesh.x
@@ -77,20 +78,26 @@ def main():
         solver = P.InterfaceElasticitySolver(mesh, E_in, nu_in, E_out, nu_out, 1.0, 1.0)
         info = solver.assemble(phi, f(x), ue, bc)
         w = solver.blocks(solver.solve(rtol=1e-10, max_iter=500000))
+        # main.py:296-325 of the reference: u_h = u_in inside, u_out outside, their mean on the cut cells
         tags = mesh.cell_tag_values()
-        vin, vout = np.unique(mesh.cells[tags == 1]), np.unique(mesh.cells[tags == 3])
-        u = np.zeros_like(ue)
-        u[vin], u[vout] = w["u_in"][vin], w["u_out"][vout]
-        sel = np.concatenate([vin, vout])
-        err = np.sqrt(((u[sel] - ue[sel]) ** 2).sum() / (ue[sel] ** 2).sum())
+        on = lambda t: np.isin(np.arange(mesh.nv), mesh.cells[tags == t])  # noqa: E731
+        v_in, v_cut, v_out = on(1), on(2), on(3)
+        u_in = np.where((v_in | v_cut)[:, None], w["u_in"], 0.0)
+        u_out = np.where((v_out | v_cut)[:, None], w["u_out"], 0.0)
+        u_in[v_cut] *= 0.5
+        u_out[v_cut] *= 0.5
+        u = u_in + u_out
+        # main.py:327-383: cell-wise H10 / L2 errors in the degree-3 space, on the GPU
+        e = cell_errors(mesh, u, lambda p: exact_solution(p.T).T, degree=1)
         dofs.append(2 * mesh.nv)
-        errs.append(err)
+        h10s.append(e["h10_relative"])
+        l2s.append(e["l2_relative"])
         print(f"n = {n:4d}: {info['n_active']:8d} active DoFs, {solver.stats['iterations']:6d} iterations, "
-              f"relative l2 error {err:.3e}")
+              f"H10 relative error {e['h10_relative']:.3e}, L2 relative error {e['l2_relative']:.3e}")
         n *= 2
-    if len(errs) > 1:
-        slope = np.polyfit(np.log(dofs), np.log(errs), 1)[0]
-        print("relative error slope (vs number of primal DoFs):", slope)
+    if len(dofs) > 1:
+        print("H10 relative error slope:", np.polyfit(np.log(dofs), np.log(h10s), 1)[0])
+        print("L2 relative error slope:", np.polyfit(np.log(dofs), np.log(l2s), 1)[0])
 
 
 if __name__ == "__main__":

@@ -293,6 +293,20 @@ int phx_halo_selftest(phx_system *s, phx_comm *c, int npeers, const int *peers,
 /* y = A x on the active system (solver ordering is internal; x, y are in active numbering).
  * For tests and halo-exchange driven (multi-GPU) solvers. */
 int phx_spmv(phx_system *s, const double *x, double *y, int loc);
+/* Cell-wise discretisation errors, demo/interface-elasticity/main.py:327-383: the exact solution
+ * and u_h are interpolated into the Lagrange space of degree 3 (= primal_degree + 2 for P1, basix's default
+ * GLL-warped variant [3P]), e = I(u_ex) - u_h, and per listed cell K
+ *   l2_local[i]  = int_K e . e            (main.py:369-377)      h10_local[i] = int_K grad e : grad e   (:347-356)
+ * norms[4] = { sum l2_local, sum h10_local, int |I u_ex|^2 (:363-367), int |grad I u_ex|^2 (:339-345) } over the
+ * listed cells, summed in a fixed order.  u_h: component-major nodal values [ncomp][nv] (degree_h 1) or
+ * [ncomp][nv + ne] (2); u_ref: the exact solution at the reference nodes of each listed cell,
+ * [ncells][n_nodes][ncomp], nodes as `phx_reference_nodes` lists them (physical point = sum_m bary[m] x_vertex_m);
+ * cell_list: ncells cell indices, or NULL for all cells (ncells == nc).  All arrays live at `loc`. */
+int phx_reference_nodes(int gdim, int degree, double *bary, int *n_nodes);
+int phx_cell_errors(phx_mesh *m, int ncomp, int degree_h, const double *u_h, const double *u_ref,
+                    int64_t ncells, const int32_t *cell_list, int loc, double *l2_local,
+                    double *h10_local, double *norms);
+
 /* Times `reps` launches of the SpMV kernel with HIP events on the mesh's stream.
  * out[3] = {avg ms per launch, algorithmic bytes per launch (12 nnz + 20 n), padded bytes}. */
 int phx_spmv_bench(phx_system *s, int reps, double *out);
