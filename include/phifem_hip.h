@@ -215,6 +215,18 @@ int phx_assemble_poisson_wd_p2(phx_mesh *m, double pen_coef, double stab_coef, c
  * space); the caller forms u_h = w_h phi_h at the nodes of its solution space (main.py:176-182). */
 int phx_assemble_poisson_sd(phx_mesh *m, double stab_coef, int degree, const double *phi_h,
                             int phi_degree, const double *f_h, int loc, phx_system **out);
+/* Neumann / Robin phi-FEM Poisson (-lap u + u = f, du/dn + kappa u = g on the boundary), mixed (u, y, p) in
+ * P1 x P1^d x DG0 with a P2 level-set, on simplices: forms demo/robin/square/main.py:112-168 + assemble_matrix /
+ * assemble_vector :145-147,167-168; kappa = 0 with facet_tag = 3 is the formulation of
+ * demo/neumann/square/main.py:113-158 (whose quadrilateral cells are not covered).
+ * params = {pen_coef, stab_coef, robin_coef}; facet_tag: the interior facets carrying the gradient-jump term
+ * (2 in the Robin demo :140, 3 in the Neumann demo :134); quadrature_degree: degree of the cut-cell rule
+ * (|grad phi_h| is not polynomial; 10 = UFL's estimate for the Robin integrand).  phi_h: [nv + ne] (P2: vertex
+ * values, then edge values), f_h, g_h (u_N / u_R): [nv].  DoFs in the full numbering: u at vertex v -> v,
+ * y_k at vertex v -> (1 + k) nv + v, p on cell c -> (1 + gdim) nv + c; n_full = (1 + gdim) nv + nc. */
+int phx_assemble_poisson_flux(phx_mesh *m, const double *params, int facet_tag, int quadrature_degree,
+                              const double *phi_h, const double *f_h, const double *g_h, int loc,
+                              phx_system **out);
 /* Interface linear elasticity, 5-field mixed phi-FEM (u_in, u_out, y_in, y_out, p), all P1:
  * demo/interface-elasticity/main.py:179-235 (bilinear form) + assemble_matrix(bcs) :237-239, linear
  * form :255-269 + apply_lifting / bc.set :271-277, material law data.py:5-36, on the tags held by

@@ -83,6 +83,7 @@ SIGNATURES = {
     "phx_assemble_poisson_wd": ([_vp, _d, _d, _vp, _vp, _vp, _i, C.POINTER(_vp)], _i),
     "phx_assemble_poisson_wd_p2": ([_vp, _d, _d, _vp, _i, _vp, _vp, _i, C.POINTER(_vp)], _i),
     "phx_assemble_poisson_sd": ([_vp, _d, _i, _vp, _i, _vp, _i, C.POINTER(_vp)], _i),
+    "phx_assemble_poisson_flux": ([_vp, _vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(_vp)], _i),
     "phx_assemble_elasticity_if": ([_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, C.POINTER(_vp)], _i),
     "phx_reference_nodes": ([_i, _i, _vp, C.POINTER(C.c_int)], _i),
     "phx_cell_errors": ([_vp, _i, _i, _vp, _vp, _i64, _vp, _i, _vp, _vp, _pd], _i),

@@ -185,6 +185,45 @@ class StrongDirichletSolver(PhiFEMSolver):
         return w * self._phi
 
 
+class NeumannRobinSolver(PhiFEMSolver):
+    """Neumann / Robin phi-FEM, mixed (u, y, p) in P1 x P1^d x DG0 with a P2 level-set: the assemble ->
+    solve sequence of demo/robin/square/main.py:98-190 over the C ABI (`phx_assemble_poisson_flux`), on
+    triangles / tetrahedra.  `robin_coef = 0`, `facet_tag = 3` is the formulation of
+    demo/neumann/square/main.py:113-158 (its quadrilateral cells are not covered).  Boundary condition:
+    du/dn + robin_coef u = g on {phi = 0}."""
+
+    def __init__(self, mesh, pen_coef=1.0, stab_coef=1.0, robin_coef=0.0, facet_tag=2, quadrature_degree=10):
+        self.mesh = mesh
+        self.params = np.array([pen_coef, stab_coef, robin_coef], dtype=np.float64)
+        self.facet_tag, self.quadrature_degree = int(facet_tag), int(quadrature_degree)
+        self.degree, self.levelset_degree = 1, 2
+        self._sys = None
+        self.stats = {}
+
+    def assemble(self, phi_h, f_h, g_h):
+        """phi_h: P2 nodal values (vertices, then edges: `mesh.p2_dof_points()`); f_h, g_h (u_N / u_R,
+        main.py:103-110): P1 nodal values."""
+        self._free()
+        m = self.mesh
+        phi_h = self._arr(phi_h, m.nv + m.ne)
+        f_h, g_h = self._arr(f_h, m.nv), self._arr(g_h, m.nv)
+        locs = {L.ptr(a)[1] for a in (phi_h, f_h, g_h)}
+        if len(locs) != 1:
+            raise ValueError("phi_h, f_h and g_h must all live on the host or all on the device")
+        h = C.c_void_p()
+        L.check(L.lib.phx_assemble_poisson_flux(
+            m._h, self.params.ctypes.data_as(C.c_void_p), self.facet_tag, self.quadrature_degree,
+            L.ptr(phi_h)[0], L.ptr(f_h)[0], L.ptr(g_h)[0], locs.pop(), C.byref(h)))
+        self._sys = h
+        return self.info()
+
+    def split(self, w):
+        """solution_wh.split() (main.py:186): u (nv,), y (nv, d), p (nc,)."""
+        m = self.mesh
+        d, nv = m.gdim, m.nv
+        return w[:nv], w[nv:(1 + d) * nv].reshape(d, nv).T, w[(1 + d) * nv:]
+
+
 class InterfaceElasticitySolver(PhiFEMSolver):
     """Two-material linear elasticity with a level-set interface, 5-field mixed phi-FEM
     (u_in, u_out, y_in, y_out, p), all first-order Lagrange: the assemble -> solve sequence of
