@@ -237,8 +237,10 @@ static int assemble_flux_with_capacity(phx_mesh *m, const double *params, int fa
   else k_fx_mark_active<3><<<gcells, block, 0, m->stream>>>(m->nc, A, flags);
   int32_t n = 0;
   PHX_CHECK(scan_flags(m, flags, scan, nent, &n));
-  s->n = n; s->nu = n;
   PHX_REQUIRE(n > 0, PHX_ERR_VALUE, "no active DoF: no cell is tagged 1 or 2");
+  // Jacobi only: the lattice preconditioner on the u rows (which come first) makes BiCGStab worse here -- the
+  // y / p penalty blocks dominate (Robin demo, 200^2: 10072 iterations instead of 2800; 400^2 diverges)
+  s->n = n; s->nu = n;
   PHX_HIP(phx_malloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)nent));
   PHX_HIP(phx_malloc(&s->dof_of_vertex_p, sizeof(int32_t) * 4));
   PHX_HIP(phx_malloc(&s->full_of_active, sizeof(int64_t) * (size_t)n));

@@ -64,3 +64,21 @@ def test_quadrature_degree_only_moves_the_nonpolynomial_terms():
     N14, _, _ = FX.assemble_poisson_flux(topo, x, cv, fv, ds, Vp, phi, f, g, robin_coef=0.0, qdeg=14)
     assert abs(N10 - N14).max() < 1e-12 * abs(N10).max()
     assert np.abs(b10 - b14).max() < 1e-6 * np.abs(b10).max()
+
+
+def test_robin_demo_data_matches_reference_fixture():
+    """demo/robin/square/data.py of this repo against values of the reference's data module at 400
+    seeded points (tests/golden/robin_data.npz, made by tests/golden/make_robin_data.py)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("robin_demo_data", os.path.join(root, "demo", "robin", "square", "data.py"))
+    mine = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mine)
+    gold = np.load(os.path.join(root, "tests", "golden", "robin_data.npz"))
+    assert float(gold["robin_coef"]) == mine.ROBIN_COEF
+    for name in ("detection_levelset", "levelset", "exact_solution", "source_term", "robin_data"):
+        got = getattr(mine, name)(gold["x"].copy())
+        assert np.abs(got - gold[name]).max() <= 1e-12 * max(1.0, np.abs(gold[name]).max()), name
+    # the sign pattern (what the tagging sees) is identical
+    assert np.array_equal(np.sign(mine.detection_levelset(gold["x"])), np.sign(gold["detection_levelset"]))
