@@ -32,6 +32,10 @@ import re
 import subprocess
 
 import numpy as np
+import sys
+# importing the reference's data modules must not leave a __pycache__ in /root/reference
+# (read-only by contract; root ignores the mode bits)
+sys.dont_write_bytecode = True
 
 REF = "/root/reference/tests/tests_data"
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -2,6 +2,11 @@
 (/root/reference/demo/robin/square/data.py, importable without dolfinx) at seeded random points.
 Run in the build container only; the .npz is the committed fixture."""
 import importlib.util
+import sys
+
+# importing the reference's data modules must not leave a __pycache__ in /root/reference
+# (read-only by contract; root ignores the mode bits)
+sys.dont_write_bytecode = True
 import os
 
 import numpy as np
