@@ -11,11 +11,17 @@ x^2 + y^2 + max(|z| - 1.5 (N - 1), 0)^2 = 1 (the sphere of N = 1 stretched by a 
 same work per unit length, full cross-sections at every slab interface), see phifem_amd/distributed.py.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+With N > 1 the driver starts the ranks itself (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`, WORLD_SIZE in the environment).  Started WITHOUT a launcher, `python bench.py --gpus N` starts the N
+ranks itself (a child `torch.distributed.run`, before this process has touched a GPU) and relays rank 0's line;
+a WORLD_SIZE that contradicts --gpus is an error, never a silent N = 1 run.
 """
 import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import warnings
@@ -26,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -43,12 +49,33 @@ def parse():
                          "(strong scaling); not the default workload")
     ap.add_argument("--config3", action="store_true",
                     help="BASELINE configs[2]: 3-D Poisson with P2 x P2 elements + stabilisation on a --cubes^3 box, "
-                         "one GPU (the 512^3 of the config does not fit one GPU in assembled form; 256^3 does); "
-                         "not the default workload")
+                         "one GPU; not the default workload")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE configs[4]: 1024 x 1024 x 128 cubes per GPU (805 306 368 tets), unit "
                          "sphere, 1024^3 box at 8 GPUs; not the default workload")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD torch.distributed.run
+    (this process has not initialised any GPU -- nothing is re-exec'd), relay its output, return its exit
+    code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
 
 def host_cores(cap=16):
@@ -75,20 +102,28 @@ def host_cores(cap=16):
 def cpu_baseline(n, rtol):
     """The C/OpenMP restatement of the same pipeline (oracle/phifem_oracle.c, "port": a CPU
     restatement, NOT dolfinx/PETSc -- those are not installed here or on the GPU box) on a bounded
-    sample of the same workload: the same sphere problem on an n^3 box, all host cores.
+    sample of the same workload: the same sphere problem on an n^3 box, all host cores.  The system is
+    tagged and assembled once and solved twice: with Jacobi-BiCGStab and with the box sine-transform
+    preconditioner the GPU path runs ("the same preconditioned Krylov solver run on
+    the CPU"); `value` takes the FASTER of the two solves, both are quoted in `sample`.
     Mesh generation is untimed, as on the GPU."""
     from oracle import c_oracle
     cores = host_cores()
-    r = c_oracle.poisson_sphere(n, threads=cores, rtol=rtol)
-    dt = r["t_tag"] + r["t_assemble"] + r["t_solve"]
+    r = c_oracle.poisson_sphere(n, threads=cores, rtol=rtol, precond=1)
+    t_j, t_p = r["t_solve"], (r["t_solve_pc"] if r["pc_built"] else float("inf"))
+    pre = r["t_tag"] + r["t_assemble"]
+    dt = pre + min(t_j, t_p)
     r1 = c_oracle.poisson_sphere(max(n // 2, 8), threads=1, rtol=rtol)
     dt1 = r1["t_tag"] + r1["t_assemble"] + r1["t_solve"]
     return {"value": r["n_active"] / dt, "unit": "DoF/s", "cores": int(r["threads"]), "kind": "port",
+            "value_same_algorithm": r["n_active"] / (pre + t_p) if r["pc_built"] else None,
+            "value_jacobi": r["n_active"] / (pre + t_j),
             "sample": f"C/OpenMP restatement (oracle/phifem_oracle.c), same sphere problem on a {n}^3 "
                       f"box: {int(r['n_active'])} active DoFs, tag {r['t_tag']:.2f} s + assemble "
-                      f"{r['t_assemble']:.2f} s + Jacobi-BiCGStab {r['t_solve']:.2f} s "
-                      f"({int(r['iterations'])} it, rtol {rtol:g}); single core on {max(n // 2, 8)}^3: "
-                      f"{r1['n_active'] / dt1:.0f} DoF/s"}
+                      f"{r['t_assemble']:.2f} s + solve to rtol {rtol:g}: Jacobi-BiCGStab {t_j:.2f} s "
+                      f"({int(r['iterations'])} it) | box sine-transform preconditioner as on the GPU "
+                      f"{t_p:.2f} s ({int(r['iterations_pc'])} it); value = the faster solve; single core, "
+                      f"Jacobi, {max(n // 2, 8)}^3: {r1['n_active'] / dt1:.0f} DoF/s"}
 
 
 # every 8th SpMV launch of the timed region is bracketed by HIP events on the launch stream
@@ -103,44 +138,56 @@ def event_pair_overhead_us(mesh):
     return 1e6 * sec.value
 
 
-def pmc_traffic(kind, cubes):
-    """HBM bytes per launch of the SpMV ("spmv") or the sine-transform y pass ("dst") from the committed
-    PMC passes (profiles/r*/pmc_<kind>_*.json), for the default workload only."""
+def pmc_traffic(kernel, algorithmic_bytes):
+    """HBM bytes per launch of `kernel` from a COMMITTED PMC record (profiles/r*/pmc_*.json; rocprofv3 --pmc in
+    separate passes, corrected as the MI355X guide prescribes).  A record only speaks for the launch it was
+    measured on: it must name the same kernel AND its algorithmic bytes per launch must equal this run's
+    (same system size, element degree and lattice) to 0.5 %.  Otherwise the bench line says null."""
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_{kind}_*.json"))):
-        with open(f) as fh:
-            d = json.load(fh)
-        if d.get("workload_cubes") == cubes:
-            best = d
-    return None if best is None else best["traffic_bytes_per_launch"]
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_*.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if d.get("kernel_key") != kernel or not d.get("algorithmic_bytes_per_launch"):
+            continue
+        if abs(d["algorithmic_bytes_per_launch"] - algorithmic_bytes) <= 5e-3 * algorithmic_bytes:
+            best = (d["traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
+    return best if best else (None, None)
 
 
-def spmv_traffic(cubes):
-    """HBM bytes per SpMV launch from the committed PMC passes (profiles/): collected with
-    rocprofv3 --pmc in separate passes and corrected as the MI355X guide prescribes; only valid
-    for the workload it was measured on."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_spmv_*.json"))):
-        d = json.load(open(f))
-        if d.get("workload_cubes") == cubes:
-            best = d
-    return None if best is None else best["traffic_bytes_per_launch"]
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # no launcher around us: become one (before any GPU / torch.cuda call in this process)
+        raise SystemExit(launch_ranks(args, argv))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} contradicts WORLD_SIZE={world}; refusing to run a different "
+              f"number of ranks than asked for", file=sys.stderr)
+        raise SystemExit(2)
 
-
-def main():
-    args = parse()
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # PHIFEM_DIST_BACKEND=gloo: rehearsal of the N>1 path with several ranks on ONE GPU (RCCL
     # refuses two ranks per device); the driver's runs use nccl (= RCCL), one rank per GPU.
     backend = os.environ.get("PHIFEM_DIST_BACKEND", "nccl")
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        print("bench.py: no GPU visible (the hot path has no CPU fallback)", file=sys.stderr)
+        raise SystemExit(2)
+    if world > 1 and backend == "nccl" and ndev < world:
+        print(f"bench.py: {world} ranks over RCCL need {world} GPUs, {ndev} visible (one rank per GPU; "
+              f"PHIFEM_DIST_BACKEND=gloo rehearses several ranks on one GPU)", file=sys.stderr)
+        raise SystemExit(2)
+    local_rank = local_rank % ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -150,7 +197,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    import phifem_amd as P
+    import phifem_amd as P  # noqa: F401
     from phifem_amd import distributed as D
 
     n = 128 if args.config5 else args.cubes
@@ -184,24 +231,35 @@ def main():
             res = prob.step(profile_spmv=SPMV_EVENT_STRIDE)
         barrier()
         dt = time.perf_counter() - t0
+    ranks_seen, converged = 1, bool(res["converged"])
     if world > 1:
+        # max time over ranks, DoFs summed, every rank counted, convergence agreed (MIN)
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([res["n_active_owned"]], dtype=torch.float64, device=dev)
+        tot = torch.tensor([res["n_active_owned"], 1.0], dtype=torch.float64, device=dev)
         dist.all_reduce(tot)
-        n_active = int(tot.item())
+        n_active, ranks_seen = int(tot[0].item()), int(round(tot[1].item()))
+        ok = torch.tensor([1 if converged else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        converged = bool(ok.item())
+        # the roofline figures come from the busiest rank (rank 0 may own an empty slab)
+        allres = [None] * world
+        dist.all_gather_object(allres, res)
+        res = max(allres, key=lambda r: r["n_active_owned"])
     else:
         n_active = res["n_active_owned"]
 
+    rc = 0
     if rank == 0:
         value = n_active * args.steps / dt
         spmv_s = res["spmv_avg_s"]
         achieved = res["spmv_algorithmic_bytes"] / spmv_s / 1e9 if spmv_s > 0 else 0.0
+        tr, src = pmc_traffic("k_spmv_sell", res["spmv_algorithmic_bytes"])
         spmv_roof = {
             "bound": "hbm", "kernel": "k_spmv_sell (SELL-64 SpMV, f64 values / i32 columns)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("spmv", n), "bytes_per_launch": res["spmv_algorithmic_bytes"],
+            "traffic": tr, "traffic_source": src, "bytes_per_launch": res["spmv_algorithmic_bytes"],
             "avg_launch_us": 1e6 * spmv_s, "launches_timed": res["spmv_count"],
             "launches_per_iteration": 2,
         }
@@ -209,13 +267,14 @@ def main():
         dst_roof = None
         if dst_s > 0:
             a2 = res["dst_algorithmic_bytes"] / dst_s / 1e9
+            tr2, src2 = pmc_traffic("k_dst_s_y", res["dst_algorithmic_bytes"])
             dst_roof = {
                 "bound": "hbm",
                 "kernel": f"k_dst_s<{'float' if res['precond_value_bytes'] == 4 else 'double'},1,false> (type-I sine "
                           f"transform along y of the preconditioner lattice, "
                           f"f{8 * res['precond_value_bytes']}, one read + one write of every lattice point)",
                 "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("dst", n), "bytes_per_launch": res["dst_algorithmic_bytes"],
+                "traffic": tr2, "traffic_source": src2, "bytes_per_launch": res["dst_algorithmic_bytes"],
                 "avg_launch_us": 1e6 * dst_s, "launches_timed": res["dst_count"],
                 "launches_per_iteration": 4, "lattice": res["precond_L"],
             }
@@ -254,8 +313,10 @@ def main():
                            "Jacobi (p)") if res.get("precond") == "box-dst"
                 else "BiCGStab + Jacobi (right)",
                 "rtol": args.rtol, "iterations": res["iterations"], "relres": res["relres"],
+                "converged": converged,
                 "stage_ms": {k: 1e3 * v for k, v in res["stage_s"].items()},
-                "parallelism": f"slab{world}",
+                "parallelism": f"slab{world}", "ranks_seen": ranks_seen,
+                "dist_backend": backend if world > 1 else None,
                 "dist_loop": getattr(getattr(prob, "dk", None), "path", "native-single"),
             },
             "roofline": dominant,
@@ -263,12 +324,23 @@ def main():
         dominant["event_pair_overhead_us"] = event_pair_overhead_us(prob.mesh)
         if other:
             out["roofline_other"] = other
-        if not args.no_cpu_baseline:
+        if not converged or ranks_seen != world:
+            # an unconverged iterate is not a solution (the reference solves directly): the figure is invalid
+            out["valid"] = False
+            out["invalid_reason"] = ("BiCGStab stopped at max_iter above rtol" if not converged
+                                     else f"{ranks_seen} of {world} ranks took part")
+            rc = 3
+        if not args.no_cpu_baseline and world == 1:
             cpu_n = args.cpu_n or (256 if host_cores() >= 12 else 160)
             out["cpu_baseline"] = cpu_baseline(cpu_n, args.rtol)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        code = torch.tensor([rc], dtype=torch.int32, device=dev)
+        dist.broadcast(code, src=0)
+        rc = int(code.item())
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

@@ -139,6 +139,9 @@ enum phx_option {
                                faster per application, but the half-length sine transform amplifies rounding
                                by O(L) and BiCGStab is not a flexible method: erratic on some problems
                                (2-D flower: 100-580 iterations against 38); 0: Jacobi everywhere          */
+  PHX_OPT_ALLOW_EMPTY = 6, /* 1: phx_assemble_poisson_wd returns an EMPTY system (n_active = 0) when no cell
+                               is tagged 1 / 2 instead of PHX_ERR_VALUE: a slab of a partitioned box that
+                               does not touch the domain still joins every collective of the solve          */
   PHX_OPT_SPMV_VALUE_INDEX = 4 /* 1 (default): systems assembled from now on store SELL slices whose
                                values take <= 64 distinct doubles as dictionary + byte codes
                                (bit-identical products, 5 instead of 12 bytes per entry); 0: raw */
@@ -255,8 +258,11 @@ int phx_system_export(phx_system *s, int64_t *rowptr, int32_t *col, double *val,
 enum phx_method { PHX_BICGSTAB_JACOBI = 0 };
 /* Replaces KSP preonly + LU/MUMPS with null-pivot detection (main.py:162-182): solves the active
  * system, returns x in FULL numbering [2*nv] with inactive DoFs = 0 (what ICNTL(24)=1 yields).
- * stats[6] = {iterations, relative residual ||b-Ax||/||b||, seconds, spmv_count,
- *            average SpMV seconds and launches timed (PHX_OPT_PROFILE_SPMV)}. */
+ * stats[8] = {iterations, relative residual ||b-Ax||/||b||, seconds, spmv_count,
+ *            average SpMV seconds and launches timed (PHX_OPT_PROFILE_SPMV),
+ *            converged (1: relative residual <= rtol; 0: max_iter reached -- the reference solves directly,
+ *            its callers assume an accurate x: treat 0 as a failure), breakdown restarts}.
+ * Returns PHX_OK also when max_iter was reached: check stats[6]. */
 int phx_solve(phx_system *s, int method, double rtol, int64_t max_iter, double *x, int loc,
               double *stats);
 
@@ -271,6 +277,11 @@ int phx_solve(phx_system *s, int method, double rtol, int64_t max_iter, double *
  * phases 7 / 8 compute from p / s (rank-local block preconditioner on the owned rows). */
 int phx_krylov_attach(phx_system *s, double *work, double *scal, const uint8_t *own);
 int phx_krylov_precond_active(const phx_system *s, int *active);
+/* Multi-GPU drivers choose the preconditioner collectively: phase 0 leaves this rank's veto in scal[8 + 5]
+ * (1: box preconditioner configured out or impossible here; 0: built, or the rank owns no u row); the driver
+ * all-reduces scal[8 + 4 .. 8 + 5] (SUM) after phase 0 and, when the vetoes add up to > 0, calls this on
+ * every rank before the first iteration: Jacobi everywhere, same vectors exchanged, same check cadence. */
+int phx_krylov_precond_disable(phx_system *s);
 /* After a solve: out[8] = {preconditioner active (0/1), transform lengths L0, L1, L2, lattice points of
  * the box, sampled average seconds of one y-pass launch of the sine transforms (PHX_OPT_PROFILE_SPMV),
  * launches sampled, bytes per lattice value (4: f32 transforms, 8: f64)}. */
@@ -298,6 +309,7 @@ int phx_comm_destroy(phx_comm *c);
 int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, const int *peers,
                           const int64_t *counts, const int64_t *const *idx, double rtol,
                           int64_t max_iter, double *x, int loc, double *stats);
+/* stats[8] as phx_solve, except stats[7] = 1 when all ranks kept the box preconditioner, 0 when one vetoed it. */
 /* One halo exchange of `vec` (solver order) through the solver's own code path: wiring test. */
 int phx_halo_selftest(phx_system *s, phx_comm *c, int npeers, const int *peers,
                       const int64_t *counts, const int64_t *const *idx, double *vec);

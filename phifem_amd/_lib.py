@@ -27,7 +27,8 @@ TRIANGLE, QUADRILATERAL, TETRAHEDRON = 0, 1, 2
 CELL_TYPES = {"triangle": TRIANGLE, "quadrilateral": QUADRILATERAL, "tetrahedron": TETRAHEDRON}
 CELL_NAMES = {v: k for k, v in CELL_TYPES.items()}
 PHI_NODAL_P1, PHI_POINTS, PHI_QUADRIC = 0, 1, 2
-OPT_PROFILE_SPMV, OPT_HAS_EXTERIOR, OPT_SPMV_XCD_GROUP, OPT_SPMV_VALUE_INDEX, OPT_PRECOND = 1, 2, 3, 4, 5
+OPT_PROFILE_SPMV, OPT_HAS_EXTERIOR, OPT_SPMV_XCD_GROUP, OPT_SPMV_VALUE_INDEX, OPT_PRECOND, OPT_ALLOW_EMPTY = (
+    1, 2, 3, 4, 5, 6)
 (ARR_COORDS, ARR_CELLS, ARR_C2F, ARR_F2C, ARR_CELL_TAGS, ARR_FACET_TAGS, ARR_BFACETS, ARR_C2E,
  ARR_EDGES) = range(9)
 
@@ -62,6 +63,7 @@ SIGNATURES = {
     "phx_box_dst_bench": ([_i, _pi, _i, _i, _pd], _i),
     "phx_mesh_tag_histogram": ([_vp, _pi64, _pi64], _i),
     "phx_krylov_precond_active": ([_vp, _pi], _i),
+    "phx_krylov_precond_disable": ([_vp], _i),
     "phx_precond_info": ([_vp, _pd], _i),
     "phx_krylov_attach": ([_vp, _vp, _vp, _vp], _i),
     "phx_krylov_phase": ([_vp, _i], _i),

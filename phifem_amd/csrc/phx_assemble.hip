@@ -962,7 +962,26 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   PHX_CHECK(scan_flags(m, fp, sp, m->nv, &np));
   s->nu = nu;
   s->n = (int64_t)nu + np;
-  PHX_REQUIRE(s->n > 0, PHX_ERR_VALUE, "no active DoF: no cell is tagged 1 or 2");
+  if (s->n == 0) {
+    PHX_HIP(hipStreamSynchronize(m->stream));
+    PHX_HIP(phx_free(fu)); PHX_HIP(phx_free(fp)); PHX_HIP(phx_free(su)); PHX_HIP(phx_free(sp));
+    if (!m->allow_empty) {
+      delete s;
+      phx_set_error("no active DoF: no cell is tagged 1 or 2");
+      return PHX_ERR_VALUE;
+    }
+    // PHX_OPT_ALLOW_EMPTY (slab drivers): a system without rows that still takes part in the collectives
+    int rc = PHX_OK;
+    if (phx_malloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)m->nv) != hipSuccess ||
+        phx_malloc(&s->dof_of_vertex_p, sizeof(int32_t) * (size_t)m->nv) != hipSuccess ||
+        hipMemsetAsync(s->dof_of_vertex_u, 0xff, sizeof(int32_t) * (size_t)m->nv, m->stream) != hipSuccess ||
+        hipMemsetAsync(s->dof_of_vertex_p, 0xff, sizeof(int32_t) * (size_t)m->nv, m->stream) != hipSuccess)
+      rc = PHX_ERR_HIP;
+    if (rc == PHX_OK) rc = phx_system_build_empty(s);
+    if (rc != PHX_OK) { phx_system_destroy(s); return rc; }
+    *out = s;
+    return PHX_OK;
+  }
   PHX_HIP(phx_malloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)m->nv));
   PHX_HIP(phx_malloc(&s->dof_of_vertex_p, sizeof(int32_t) * (size_t)m->nv));
   PHX_HIP(phx_malloc(&s->full_of_active, sizeof(int64_t) * (size_t)s->n));

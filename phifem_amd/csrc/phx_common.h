@@ -119,6 +119,7 @@ struct phx_mesh {
   int spmv_value_index = 1;        // PHX_OPT_SPMV_VALUE_INDEX
   int precond = 1;                 // PHX_OPT_PRECOND: 0 Jacobi, 1 / 2 box sine transforms in f64 / f32 where applicable
   int has_exterior_override = -1;  // -1: decide from the local tags; 0/1: imposed (multi-GPU)
+  int allow_empty = 0;             // PHX_OPT_ALLOW_EMPTY: assembly returns an EMPTY system when no cell is tagged 1 / 2
 };
 
 struct phx_system {
@@ -161,6 +162,7 @@ struct phx_system {
   bool u_p2_block = false;         // rows [0, nu): P2, one DoF per active vertex and edge (entities nv + ne)
   struct phx_box_precond *precond = nullptr;
   int precond_state = 0;           // 0 not tried, 1 built, -1 not applicable
+  bool precond_veto = false;       // multi-GPU vote: this rank cannot run the box preconditioner although it has u rows
   std::vector<hipEvent_t> prof_ev[2];  // event pairs of the sampled launches: [0] SpMV, [1] sine-transform y pass
   int prof_used[2] = {0, 0}, prof_seen[2] = {0, 0};
 };
@@ -171,5 +173,6 @@ int phx_begin_timing(phx_mesh *m);
 int phx_end_timing(phx_mesh *m, int slot);
 int phx_mesh_build_edges(phx_mesh *m);
 
+int phx_system_build_empty(phx_system *s);  // phx_solve.hip
 struct phx_box_precond;
 void phx_box_precond_destroy(phx_box_precond *bp);  // phx_solve.hip

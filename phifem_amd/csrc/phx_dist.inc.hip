@@ -25,8 +25,10 @@ enum { PHX_NCCL_FLOAT64 = 8, PHX_NCCL_SUM = 0 };  // ncclDataType_t / ncclRedOp_
 static int nccl_bind() {
   if (g_nccl.ok) return PHX_OK;
   void *h = nullptr;
-  const char *names[] = {"librccl.so.1", "librccl.so", "libnccl.so.2"};
-  for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+  // PHX_RCCL_LIB: an explicit library path (the tests load a host-staged stand-in that lets several ranks share
+  // the one GPU of the test box, which RCCL itself refuses)
+  const char *names[] = {getenv("PHX_RCCL_LIB"), "librccl.so.1", "librccl.so", "libnccl.so.2"};
+  for (const char *n : names) { if (!n || !*n) continue; h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
   PHX_REQUIRE(h != nullptr, PHX_ERR_HIP, "librccl not found: %s", dlerror());
 #define BIND(field, sym) \
   *(void **)(&g_nccl.field) = dlsym(h, sym); \
@@ -139,7 +141,7 @@ static int allreduce_R(phx_system *s, phx_comm *c, int lo, int hi) {
 
 // peers[npeers], counts[2*npeers] = {nsend, nrecv} per peer, idx[2*npeers] device pointers
 // {send_idx, recv_idx} (int64 solver positions), work/scal/own as phx_krylov_attach (already
-// attached).  stats[6] as phx_solve.  Exchange `check` != 0 first verifies the halo wiring by
+// attached).  stats[8] as phx_solve (stats[7]: 1 = every rank kept the box preconditioner).  Exchange `check` != 0 first verifies the halo wiring by
 // sending each peer the int64 tags in `tags_send[p]` and comparing with `tags_expect[p]`.
 extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, const int *peers,
                                      const int64_t *counts, const int64_t *const *idx, double rtol,
@@ -164,12 +166,16 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     PHX_CHECK(prof_reset(s));
     PHX_CHECK(phx_begin_timing(m));
     PHX_CHECK(phx_krylov_phase(s, 0));
-    PHX_CHECK(allreduce_R(s, c, R_RHO, R_RHO + 1));
+    PHX_CHECK(allreduce_R(s, c, R_RHO, R_RR + 1));  // (b, b) and the preconditioner vetoes
     PHX_CHECK(phx_krylov_phase(s, 1));
-    const KrVecs V = kr_vecs(s);  // after phase 0: the preconditioner decides where phat / shat live
-    const int check_every = s->precond_state == 1 ? 2 : 8;
     PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
     PHX_HIP(hipStreamSynchronize(st));
+    // the preconditioner is a COLLECTIVE choice: one veto and every rank iterates with Jacobi, so that all
+    // ranks exchange the same vectors and test convergence at the same iterations
+    const bool pc_all = s->scal_h[R_OFF + R_RR] == 0.0;
+    if (!pc_all) PHX_CHECK(phx_krylov_precond_disable(s));
+    const KrVecs V = kr_vecs(s);  // after the vote: the preconditioner decides where phat / shat live
+    const int check_every = pc_all ? 2 : 8;
     const double bb = s->scal_h[S_BB];
     int64_t it = 0;
     double relres = bb == 0.0 ? 0.0 : 1.0;
@@ -207,6 +213,7 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     if (stats) {
       stats[0] = (double)it; stats[1] = relres; stats[2] = m->timings[3];
       stats[3] = (double)(2 * it); stats[4] = pavg; stats[5] = (double)pcount;
+      stats[6] = relres <= rtol ? 1.0 : 0.0; stats[7] = pc_all ? 1.0 : 0.0;
     }
     return PHX_OK;
   };

@@ -803,6 +803,7 @@ __global__ void k_dscale_weighted(int64_t n, const int32_t *__restrict__ perm, c
 static int box_precond_setup(phx_system *s) {
   phx_mesh *m = s->mesh;
   s->precond_state = -1;
+  s->precond_veto = true;   // until built, or found to have nothing to build (multi-GPU vote, phx_solve.hip)
   const bool p2 = s->u_p2_block && m->is_box && m->edges != nullptr;
   const bool p1 = (m->is_box || m->on_box_lattice) && s->u_vertex_block;
   if (!m->precond || (!p1 && !p2)) return PHX_OK;
@@ -820,7 +821,7 @@ static int box_precond_setup(phx_system *s) {
   PHX_HIP(hipMemcpyAsync(hbb, dbb, sizeof(hbb), hipMemcpyDeviceToHost, st));
   PHX_HIP(hipStreamSynchronize(st));
   PHX_HIP(phx_free(dbb));
-  if (hbb[3] < 0) return PHX_OK;  // no active u DoF here
+  if (hbb[3] < 0) { s->precond_veto = false; return PHX_OK; }  // no (owned) active u DoF here: nothing to precondition
   int L[3], lo[3];
   for (int a = 0; a < 3; ++a) {
     const int extent = hbb[3 + a] - hbb[a] + 1;
@@ -870,6 +871,7 @@ static int box_precond_setup(phx_system *s) {
   bp->own_ptr = s->own;
   s->precond = bp;
   s->precond_state = 1;
+  s->precond_veto = false;
   return PHX_OK;
 }
 

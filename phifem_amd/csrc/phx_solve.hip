@@ -281,6 +281,18 @@ int phx_system_build_sell(phx_system *s) {
   return PHX_OK;
 }
 
+// Workspace of a system without any active DoF (a slab that does not touch the domain): it takes part in
+// every collective of a multi-GPU solve with zero contributions.
+int phx_system_build_empty(phx_system *s) {
+  s->n = 0; s->nu = 0; s->nnz = 0; s->nslices = 0; s->sell_nnz = 0; s->sell_true_nnz = 0;
+  PHX_HIP(phx_malloc(&s->work, sizeof(double) * 16));
+  PHX_HIP(phx_malloc(&s->scal, sizeof(double) * PHX_SCAL_DOUBLES));
+  PHX_HIP(hipMemsetAsync(s->scal, 0, sizeof(double) * PHX_SCAL_DOUBLES, s->mesh->stream));
+  PHX_HIP(hipHostMalloc(&s->scal_h, sizeof(double) * 16));
+  PHX_HIP(hipStreamSynchronize(s->mesh->stream));
+  return PHX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // SpMV: one wavefront per slice, 4 slices per 256-thread block.  DOTS > 0 fuses dot products of
 // the result with up to two vectors into the same pass (block reduction + one f64 atomic each).
@@ -481,6 +493,12 @@ k_kr_begin(int64_t n, const int32_t *__restrict__ perm, const double *__restrict
   block_atomic_sum(acc, slot_base(S, 0, R_RHO));
 }
 
+// Multi-GPU: the preconditioner must be chosen by ALL ranks together.  Phase 0 leaves this rank's veto (1: the
+// box preconditioner is configured out or cannot be built here, 0: built, or nothing to build because the rank
+// owns no u DoF) in R[R_RR], the driver all-reduces it with (b, b), and every rank that reads a sum > 0 after
+// phase 1 drops its preconditioner (phx_krylov_precond_disable).
+__global__ void k_set_scalar(double *p, double v) { *p = v; }
+
 // after the (optional) all-reduce of R: rho = bb = R_RHO
 __global__ void k_kr_begin2(double *S, int mode) {
   S[S_MODE] = mode ? 1.0 : 0.0;
@@ -583,11 +601,12 @@ __global__ void k_scatter_solution(int64_t n, const int32_t *__restrict__ perm,
   xfull[full_of_active[r]] = y[i] / diag[r];
 }
 
-static inline dim3 vec_grid(int64_t n) { return dim3((unsigned)std::min<int64_t>(phx_div_up(n, 256), 2048)); }
+static inline dim3 vec_grid(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(phx_div_up(n, 256), 2048))); }
 
 static int launch_spmv(phx_system *s, const double *vals, const double *x, double *y, int dots,
                        const double *d0, double *o0, double *o1) {
   hipStream_t st = s->mesh->stream;
+  if (s->nslices == 0) return PHX_OK;  // empty system (a slab outside the domain): the dot-product slots stay zero
   const dim3 block(256), grid((unsigned)phx_div_up(s->nslices, 4));
   const uint8_t *own = s->own;
   const int xg = s->mesh->spmv_xcd_group;
@@ -699,6 +718,7 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       PHX_HIP(hipMemsetAsync(S, 0, sizeof(double) * PHX_SCAL_DOUBLES, st));
       k_kr_begin<<<vec_grid(n), block, 0, st>>>(n, s->perm, s->rhs, s->own, V.b, V.r, V.rhat, V.p, V.y, S);
       k_reduce_slots<<<1, 64, 0, st>>>(S, 0, R_RHO, 1, 1);
+      if (mode) k_set_scalar<<<1, 1, 0, st>>>(S + R_OFF + R_RR, s->precond_veto ? 1.0 : 0.0);
       break;
     case 1:
       k_kr_begin2<<<1, 1, 0, st>>>(S, mode);
@@ -755,8 +775,9 @@ extern "C" int phx_krylov_finish(phx_system *s, double *x_out, int loc) {
   double *owned = nullptr;
   if (loc != PHX_DEVICE) { PHX_HIP(phx_malloc(&owned, sizeof(double) * (size_t)s->nfull)); xfull = owned; }
   PHX_HIP(hipMemsetAsync(xfull, 0, sizeof(double) * (size_t)s->nfull, st));
-  k_scatter_solution<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, st>>>(
-      n, s->perm, s->full_of_active, s->diag, V.y, xfull);
+  if (n > 0)
+    k_scatter_solution<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, st>>>(
+        n, s->perm, s->full_of_active, s->diag, V.y, xfull);
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(st));
   if (owned) {
@@ -770,6 +791,18 @@ extern "C" int phx_krylov_finish(phx_system *s, double *x_out, int loc) {
 // the vectors a multi-GPU driver must halo-exchange instead of p / s)
 extern "C" int phx_krylov_precond_active(const phx_system *s, int *active) {
   *active = s->precond_state == 1 ? 1 : 0;
+  return PHX_OK;
+}
+
+// Collective decision (see k_set_scalar): drop this rank's preconditioner; phat / shat alias p / s again.
+extern "C" int phx_krylov_precond_disable(phx_system *s) {
+  if (s->precond_state == 1) {
+    PHX_HIP(hipSetDevice(s->mesh->device));
+    PHX_HIP(hipStreamSynchronize(s->mesh->stream));
+    phx_box_precond_destroy(s->precond);
+    s->precond = nullptr;
+  }
+  s->precond_state = -1;
   return PHX_OK;
 }
 
@@ -887,6 +920,8 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
     stats[3] = (double)spmvs;
     stats[4] = pavg;
     stats[5] = (double)pcount;
+    stats[6] = relres <= rtol ? 1.0 : 0.0;  // converged: the caller decides what an unconverged iterate is worth
+    stats[7] = s->scal_h[S_RESTARTS];
   }
   return rc;
 }

@@ -68,6 +68,9 @@ class HipBackend:
         self.L.check(self.L.lib.phx_krylov_precond_active(self.sys, C.byref(a)))
         return bool(a.value)
 
+    def precond_disable(self):
+        self.L.check(self.L.lib.phx_krylov_precond_disable(self.sys))
+
     def finish(self, out):
         self.L.check(self.L.lib.phx_krylov_finish(self.sys, C.c_void_p(out.data_ptr()), self.L.DEVICE))
 
@@ -154,6 +157,7 @@ class DistributedSolver:
     def _verify_halos(self):
         """Both sides of an interface must enumerate the same DoFs: compare the global ids."""
         torch, dist = self.torch, self.dist
+        live = []
         for h in self.halos:
             mine = torch.tensor([h["send"][1].numel(), h["recv"][1].numel()], dtype=torch.long,
                                 device=h["send"][1].device)
@@ -164,12 +168,16 @@ class DistributedSolver:
                     f"rank {self.rank}: halo size mismatch with rank {h['peer']}: they send "
                     f"{int(theirs[0])} / expect {int(theirs[1])}, I expect "
                     f"{h['recv'][1].numel()} / send {h['send'][1].numel()}")
+            if h["send"][1].numel() == 0 and h["recv"][1].numel() == 0:
+                continue   # an interface outside the domain (e.g. next to an empty slab): both sides drop it
+            live.append(h)
             got = torch.empty_like(h["recv"][1])
             self._sendrecv(h["peer"], h["send"][1].contiguous(), got)
             if not torch.equal(got, h["recv"][1]):
                 raise RuntimeError(f"rank {self.rank}: halo DoF sets differ from rank {h['peer']}")
             h["sbuf"] = torch.empty(h["send"][0].numel(), dtype=torch.float64, device=got.device)
             h["rbuf"] = torch.empty(h["recv"][0].numel(), dtype=torch.float64, device=got.device)
+        self.halos = live
 
     def _sendrecv(self, peer, out_t, in_t):
         dist = self.dist
@@ -208,12 +216,17 @@ class DistributedSolver:
         b.synchronize()
         t0 = time.perf_counter()
         b.phase(0)
-        self._allreduce(R_RHO, R_RHO + 1)
+        self._allreduce(R_RHO, R_RR + 1)     # (b, b) and the preconditioner vetoes (phx_krylov_precond_disable)
         b.phase(1)
-        bb = float(self.scal[S_BB].item())
+        head = self.scal[:16].cpu()
+        bb = float(head[S_BB])
         it, relres = 0, (0.0 if bb == 0.0 else 1.0)
-        # with a rank-local block preconditioner the SpMV inputs are phat = P p, shat = P s
-        pc = getattr(b, "precond_active", lambda: False)()
+        # The preconditioner is a COLLECTIVE choice: with one veto every rank iterates with Jacobi, so that all
+        # ranks exchange the same vectors (phat / shat = P p / P s, or p / s) and test convergence at the
+        # same iterations.  A rank without owned u rows (an empty slab) does not veto.
+        pc = float(head[R_OFF + R_RR]) == 0.0
+        if not pc:
+            b.precond_disable()
         vp, vs = (self.phat, self.shat) if pc else (self.p, self.s)
         check_every = 2 if pc else self.check_every
         while bb != 0.0 and it < self.max_iter:
@@ -242,7 +255,8 @@ class DistributedSolver:
         b.finish(out)
         b.synchronize()
         dt = time.perf_counter() - t0
-        st = {"iterations": it, "relres": relres, "seconds": dt, "n_owned": self.n_owned}
+        st = {"iterations": it, "relres": relres, "seconds": dt, "n_owned": self.n_owned,
+              "converged": bool(relres <= self.rtol), "precond_all": pc}
         if profile_spmv:
             prof = b.profile(False)
             if prof:
@@ -273,24 +287,34 @@ class DistributedKrylov:
         from . import _lib as L
         hist = (C.c_int64 * 4)()
         L.check(L.lib.phx_mesh_tag_histogram(self.prob.mesh._h, hist, None))
-        flag = self.torch.tensor([1 if hist[3] > 0 else 0], dtype=self.torch.int32, device=self.dev)
+        flag = self.torch.tensor([1 if hist[3] > 0 else 0], dtype=self.torch.int32, device=self._ctl_device())
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
         L.check(L.lib.phx_set_option(self.prob.mesh._h, L.OPT_HAS_EXTERIOR, int(flag.item())))
 
+    def _ctl_device(self):
+        """Device of the small control tensors: the GPU with nccl, the host with gloo."""
+        return self.dev if self.dist.get_backend() == "nccl" else self.torch.device("cpu")
+
     def _all_ok(self, ok):
-        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.dev)
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self._ctl_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return bool(t.item())
 
     def _init_native(self):
-        """RCCL communicator of the library: id from rank 0, broadcast with torch.distributed."""
+        """RCCL communicator of the library: id from rank 0, broadcast with torch.distributed.
+        The native loop is the default with the nccl backend; PHIFEM_NATIVE_LOOP=1 asks for it under
+        gloo as well (tests: several ranks on one GPU with PHX_RCCL_LIB naming the host-staged stand-in
+        of tests/fake_rccl), PHIFEM_NATIVE_LOOP=0 forces the Python loop."""
+        import os
         from . import _lib as L
         torch, dist = self.torch, self.dist
-        if dist.get_backend() != "nccl":
+        want = os.environ.get("PHIFEM_NATIVE_LOOP", "")
+        if want == "0" or (dist.get_backend() != "nccl" and want != "1"):
             self.native = False
             return
         ok = True
-        uid = torch.zeros(128, dtype=torch.uint8, device=self.dev)
+        ctl = self._ctl_device()
+        uid = torch.zeros(128, dtype=torch.uint8, device=ctl)
         try:
             if self.prob.rank == 0:
                 buf = (C.c_ubyte * 128)()
@@ -365,7 +389,7 @@ class DistributedKrylov:
             return ds.solve(out, profile_spmv=profile_spmv)
         self.path = "native"
         np_, peers, counts, idx, keep = self._halo_arrays(ds)
-        st = (C.c_double * 6)()
+        st = (C.c_double * 8)()
         self.torch.cuda.synchronize(self.dev)
         t0 = time.perf_counter()
         L.check(L.lib.phx_solve_distributed(backend.sys, self.comm, np_, peers, counts, idx,
@@ -373,4 +397,5 @@ class DistributedKrylov:
                                             C.c_void_p(out.data_ptr()), L.DEVICE, st))
         self.torch.cuda.synchronize(self.dev)
         return {"iterations": int(st[0]), "relres": st[1], "seconds": time.perf_counter() - t0,
-                "n_owned": ds.n_owned, "spmv_avg_s": st[4], "spmv_timed": int(st[5])}
+                "n_owned": ds.n_owned, "spmv_avg_s": st[4], "spmv_timed": int(st[5]),
+                "converged": bool(st[6]), "precond_all": bool(st[7])}

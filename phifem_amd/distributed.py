@@ -58,6 +58,10 @@ class SlabProblem:
         # the slab's end planes inside the global box are cuts, not background boundary
         L.check(L.lib.phx_mesh_set_slab_faces(self.mesh._h, 1 if lay["k0"] > 0 else 0,
                                               1 if lay["k1"] < lay["nz"] else 0))
+        if w > 1:
+            # a slab that does not touch the domain (ranks 0 and 7 of the 1024^3 box around the unit sphere)
+            # gets an empty system and still joins every collective
+            L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_ALLOW_EMPTY, 1))
         dev = torch.device("cuda", self.device)
         x = torch.empty((self.mesh.nv, 3), dtype=torch.float64, device=dev)
         L.check(L.lib.phx_mesh_get_array(self.mesh._h, L.ARR_COORDS, C.c_void_p(x.data_ptr()), L.DEVICE))
@@ -75,14 +79,23 @@ class SlabProblem:
             from .dist_solver import DistributedKrylov
             self.dk = DistributedKrylov(self)
 
+    # --- one step of the hot path; the subclasses only say how they tag and assemble -----------------
+    single_layer_cut = True
+
+    def _assemble(self):
+        return self.solver.assemble(self.phi, self.f, self.u_ex)
+
+    def _tag_levelset(self):
+        return self.phi
+
     def step(self, profile_spmv=False):
         """tag -> assemble -> solve, everything resident on the device."""
         mesh = self.mesh
-        staged = _tag_cells(mesh, NodalFunction(self.phi), 1, single_layer_cut=True)
+        staged = _tag_cells(mesh, NodalFunction(self._tag_levelset()), 1, single_layer_cut=self.single_layer_cut)
         if self.world > 1:
             self.dk.agree_on_exterior()
         _tag_facets(mesh, staged, 1)
-        info = self.solver.assemble(self.phi, self.f, self.u_ex)
+        info = self._assemble()
         if self.world == 1:
             self.solver.solve(rtol=self.rtol, max_iter=self.max_iter, out=self.out,
                               profile_spmv=profile_spmv)
@@ -95,10 +108,12 @@ class SlabProblem:
         pc = self.solver.precond_info()
         return {
             "n_active_owned": n_owned, "iterations": st["iterations"], "relres": st["relres"],
+            "converged": bool(st.get("converged", st["relres"] <= self.rtol)),
             "stage_s": {"tag": t["tag_cells"] + t["tag_facets"], "assemble": t["assemble"],
                         "solve": st["seconds"]},
             "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),
             "spmv_algorithmic_bytes": 12.0 * info["sell_nnz"] + 20.0 * info["n_active"],
+            "spmv_stream_bytes": info["spmv_matrix_bytes"],
             # sine-transform y pass of the preconditioner: reads and writes every lattice point once
             "precond": pc["precond"], "precond_L": pc["precond_L"],
             "dst_avg_s": pc["dst_avg_s"], "dst_count": pc["dst_timed"],
@@ -147,38 +162,13 @@ class ElasticitySlabProblem(SlabProblem):
             from .dist_solver import DistributedKrylov
             self.dk = DistributedKrylov(self)
 
-    def step(self, profile_spmv=False):
-        mesh = self.mesh
-        staged = _tag_cells(mesh, NodalFunction(self.phi), 1, single_layer_cut=False)
-        if self.world > 1:
-            self.dk.agree_on_exterior()
-        _tag_facets(mesh, staged, 1)
-        info = self.solver.assemble(self.phi, self.f, self.u_D, self.bc_vertices)
-        if self.world == 1:
-            self.solver.solve(rtol=self.rtol, max_iter=self.max_iter, out=self.out,
-                              profile_spmv=profile_spmv)
-            st = self.solver.stats
-            n_owned = info["n_active"]
-        else:
-            st = self.dk.solve(self.out, profile_spmv=profile_spmv)
-            n_owned = st["n_owned"]
-        t = mesh.timings()
-        pc = self.solver.precond_info()
-        return {
-            "n_active_owned": n_owned, "iterations": st["iterations"], "relres": st["relres"],
-            "stage_s": {"tag": t["tag_cells"] + t["tag_facets"], "assemble": t["assemble"],
-                        "solve": st["seconds"]},
-            "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),
-            "spmv_algorithmic_bytes": 12.0 * info["sell_nnz"] + 20.0 * info["n_active"],
-            # sine-transform y pass of the preconditioner: reads and writes every lattice point once
-            "precond": pc["precond"], "precond_L": pc["precond_L"],
-            "dst_avg_s": pc["dst_avg_s"], "dst_count": pc["dst_timed"],
-            "dst_algorithmic_bytes": 2.0 * pc["precond_value_bytes"] * pc["precond_points"],
-            "precond_value_bytes": pc["precond_value_bytes"],
-        }
+    single_layer_cut = False
+
+    def _assemble(self):
+        return self.solver.assemble(self.phi, self.f, self.u_D, self.bc_vertices)
 
 
-class P2Problem:
+class P2Problem(SlabProblem):
     """BASELINE configs[2] on one GPU: 3-D weak-Dirichlet Poisson, P2 x P2 with the div(grad) and ghost-penalty
     stabilisation terms, level-set in P2, spherical domain, n^3 Kuhn box (the 512^3 of the config does not fit
     one GPU in assembled form; 256^3 = 2.3e7 DoFs does)."""
@@ -206,22 +196,5 @@ class P2Problem:
         del x, e, pts
         torch.cuda.synchronize()
 
-    def step(self, profile_spmv=False):
-        mesh = self.mesh
-        staged = _tag_cells(mesh, NodalFunction(self.phi1), 1, single_layer_cut=True)
-        _tag_facets(mesh, staged, 1)
-        info = self.solver.assemble(self.phi, self.f, self.u_ex)
-        self.solver.solve(rtol=self.rtol, max_iter=self.max_iter, out=self.out, profile_spmv=profile_spmv)
-        st = self.solver.stats
-        t = mesh.timings()
-        pc = self.solver.precond_info()
-        return {
-            "n_active_owned": info["n_active"], "iterations": st["iterations"], "relres": st["relres"],
-            "stage_s": {"tag": t["tag_cells"] + t["tag_facets"], "assemble": t["assemble"], "solve": st["seconds"]},
-            "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),
-            "spmv_algorithmic_bytes": 12.0 * info["sell_nnz"] + 20.0 * info["n_active"],
-            "precond": pc["precond"], "precond_L": pc["precond_L"],
-            "dst_avg_s": pc["dst_avg_s"], "dst_count": pc["dst_timed"],
-            "dst_algorithmic_bytes": 2.0 * pc["precond_value_bytes"] * pc["precond_points"],
-            "precond_value_bytes": pc["precond_value_bytes"],
-        }
+    def _tag_levelset(self):
+        return self.phi1

@@ -25,9 +25,10 @@ class MeshTags:
 class Mesh:
     """Owns a `phx_mesh*`.  Arrays stay on the GPU; accessors copy on demand."""
 
-    def __init__(self, handle, parent=None):
+    def __init__(self, handle, parent=None, device=None):
         self._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
         self.parent = parent
+        self.device = int(device) if device is not None else (parent.device if parent is not None else 0)
         cnt = (C.c_int64 * 6)()
         L.check(L.lib.phx_mesh_counts(self._h, cnt))
         self.gdim, ct, self.nv, self.nc, self.nf, self.nbf = (int(v) for v in cnt)
@@ -51,7 +52,7 @@ class Mesh:
         L.check(L.lib.phx_mesh_create(x.shape[1], L.CELL_TYPES[cell_type], x.shape[0],
                                       x.ctypes.data_as(C.c_void_p), cells.shape[0],
                                       cells.ctypes.data_as(C.c_void_p), device, C.byref(h)))
-        return cls(h)
+        return cls(h, device=device)
 
     def __del__(self):
         try:
@@ -142,7 +143,7 @@ def create_box(lo, hi, n, device=0, offset=None, n_global=None):
         n.ctypes.data_as(C.c_void_p),
         None if off is None else off.ctypes.data_as(C.c_void_p),
         None if ng is None else ng.ctypes.data_as(C.c_void_p), device, C.byref(h)))
-    return Mesh(h)
+    return Mesh(h, device=device)
 
 
 def create_rectangle(bbox, n, device=0):

@@ -80,7 +80,14 @@ def _levelset_args(mesh, levelset, degree):
         return L.PHI_POINTS, p, loc, vals
     if isinstance(levelset, NodalFunction):
         v = levelset.values
-        if not hasattr(v, "data_ptr"):
+        if hasattr(v, "data_ptr"):
+            # the kernels read the tensor as a raw double*: it has to be one
+            import torch
+            if v.dtype != torch.float64 or not v.is_contiguous() or v.numel() != mesh.nv:
+                raise ValueError("a nodal level-set tensor must be contiguous float64 with one value per mesh vertex")
+            if v.is_cuda and v.device.index != mesh.device:
+                raise ValueError(f"nodal level-set lives on cuda:{v.device.index}, the mesh on cuda:{mesh.device}")
+        else:
             v = np.ascontiguousarray(v, dtype=np.float64)
             if v.shape[0] != mesh.nv:
                 raise ValueError("nodal level-set must have one value per mesh vertex")

@@ -6,10 +6,28 @@ class-based interface for it.  This class is that interface for the P1 x P1 weak
 Poisson problem, with the element integration, scatter and Krylov solve in HIP.
 """
 import ctypes as C
+import warnings
 
 import numpy as np
 
 from . import _lib as L
+
+
+class ConvergenceWarning(RuntimeWarning):
+    """The Krylov solve stopped at max_iter with a relative residual above rtol.  The reference solves
+    directly (MUMPS LU, demo/weak-dirichlet/flower/main.py:162-182), so its callers assume an accurate
+    solution: an unconverged iterate must not pass silently."""
+
+
+def check_converged(stats, rtol, strict=False):
+    """Warn (or raise with strict=True) when `stats` describes an unconverged solve."""
+    if stats.get("converged", True):
+        return
+    msg = (f"BiCGStab did not converge: relative residual {stats['relres']:.3e} > rtol {rtol:g} after "
+           f"{stats['iterations']} iterations")
+    if strict:
+        raise ArithmeticError(msg)
+    warnings.warn(msg, ConvergenceWarning, stacklevel=3)
 
 
 class PhiFEMSolver:
@@ -41,9 +59,20 @@ class PhiFEMSolver:
         except Exception:
             pass
 
-    @staticmethod
-    def _arr(a, n):
+    def _arr(self, a, n):
+        """Nodal array of the C ABI: numpy (converted) or a torch tensor, which is handed to the kernels as a
+        raw `double*` and therefore has to BE one: float64, contiguous, n values, and -- on the device -- on
+        the mesh's GPU."""
         if hasattr(a, "data_ptr"):
+            import torch
+            if a.dtype != torch.float64:
+                raise ValueError(f"nodal tensor has dtype {a.dtype}, the C ABI takes float64")
+            if not a.is_contiguous():
+                raise ValueError("nodal tensor is not contiguous")
+            if a.numel() != n:
+                raise ValueError(f"nodal tensor has {a.numel()} values, the space has {n} DoFs")
+            if a.is_cuda and a.device.index != self.mesh.device:
+                raise ValueError(f"nodal tensor lives on cuda:{a.device.index}, the mesh on cuda:{self.mesh.device}")
             return a
         a = np.ascontiguousarray(a, dtype=np.float64)
         if a.shape[0] != n:
@@ -70,6 +99,7 @@ class PhiFEMSolver:
                 self.mesh._h, self.pen_coef, self.stab_coef, L.ptr(phi_h)[0], self.levelset_degree,
                 L.ptr(f_h)[0], L.ptr(u_D)[0], locs.pop(), C.byref(h)))
         self._sys = h
+        self._keep = (phi_h, f_h, u_D)   # device inputs stay alive as long as the system they were read for
         return self.info()
 
     @property
@@ -97,20 +127,28 @@ class PhiFEMSolver:
                                                      for a in (rowptr, col, val, rhs, dof))))
         return rowptr, col, val, rhs, dof
 
-    def solve(self, rtol=1e-8, max_iter=20000, out=None, profile_spmv=False):
+    def solve(self, rtol=1e-8, max_iter=20000, out=None, profile_spmv=False, strict=False):
         """Replaces the KSP/MUMPS block of main.py:162-182.  Returns the mixed solution in the
         full numbering [u (nv), p (nv)] with inactive DoFs at zero; `out` may be a device
-        tensor of 2*nv doubles."""
+        tensor of 2*nv doubles.  `stats["converged"]` says whether rtol was reached; if not, a
+        `ConvergenceWarning` is issued (strict=True: ArithmeticError) -- the reference's direct solve
+        never returns an inaccurate x silently."""
         nfull = self.info()["n_full"]
         if out is None:
             out = np.empty(nfull, dtype=np.float64)
+        elif hasattr(out, "data_ptr"):
+            import torch
+            if out.dtype != torch.float64 or not out.is_contiguous() or out.numel() != nfull:
+                raise ValueError(f"`out` must be a contiguous float64 tensor of {nfull} values")
         p, loc = L.ptr(out)
-        st = (C.c_double * 6)()
+        st = (C.c_double * 8)()
         L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_PROFILE_SPMV, int(profile_spmv)))
         L.check(L.lib.phx_solve(self._sys, 0, float(rtol), int(max_iter), p, loc, st))
         self.stats = {"iterations": int(st[0]), "relres": st[1], "seconds": st[2],
-                      "spmv": int(st[3]), "spmv_avg_s": st[4], "spmv_timed": int(st[5])}
+                      "spmv": int(st[3]), "spmv_avg_s": st[4], "spmv_timed": int(st[5]),
+                      "converged": bool(st[6]), "restarts": int(st[7])}
         self.stats.update(self.precond_info())
+        check_converged(self.stats, rtol, strict)
         return out
 
     def split(self, w):

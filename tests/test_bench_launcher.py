@@ -1,0 +1,60 @@
+"""bench.py's own launcher: `--gpus N` must never silently run one rank."""
+import os
+import subprocess
+import sys
+
+import bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(kw)
+    return env
+
+
+def test_world_size_contradicting_gpus_is_an_error():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline"],
+                       env=_env(WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "contradicts WORLD_SIZE" in r.stderr
+    assert "{" not in r.stdout
+
+
+def test_launcher_command(monkeypatch):
+    seen = {}
+
+    class R:
+        returncode = 7
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return R()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    argv = ["--gpus", "3", "--steps", "2", "--cubes", "64"]
+    rc = bench.launch_ranks(bench.parse(argv), argv)
+    cmd = seen["cmd"]
+    assert rc == 7                                   # the child's exit code is the parent's
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=3" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-len(argv):] == argv and cmd[-len(argv) - 1].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_gpus_2_without_launcher_starts_ranks_and_fails_without_a_gpu():
+    """No GPU in the build container: the two ranks the launcher starts must each fail loudly (no CPU
+    fallback), and the parent must hand that failure on -- not print an n_gpus = 1 line."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: covered by tests/test_hip_multirank.py")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cubes", "16",
+                        "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       env=_env(PHIFEM_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "no GPU visible" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -25,13 +25,13 @@ def free_port():
     return p
 
 
-def worker(rank, world, n, port, outdir):
+def worker(rank, world, n, port, outdir, sphere=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         lay = slab_layout(n, rank, world)
-        x, topo, cv, A, b, act = assemble_local(n, world, lay["k0"], lay["k1"], has_exterior=True)
+        x, topo, cv, A, b, act = assemble_local(n, world, lay["k0"], lay["k1"], has_exterior=True, sphere=sphere)
         be = CpuBackend(A, b, act, topo.nv)
         plane = (n + 1) * (n + 1)
         ds = DistributedSolver(be, dist, torch, rank, world, plane, lay["k0"], lay["P0"], lay["P1"],
@@ -74,6 +74,29 @@ def test_slab_solver_matches_single_mesh(world, tmp_path):
     scale = np.abs(wref).max()
     assert np.abs(u - wref[:nvg]).max() <= 1e-7 * scale
     assert np.abs(p - wref[nvg:]).max() <= 1e-7 * scale
+
+
+def test_empty_end_slabs_join_the_collectives(tmp_path):
+    """BASELINE configs[4] in miniature: the unit sphere in a box four slabs tall.  Ranks 0
+    and 3 own no active DoF (their slab + ghost layers do not touch the sphere); they must run the same
+    collectives with zero contributions and empty halos, and the two middle ranks must reproduce the
+    single-mesh solution."""
+    n, world = 6, 4
+    port = free_port()
+    mp.spawn(worker, args=(world, n, port, str(tmp_path), True), nprocs=world, join=True)
+    x, topo, cv, A, b, act = assemble_local(n, world, 0, n * world, sphere=True)
+    wref = OA.solve_direct(A, b, act)
+    nvg = topo.nv
+    u = np.zeros(nvg)
+    owned = []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        u[d["gid"]] = d["u"]
+        owned.append(int(d["n_owned"]))
+        assert d["relres"] <= 1e-11 and d["it"] > 0    # every rank saw the same (all-reduced) residual
+    assert owned[0] == 0 and owned[3] == 0 and owned[1] > 0 and owned[2] > 0
+    assert sum(owned) == int(act.sum())
+    assert np.abs(u - wref[:nvg]).max() <= 1e-7 * np.abs(wref).max()
 
 
 def test_slab_layout_covers_the_box():

@@ -243,7 +243,7 @@ def test_native_rccl_loop_world1(P):
     ds = DistributedSolver(be, None, torch, 0, 1, (prob.n + 1) ** 2, lay["k0"], lay["P0"], lay["P1"],
                            lay["k1"] - lay["k0"] + 1, rtol=1e-10)
     out = torch.zeros_like(native)
-    st = (C.c_double * 6)()
+    st = (C.c_double * 8)()
     peers, counts, idx = (C.c_int * 1)(), (C.c_int64 * 1)(), (C.c_void_p * 1)()
     L.check(L.lib.phx_solve_distributed(be.sys, comm, 0, peers, counts, idx, 1e-10, 20000,
                                         C.c_void_p(out.data_ptr()), L.DEVICE, st))

@@ -145,3 +145,151 @@ def test_elasticity_slabs_match_single_mesh(world, tmp_path):
         assert d["relres"] <= 1e-11
     assert not np.any(np.isnan(got)) and n_owned == info["n_active"]
     assert np.abs(got - wref).max() <= 1e-6 * np.abs(wref).max()
+
+
+# ---------------------------------------------------------------------------------------------------
+# The NATIVE loop (phx_solve_distributed: pack kernel -> ncclSend/ncclRecv group -> unpack kernel,
+# ncclAllReduce of the batched dot products, collective preconditioner vote) with more than one rank.
+# RCCL refuses two ranks per device and the test box has one GPU, so the nine RCCL entry points the library
+# binds with dlopen are served by the host-staged stand-in of tests/fake_rccl (PHX_RCCL_LIB).
+# ---------------------------------------------------------------------------------------------------
+_FAKE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfake_rccl.so")
+
+
+def _worker_native(rank, world, n, nxy, port, outdir, native):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PHIFEM_NATIVE_LOOP"] = "1" if native else "0"
+    os.environ["PHX_RCCL_LIB"] = _FAKE
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from phifem_amd.distributed import SlabProblem
+        prob = SlabProblem(n, rank=rank, world=world, device=0, rtol=1e-11, nxy=nxy)
+        prob.setup()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = prob.step()
+        lay = prob.lay
+        nx = prob.nxy
+        plane = (nx + 1) * (nx + 1)
+        nv = prob.mesh.nv
+        w = prob.out.cpu().numpy()
+        vplane = np.arange(nv) // plane + lay["k0"]
+        owned = (vplane >= lay["P0"]) & (vplane < lay["P1"])
+        gid = np.arange(nv) + lay["k0"] * plane
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), gid=gid[owned], u=w[:nv][owned],
+                 p=w[nv:][owned], it=res["iterations"], relres=res["relres"],
+                 n_owned=res["n_active_owned"], path=prob.dk.path, converged=res["converged"],
+                 precond=res["precond"])
+    finally:
+        dist.destroy_process_group()
+
+
+def _single_mesh(n, world, nxy=None):
+    import phifem_amd as P
+    from phifem_amd.mesh_scripts import NodalFunction
+    nx = nxy or n
+    zext = 1.5 * world * n / nx if nxy else 1.5 * world
+    mesh = P.create_box([-1.5, -1.5, -zext], [1.5, 1.5, zext], [nx, nx, n * world])
+    x = mesh.x
+    cyl = 0.0 if nxy else 1.5 * (world - 1)
+    dz = np.maximum(np.abs(x[:, 2]) - cyl, 0.0)
+    phi = x[:, 0] ** 2 + x[:, 1] ** 2 + dz ** 2 - 1.0
+    uex = np.sin(x[:, 0]) * np.sin(x[:, 1]) * np.sin(x[:, 2])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        P.compute_tags_measures(mesh, NodalFunction(phi), 1, box_mode=True, single_layer_cut=True)
+    s = P.PhiFEMSolver(mesh)
+    info = s.assemble(phi, 3.0 * uex, uex)
+    return mesh, info, s.solve(rtol=1e-11), s.stats
+
+
+def _collect(tmp_path, world, nvg):
+    u = np.full(nvg, np.nan)
+    p = np.full(nvg, np.nan)
+    rows = []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        assert np.all(np.isnan(u[d["gid"]]))
+        u[d["gid"]] = d["u"]
+        p[d["gid"]] = d["p"]
+        rows.append(d)
+    assert not np.any(np.isnan(u))
+    return u, p, rows
+
+
+@pytest.mark.skipif(not os.path.exists(_FAKE), reason="tests/fake_rccl/libfake_rccl.so not built (build())")
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_loop_multi_rank_matches_single_mesh(world, tmp_path):
+    import torch.multiprocessing as mp
+    n = 20
+    mp.spawn(_worker_native, args=(world, n, None, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    mesh, info, wref, st = _single_mesh(n, world)
+    u, p, rows = _collect(tmp_path, world, mesh.nv)
+    assert all(str(d["path"]) == "native" for d in rows), "the library's own loop did not run"
+    assert all(bool(d["converged"]) and d["relres"] <= 1e-11 for d in rows)
+    assert len({int(d["it"]) for d in rows}) == 1, "ranks stopped at different iterations"
+    assert all(str(d["precond"]) == "box-dst" for d in rows)
+    assert sum(int(d["n_owned"]) for d in rows) == info["n_active"]
+    scale = np.abs(wref).max()
+    assert np.abs(u - wref[:mesh.nv]).max() <= 1e-7 * scale
+    assert np.abs(p - wref[mesh.nv:]).max() <= 1e-7 * scale
+
+
+@pytest.mark.skipif(not os.path.exists(_FAKE), reason="tests/fake_rccl/libfake_rccl.so not built (build())")
+@pytest.mark.parametrize("native", [False, True])
+def test_empty_end_slabs_on_the_gpu(native, tmp_path):
+    """BASELINE configs[4] in miniature: unit sphere, four slabs, ranks 0 and 3 do not touch
+    the domain -> empty systems (PHX_OPT_ALLOW_EMPTY) that still join every collective, in the Python-driven
+    and in the native loop."""
+    import torch.multiprocessing as mp
+    world, n, nxy = 4, 10, 16
+    mp.spawn(_worker_native, args=(world, n, nxy, _free_port(), str(tmp_path), native), nprocs=world, join=True)
+    mesh, info, wref, st = _single_mesh(n, world, nxy)
+    u, p, rows = _collect(tmp_path, world, mesh.nv)
+    owned = [int(d["n_owned"]) for d in rows]
+    assert owned[0] == 0 and owned[3] == 0 and owned[1] > 0 and owned[2] > 0
+    assert sum(owned) == info["n_active"]
+    assert all(str(d["path"]) == ("native" if native else "python") for d in rows)
+    assert all(bool(d["converged"]) for d in rows) and len({int(d["it"]) for d in rows}) == 1
+    scale = np.abs(wref).max()
+    assert np.abs(u - wref[:mesh.nv]).max() <= 1e-7 * scale
+    assert np.abs(p - wref[mesh.nv:]).max() <= 1e-7 * scale
+
+
+def _run_bench(extra_env, *args):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env,
+                          capture_output=True, text=True, timeout=900)
+
+
+def test_bench_gpus_2_launches_two_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (gloo rehearsal on the one GPU) and
+    prints ONE line that says so."""
+    import json
+    r = _run_bench({"PHIFEM_DIST_BACKEND": "gloo"}, "--gpus", "2", "--cubes", "32", "--steps", "1",
+                   "--warmup", "0", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and d["config"]["converged"]
+    assert d["config"]["parallelism"] == "slab2" and d["scaling"] == "weak" and d["value"] > 0
+
+
+def test_bench_rccl_on_one_device_fails_loudly():
+    """Two RCCL ranks need two GPUs: on the one-GPU box the run must fail, not report n_gpus = 1."""
+    r = _run_bench({"PHIFEM_DIST_BACKEND": "nccl"}, "--gpus", "2", "--cubes", "32", "--steps", "1",
+                   "--warmup", "0", "--no-cpu-baseline")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "need 2 GPUs" in r.stderr
