@@ -345,7 +345,10 @@ struct BoxGrid {
   int64_t pitch, plane;
   double scale;      // (2/Lx)(2/Ly)(2/Lz): the three inverse transforms
   const double *lam[3];  // c_a (2 - 2 cos(pi k / L_a)), k = 0 .. L_a - 1 (device)
+  double c[3];       // coefficient of tridiag(-1, 2, -1) per axis
 };
+
+#include "phx_tridiag.inc.hip"
 
 // ---- x lines (contiguous): pair = two consecutive lines of the flattened (y, z) index.
 // IO = 1: the input is gathered from the Krylov vector through gmap (solver position of the u DoF at the
@@ -541,6 +544,7 @@ struct phx_box_precond {
   int64_t nrest = 0;
   double *lam[3] = {nullptr, nullptr, nullptr};
   int lo[3] = {0, 0, 0};     // lattice index of the lower Dirichlet face
+  bool ztri = true;          // z direction: tridiagonal solve (default) or forward / inverse sine transform in LDS
 };
 
 static void box_precond_free(phx_box_precond *bp) {
@@ -577,9 +581,11 @@ static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const
   bp->f32 = f32;
   PHX_CHECK(dst_allow_lds());
   BoxGrid &g = bp->g;
+  if (const char *e = getenv("PHX_Z_TRIDIAG")) bp->ztri = atoi(e) != 0;  // A/B aid: 0 = sine transforms in z
   for (int a = 0; a < 3; ++a) {
     g.L[a] = L[a];
     g.m[a] = L[a] - 1;
+    g.c[a] = c[a];
     PHX_CHECK(dst_get_plan(device, L[a], f32, &bp->plan[a]));
   }
   g.pitch = L[0];
@@ -597,19 +603,40 @@ static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const
   return PHX_OK;
 }
 
-// the three middle passes (y, z with the spectral solve, y) on G
+// z pass on G: tridiagonal solve per (kx, ky) column, or forward sine transform, 1 / lambda, inverse in LDS
+template <typename T>
+static int box_pass_z_t(phx_box_precond *bp, hipStream_t st) {
+  const BoxGrid &g = bp->g;
+  T *G = static_cast<T *>(bp->G);
+  if (bp->ztri) {
+    TriArgs a;
+    memset(&a, 0, sizeof(a));
+    a.m0 = g.m[0]; a.m1 = g.m[1]; a.pitch = (int)g.pitch; a.plane = g.plane;
+    a.nloc = g.m[2]; a.k0 = 1; a.N = g.m[2];
+    a.cz = g.c[2]; a.scale_xy = (2.0 / g.L[0]) * (2.0 / g.L[1]);
+    a.lamx = g.lam[0]; a.lamy = g.lam[1];
+    return tri_launch<T, 0>(a, G, st);
+  }
+  const DstPlan &pz = bp->plan[2];
+  const int W = 2 * pz.pairs, ncb = (g.m[0] + W - 1) / W;
+  const dim3 grid((unsigned)((int64_t)ncb * g.m[1])), block((unsigned)(pz.pairs * pz.slot));
+  const size_t lds = (size_t)pz.lds_elems * sizeof(T) * 2;
+  if (pz.wave) k_dst_s<T, 2, true, true><<<grid, block, lds, st>>>(g, pz, G);
+  else k_dst_s<T, 2, true, false><<<grid, block, lds, st>>>(g, pz, G);
+  PHX_HIP(hipGetLastError());
+  return PHX_OK;
+}
+
+// the three middle passes (y, z solve, y) on G
 template <typename T>
 static int box_solve_middle_t(phx_box_precond *bp, hipStream_t st, phx_system *prof) {
   const BoxGrid &g = bp->g;
-  const DstPlan &py = bp->plan[1], &pz = bp->plan[2];
+  const DstPlan &py = bp->plan[1];
   T *G = static_cast<T *>(bp->G);
   const size_t el = sizeof(T) * 2;  // LDS bytes per complex value
   for (int pass = 0; pass < 3; ++pass) {
     if (pass == 1) {
-      const int W = 2 * pz.pairs, ncb = (g.m[0] + W - 1) / W;
-      const dim3 grid((unsigned)((int64_t)ncb * g.m[1])), block((unsigned)(pz.pairs * pz.slot));
-      if (pz.wave) k_dst_s<T, 2, true, true><<<grid, block, (size_t)pz.lds_elems * el, st>>>(g, pz, G);
-      else k_dst_s<T, 2, true, false><<<grid, block, (size_t)pz.lds_elems * el, st>>>(g, pz, G);
+      PHX_CHECK(box_pass_z_t<T>(bp, st));
     } else {
       const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
       const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.slot));
@@ -943,20 +970,17 @@ extern "C" int phx_box_dst_bench(int device, const int *L, int f32, int reps, do
   for (int which = 0; which < 3 && rc == PHX_OK; ++which) {
     auto run = [&]() -> int {
       if (which == 0) return box_pass_x<0>(bp, st, nullptr, nullptr);
-      const DstPlan &P = bp->plan[which];
+      if (which == 2) return f32 ? box_pass_z_t<float>(bp, st) : box_pass_z_t<double>(bp, st);
+      const DstPlan &P = bp->plan[1];
       const int W = 2 * P.pairs, ncb = (g.m[0] + W - 1) / W;
-      const dim3 grid((unsigned)((int64_t)ncb * g.m[which == 1 ? 2 : 1])), block((unsigned)(P.pairs * P.slot));
+      const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(P.pairs * P.slot));
       const size_t lds = (size_t)P.lds_elems * (f32 ? sizeof(float2) : sizeof(double2));
       if (f32) {
-        if (which == 1 && P.wave) k_dst_s<float, 1, false, true><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
-        else if (which == 1) k_dst_s<float, 1, false, false><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
-        else if (P.wave) k_dst_s<float, 2, true, true><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
-        else k_dst_s<float, 2, true, false><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
+        if (P.wave) k_dst_s<float, 1, false, true><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
+        else k_dst_s<float, 1, false, false><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
       } else {
-        if (which == 1 && P.wave) k_dst_s<double, 1, false, true><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
-        else if (which == 1) k_dst_s<double, 1, false, false><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
-        else if (P.wave) k_dst_s<double, 2, true, true><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
-        else k_dst_s<double, 2, true, false><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
+        if (P.wave) k_dst_s<double, 1, false, true><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
+        else k_dst_s<double, 1, false, false><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
       }
       return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_HIP;
     };
