@@ -139,6 +139,15 @@ enum phx_option {
                                faster per application, but the half-length sine transform amplifies rounding
                                by O(L) and BiCGStab is not a flexible method: erratic on some problems
                                (2-D flower: 100-580 iterations against 38); 0: Jacobi everywhere          */
+  PHX_OPT_EXPORT_CSR = 7, /* 1: systems assembled from now on ALSO keep the CSR copy phx_system_export
+                               hands out (sorted columns, dolfinx sparsity pattern with its explicit zeros).
+                               Default 0: the solver formats are built straight from the row slots and the CSR
+                               is never formed for P1 weak-Dirichlet systems on Kuhn boxes -- export then
+                               returns PHX_ERR_VALUE and the host re-assembles with this option set         */
+  PHX_OPT_STRUCTURED = 8, /* 1 (default): P1 weak-Dirichlet systems on Kuhn boxes apply their
+                               translation-invariant interior rows from a 7-point stencil over runs of
+                               consecutive rows (no stored columns or values); only the rows near Gamma_h keep
+                               SELL storage.  0: every row stored (SELL), as for all other systems           */
   PHX_OPT_ALLOW_EMPTY = 6, /* 1: phx_assemble_poisson_wd returns an EMPTY system (n_active = 0) when no cell
                                is tagged 1 / 2 instead of PHX_ERR_VALUE: a slab of a partitioned box that
                                does not touch the domain still joins every collective of the solve          */
@@ -243,10 +252,11 @@ int phx_assemble_elasticity_if(phx_mesh *m, const double *params, const double *
                                const double *f_h, const double *u_D, const int32_t *bc_vertices,
                                int64_t nbc, int loc, phx_system **out);
 int phx_system_destroy(phx_system *s);
-/* info[11] = {n_active, n_active_u, nnz (structural, CSR), n_full (= 2*nv), sell_padded_nnz,
+/* info[13] = {n_active, n_active_u, nnz (structural, CSR), n_full (= 2*nv), sell_padded_nnz,
  *             slot_capacity, sell_nnz (explicit zeros dropped), n_slices, value-indexed slices,
  *             matrix bytes one SpMV of the solve streams (columns + value stream + slice table),
- *             value-indexed slices whose dictionary exceeds 64 entries (LDS look-up)} */
+ *             value-indexed slices whose dictionary exceeds 64 entries (LDS look-up),
+ *             rows applied from the stencil (structured systems, else 0), stencil runs} */
 int phx_system_info(const phx_system *s, int64_t *info);
 /* CSR of the active system in ORIGINAL active numbering (sorted columns) + the map active row ->
  * full DoF index; host buffers: rowptr[n_active+1], col[nnz], val[nnz], rhs[n_active],

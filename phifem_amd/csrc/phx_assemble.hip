@@ -182,6 +182,12 @@ struct AsmArgs {
   double gamma, sigma;
   double *rhs;
   Slots slots;
+  // structured systems (phx_common.h): rows of C0 are not stored -- the row kernel leaves their diagonal in
+  // `diag`, one of them the stencil coefficients in `stencil`; store_c0 != 0 (PHX_OPT_EXPORT_CSR) stores them too
+  const uint8_t *c0 = nullptr;
+  double *diag = nullptr;
+  double *stencil = nullptr;
+  int store_c0 = 1;
 };
 
 // (1/|K|) int N_i N_j N_k N_l = D! alpha! / (D+4)!
@@ -314,6 +320,54 @@ k_assemble_rows(int64_t nv, const int64_t *__restrict__ v2c_ptr, const int32_t *
 // coordinate-based evaluation by a few ulp).
 struct BoxDims { int64_t n[3]; double h[3]; };
 
+// C0: active vertices strictly inside the box that no scattering kernel touches and whose whole star (24 tets,
+// 2-D: 6 triangles) is tagged inside.  Their rows are the translation-invariant lattice Laplacian row.
+template <int D>
+__global__ void __launch_bounds__(256)
+k_mark_c0(int64_t nv, BoxDims bd, const int32_t *__restrict__ du, const int8_t *__restrict__ ctags,
+          const uint8_t *__restrict__ touched, uint8_t *__restrict__ c0) {
+  constexpr int N = D + 1, NPERM = D == 3 ? 6 : 2;
+  constexpr int P[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+  constexpr int P2[2][3] = {{0, 1, 0}, {1, 0, 0}};
+  const int64_t vtx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (vtx >= nv) return;
+  const int32_t row = du[vtx];
+  if (row < 0) return;
+  const int64_t n0 = bd.n[0] + 1, n1 = bd.n[1] + 1;
+  const int64_t idx[3] = {vtx % n0, D == 3 ? (vtx / n0) % n1 : vtx / n0, D == 3 ? vtx / (n0 * n1) : 0};
+  const int64_t cstride[3] = {1, bd.n[0], bd.n[0] * bd.n[1]};
+  bool ok = !touched[vtx];
+  for (int a = 0; a < D; ++a) ok = ok && idx[a] >= 1 && idx[a] <= bd.n[a] - 1;
+  if (ok) {
+#pragma unroll
+    for (int t = 0; t < NPERM; ++t) {
+#pragma unroll
+      for (int m = 0; m < N; ++m) {
+        int dd[3] = {0, 0, 0};
+        for (int q = 0; q < m; ++q) dd[D == 3 ? P[t][q] : P2[t][q]] -= 1;
+        int64_t cube = 0;
+        for (int a = 0; a < D; ++a) cube += (idx[a] + dd[a]) * cstride[a];
+        ok = ok && (ctags[cube * NPERM + t] & PHX_TAG_MASK) == 1;
+      }
+    }
+  }
+  c0[row] = ok ? 1 : 0;
+}
+
+__global__ void k_not_flags(int64_t n, const uint8_t *__restrict__ in, uint8_t *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i] ? 0 : 1;
+}
+
+// slot offsets of the rows that are stored: rank[row] = number of stored rows before it (exclusive scan of 1 - c0)
+__global__ void k_slot_offsets(int64_t n, int W, int wl, const uint8_t *__restrict__ c0, const int32_t *__restrict__ rank,
+                               int64_t *__restrict__ off, uint8_t *__restrict__ wlog) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  off[r] = c0[r] ? 0 : (int64_t)rank[r] * W;   // a C0 row is never written: any in-range offset
+  wlog[r] = (uint8_t)wl;
+}
+
 template <int D>
 __global__ void __launch_bounds__(256)
 k_assemble_rows_box(int64_t nv, BoxDims bd, AsmArgs A) {
@@ -393,9 +447,26 @@ k_assemble_rows_box(int64_t nv, BoxDims bd, AsmArgs A) {
     }
   }
   A.rhs[row] = rhs;
+  if (A.c0 && A.c0[row]) {
+    // translation-invariant interior row: applied from the stencil, not stored (unless the CSR is exported)
+    A.diag[row] = acc[SELF];
+    // one C0 row leaves the stencil coefficients (all C0 rows hold the same bits).  The plain load first: 2.4e6
+    // rows hammering one address with atomics cost 27 ms at 256^3
+    unsigned long long *claim = reinterpret_cast<unsigned long long *>(A.stencil + 4);
+    if (__hip_atomic_load(claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull &&
+        atomicCAS(claim, 0ull, 1ull) == 0ull) {
+      A.stencil[0] = acc[SELF];
+      A.stencil[1] = acc[SELF + 1];
+      A.stencil[2] = acc[SELF + 3];
+      A.stencil[3] = D == 3 ? acc[SELF + 9] : 0.0;
+    }
+    if (!A.store_c0) return;
+  }
   // a row no scattering kernel will touch is stored densely and already sorted (codes ascend with the
   // vertex index, hence with the column): it skips the hash table and the sort of the compaction
   const bool clean = A.slots.clean && A.touched && !A.touched[vtx];
+  int slotW;
+  const int64_t sbase = slot_base(A.slots, row, &slotW);
   int cnt = 0;
 #pragma unroll
   for (int code = 0; code < NCODE; ++code) {
@@ -404,8 +475,8 @@ k_assemble_rows_box(int64_t nv, BoxDims bd, AsmArgs A) {
     w += (code % 3 - 1) * vstride[0] + ((code / 3) % 3 - 1) * vstride[1];
     if (D == 3) w += (code / 9 - 1) * vstride[2];
     if (clean) {
-      A.slots.cols[(int64_t)row * A.slots.W + cnt] = (int32_t)w;
-      A.slots.vals[(int64_t)row * A.slots.W + cnt] = acc[code];
+      A.slots.cols[sbase + cnt] = (int32_t)w;
+      A.slots.vals[sbase + cnt] = acc[code];
       ++cnt;
     } else {
       slot_add_owned(A.slots, row, (int32_t)w, acc[code]);
@@ -844,7 +915,8 @@ extern "C" int phx_system_destroy(phx_system *s) {
   (void)hipDeviceSynchronize();
   void *ptrs[] = {s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active, s->rowptr, s->col,
                   s->val, s->rhs, s->diag, s->slice_ptr, s->sell_col, s->sell_val,
-                  s->sell_val_raw, s->sell_kind, s->perm, s->iperm, s->work, s->scal, s->row_nz};
+                  s->sell_val_raw, s->sell_kind, s->perm, s->iperm, s->work, s->scal, s->row_nz,
+                  s->c0, s->stencil, s->seg, s->slice_seg, s->sell_rows, s->cscale, s->pvec};
   for (void *p : ptrs) (void)phx_free(p);
   phx_box_precond_destroy(s->precond);
   if (s->scal_h) (void)hipHostFree(s->scal_h);
@@ -853,20 +925,50 @@ extern "C" int phx_system_destroy(phx_system *s) {
   return PHX_OK;
 }
 
-// overflow check -> compaction of the slot tables into CSR (sorted columns) -> SELL
-int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
-  phx_mesh *m = s->mesh;
-  const int W = sl.W;
-  const dim3 block(256);
+static int free_slots(Slots &sl) {
+  PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow)); PHX_HIP(phx_free(sl.clean));
+  PHX_HIP(phx_free((void *)sl.off)); PHX_HIP(phx_free((void *)sl.wlog));
+  sl.cols = nullptr; sl.vals = nullptr; sl.overflow = nullptr; sl.clean = nullptr; sl.off = nullptr; sl.wlog = nullptr;
+  return PHX_OK;
+}
+
+static int check_overflow(phx_mesh *m, Slots &sl) {
   int overflow = 0;
   PHX_HIP(hipMemcpyAsync(&overflow, sl.overflow, sizeof(int), hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
   if (overflow) {
-    PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow)); PHX_HIP(phx_free(sl.clean));
-    PHX_HIP(phx_free((void *)sl.off)); PHX_HIP(phx_free((void *)sl.wlog));
-    phx_set_error("row-slot capacity %d exceeded", W);
+    PHX_CHECK(free_slots(sl));
+    phx_set_error("row-slot capacity %d exceeded", sl.W);
     return PHX_ERR_CAPACITY;
   }
+  return PHX_OK;
+}
+
+static int csr_from_slots(phx_system *s, Slots &sl, int32_t nent);
+
+// overflow check -> compaction of the slot tables into CSR (sorted columns) -> SELL
+int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
+  PHX_CHECK(check_overflow(s->mesh, sl));
+  PHX_CHECK(csr_from_slots(s, sl, nent));
+  PHX_CHECK(free_slots(sl));
+  return phx_system_build_sell(s);
+}
+
+// Structured systems: the solver formats come straight from the slots (stencil segments + SELL over the stored
+// rows); the CSR copy only when PHX_OPT_EXPORT_CSR asks for it (then every row, C0 included, sits in the slots).
+static int finish_structured(phx_system *s, Slots &sl, int32_t nent, bool with_csr) {
+  PHX_CHECK(check_overflow(s->mesh, sl));
+  if (with_csr) PHX_CHECK(csr_from_slots(s, sl, nent));
+  const phx_slot_view sv{sl.cols, sl.vals, sl.W, sl.clean, sl.off, sl.wlog};
+  const int rc = phx_system_build_structured(s, sv, nent);
+  PHX_CHECK(free_slots(sl));
+  return rc;
+}
+
+static int csr_from_slots(phx_system *s, Slots &sl, int32_t nent) {
+  phx_mesh *m = s->mesh;
+  const int W = sl.W;
+  const dim3 block(256);
   int64_t *counts = nullptr;
   PHX_HIP(phx_malloc(&counts, sizeof(int64_t) * (size_t)(s->n + 1)));
   PHX_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (size_t)(s->n + 1), m->stream));
@@ -881,8 +983,10 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   s->nnz = nnz;
   PHX_HIP(phx_malloc(&s->col, sizeof(int32_t) * (size_t)nnz));
   PHX_HIP(phx_malloc(&s->val, sizeof(double) * (size_t)nnz));
-  PHX_HIP(phx_malloc(&s->diag, sizeof(double) * (size_t)s->n));
-  PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
+  if (!s->diag) {
+    PHX_HIP(phx_malloc(&s->diag, sizeof(double) * (size_t)s->n));
+    PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
+  }
   if (W <= 64 || sl.off) PHX_HIP(phx_malloc(&s->row_nz, sizeof(int32_t) * (size_t)s->n));
   if (sl.off) {
     // per-row capacities: narrow rows one wave each, the wide ones (list) one block of W threads each
@@ -928,9 +1032,7 @@ int phx_finish_system(phx_system *s, Slots &sl, int32_t nent) {
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(counts));
-  PHX_HIP(phx_free(sl.cols)); PHX_HIP(phx_free(sl.vals)); PHX_HIP(phx_free(sl.overflow)); PHX_HIP(phx_free(sl.clean));
-  PHX_HIP(phx_free((void *)sl.off)); PHX_HIP(phx_free((void *)sl.wlog));
-  return phx_system_build_sell(s);
+  return PHX_OK;
 }
 
 static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef,
@@ -989,28 +1091,24 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
       m->nv, fu, fp, su, sp, nu, s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active);
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(fu)); PHX_HIP(phx_free(fp)); PHX_HIP(phx_free(su)); PHX_HIP(phx_free(sp));
-  // ---- slots
+  // ---- element kernels run over compacted work lists
+  int32_t *l_cut = nullptr, *l_fac = nullptr;
+  int64_t n_cut = 0, n_fac = 0;
+  PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut));
+  PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac));
   Slots sl;
   sl.W = W;
-  PHX_HIP(phx_malloc(&sl.cols, sizeof(int32_t) * (size_t)s->n * W));
-  PHX_HIP(phx_malloc(&sl.vals, sizeof(double) * (size_t)s->n * W));
-  PHX_HIP(phx_malloc(&sl.overflow, sizeof(int)));
-  PHX_HIP(hipMemsetAsync(sl.cols, 0xff, sizeof(int32_t) * (size_t)s->n * W, m->stream));
-  PHX_HIP(hipMemsetAsync(sl.vals, 0, sizeof(double) * (size_t)s->n * W, m->stream));
-  PHX_HIP(hipMemsetAsync(sl.overflow, 0, sizeof(int), m->stream));
+  sl.cols = nullptr; sl.vals = nullptr; sl.overflow = nullptr;
   PHX_HIP(phx_malloc(&s->rhs, sizeof(double) * (size_t)s->n));
   PHX_HIP(hipMemsetAsync(s->rhs, 0, sizeof(double) * (size_t)s->n, m->stream));
   AsmArgs A;
   A.cells = m->cells; A.x = m->x; A.ctags = m->cell_tags; A.ftags = m->facet_tags;
   A.c2f = m->c2f; A.f2c = m->f2c; A.du = s->dof_of_vertex_u; A.dp = s->dof_of_vertex_p;
   A.phi = dphi; A.f = df; A.ud = dud; A.gamma = pen_coef; A.sigma = stab_coef;
-  A.rhs = s->rhs; A.slots = sl; A.nv = (int32_t)m->nv;
-  // ---- element kernels over compacted work lists
-  int32_t *l_cut = nullptr, *l_fac = nullptr;
-  int64_t n_cut = 0, n_fac = 0;
-  PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut));
-  PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac));
+  A.rhs = s->rhs; A.nv = (int32_t)m->nv;
   uint8_t *touched = nullptr;
+  const bool structured = m->is_box && !m->is_submesh && m->structured != 0;
+  int64_t slot_rows = s->n;
   if (m->is_box && !m->is_submesh) {
     // rows of vertices no scattering kernel reaches are written dense and sorted by the gather kernel
     PHX_CHECK(phx_collect_entities(m));
@@ -1035,8 +1133,57 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
       else k_mark_entity_cells<4><<<g, dim3(TB), 0, m->stream>>>(m->ent_count[0], m->ent_buf[0], m->cells, touched);
     }
     A.touched = touched;
-    A.slots = sl;
   }
+  if (structured) {
+    // C0 rows (translation-invariant interior rows) are applied from a stencil: no slots, no stored entries
+    s->structured = true;
+    s->u_unscaled = true;
+    PHX_HIP(phx_malloc(&s->c0, (size_t)s->n));
+    PHX_HIP(phx_malloc(&s->diag, sizeof(double) * (size_t)s->n));
+    PHX_HIP(phx_malloc(&s->stencil, sizeof(double) * 8));
+    PHX_HIP(hipMemsetAsync(s->c0, 0, (size_t)s->n, m->stream));
+    PHX_HIP(hipMemsetAsync(s->diag, 0, sizeof(double) * (size_t)s->n, m->stream));
+    PHX_HIP(hipMemsetAsync(s->stencil, 0, sizeof(double) * 8, m->stream));
+    const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}, {m->box_h[0], m->box_h[1], m->box_h[2]}};
+    const dim3 g((unsigned)phx_div_up(m->nv, 256));
+    if (D == 2) k_mark_c0<2><<<g, block, 0, m->stream>>>(m->nv, bd, s->dof_of_vertex_u, m->cell_tags, touched, s->c0);
+    else k_mark_c0<3><<<g, block, 0, m->stream>>>(m->nv, bd, s->dof_of_vertex_u, m->cell_tags, touched, s->c0);
+    A.c0 = s->c0; A.diag = s->diag; A.stencil = s->stencil;
+    A.store_c0 = m->export_csr ? 1 : 0;
+    if (!m->export_csr) {
+      // only the stored rows get slots: offsets from the rank among the non-C0 rows
+      int32_t *rank = nullptr, nstored_before_last = 0;
+      uint8_t *notc0 = nullptr;
+      PHX_HIP(phx_malloc(&rank, sizeof(int32_t) * (size_t)s->n));
+      PHX_HIP(phx_malloc(&notc0, (size_t)s->n));
+      k_not_flags<<<dim3((unsigned)phx_div_up(s->n, 256)), block, 0, m->stream>>>(s->n, s->c0, notc0);
+      int32_t nstored = 0;
+      PHX_CHECK(scan_flags(m, notc0, rank, s->n, &nstored));
+      (void)nstored_before_last;
+      slot_rows = nstored;
+      int64_t *off = nullptr;
+      uint8_t *wl = nullptr;
+      PHX_HIP(phx_malloc(&off, sizeof(int64_t) * (size_t)s->n));
+      PHX_HIP(phx_malloc(&wl, (size_t)s->n));
+      int lg = 0;
+      while ((1 << lg) < W) ++lg;
+      k_slot_offsets<<<dim3((unsigned)phx_div_up(s->n, 256)), block, 0, m->stream>>>(s->n, W, lg, s->c0, rank, off, wl);
+      sl.off = off; sl.wlog = wl;
+      PHX_HIP(hipStreamSynchronize(m->stream));
+      PHX_HIP(phx_free(rank)); PHX_HIP(phx_free(notc0));
+    }
+  }
+  // ---- slots (of the stored rows)
+  {
+    const size_t ns = (size_t)std::max<int64_t>(slot_rows, 1) * W;
+    PHX_HIP(phx_malloc(&sl.cols, sizeof(int32_t) * ns));
+    PHX_HIP(phx_malloc(&sl.vals, sizeof(double) * ns));
+    PHX_HIP(phx_malloc(&sl.overflow, sizeof(int)));
+    PHX_HIP(hipMemsetAsync(sl.cols, 0xff, sizeof(int32_t) * ns, m->stream));
+    PHX_HIP(hipMemsetAsync(sl.vals, 0, sizeof(double) * ns, m->stream));
+    PHX_HIP(hipMemsetAsync(sl.overflow, 0, sizeof(int), m->stream));
+  }
+  A.slots = sl;
   {
     if (m->is_box) {
       const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}, {m->box_h[0], m->box_h[1], m->box_h[2]}};
@@ -1085,7 +1232,8 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_fac));
   if (touched) PHX_HIP(phx_free(touched));
   {
-    const int rc = phx_finish_system(s, sl, (int32_t)m->nv);
+    const int rc = structured ? finish_structured(s, sl, (int32_t)m->nv, m->export_csr != 0)
+                              : phx_finish_system(s, sl, (int32_t)m->nv);
     if (rc != PHX_OK) { phx_system_destroy(s); return rc; }
   }
   *out = s;
@@ -1152,6 +1300,7 @@ extern "C" int phx_system_info(const phx_system *s, int64_t *info) {
   info[0] = s->n; info[1] = s->nu; info[2] = s->nnz; info[3] = s->nfull;
   info[4] = s->sell_nnz; info[5] = s->slot_cap; info[6] = s->sell_true_nnz; info[7] = s->nslices;
   info[8] = s->sell_indexed_slices; info[9] = s->sell_stream_bytes; info[10] = s->sell_indexed_large;
+  info[11] = s->nc0; info[12] = s->nseg;
   return PHX_OK;
 }
 
@@ -1168,6 +1317,8 @@ extern "C" int phx_system_get_perm(phx_system *s, int32_t *perm, int32_t *dof_u,
 extern "C" int phx_system_export(phx_system *s, int64_t *rowptr, int32_t *col, double *val,
                                  double *rhs, int64_t *dof) {
   PHX_HIP(hipSetDevice(s->mesh->device));
+  PHX_REQUIRE(s->rowptr != nullptr || (!rowptr && !col && !val), PHX_ERR_VALUE,
+              "this system was assembled without its CSR copy: set PHX_OPT_EXPORT_CSR before assembling");
   if (rowptr) PHX_HIP(hipMemcpy(rowptr, s->rowptr, sizeof(int64_t) * (size_t)(s->n + 1), hipMemcpyDeviceToHost));
   if (col) PHX_HIP(hipMemcpy(col, s->col, sizeof(int32_t) * (size_t)s->nnz, hipMemcpyDeviceToHost));
   if (val) PHX_HIP(hipMemcpy(val, s->val, sizeof(double) * (size_t)s->nnz, hipMemcpyDeviceToHost));

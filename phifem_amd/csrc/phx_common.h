@@ -119,6 +119,8 @@ struct phx_mesh {
   int spmv_value_index = 1;        // PHX_OPT_SPMV_VALUE_INDEX
   int precond = 1;                 // PHX_OPT_PRECOND: 0 Jacobi, 1 / 2 box sine transforms in f64 / f32 where applicable
   int has_exterior_override = -1;  // -1: decide from the local tags; 0/1: imposed (multi-GPU)
+  int export_csr = 0;              // PHX_OPT_EXPORT_CSR: assembly also builds the CSR copy phx_system_export reads
+  int structured = 1;              // PHX_OPT_STRUCTURED: stencil-coded interior rows on Kuhn boxes (P1 weak Dirichlet)
   int allow_empty = 0;             // PHX_OPT_ALLOW_EMPTY: assembly returns an EMPTY system when no cell is tagged 1 / 2
 };
 
@@ -163,6 +165,24 @@ struct phx_system {
   struct phx_box_precond *precond = nullptr;
   int precond_state = 0;           // 0 not tried, 1 built, -1 not applicable
   bool precond_veto = false;       // multi-GPU vote: this rank cannot run the box preconditioner although it has u rows
+  // --- structured systems (P1 weak-Dirichlet on a Kuhn box).  C0 = rows of vertices interior to the box, untouched
+  // by the scattering kernels, whose whole star is tagged inside: the translation-invariant 7-point (2-D: 5-point)
+  // row.  Solver order: C0 rows in lattice order, then the other u rows, then the p rows.  C0 rows whose axis
+  // neighbours are C0 rows too are APPLIED from `stencil` over runs of consecutive positions of one x line
+  // (`seg`), never stored; all other rows sit in a SELL-16 copy over a row list (`sell_rows`).
+  bool structured = false;
+  bool u_unscaled = false;         // columns of u DoFs carry A (the u preconditioner is K_box^-1 or D_u^-1), p columns A D^-1
+  uint8_t *c0 = nullptr;           // [n] 1: row applied by the stencil kernel
+  int64_t nc0 = 0;                 // rows the stencil applies
+  int64_t nstencil_pos = 0;        // solver positions [0, nstencil_pos) hold the C0 rows (the stencil slices cover them)
+  double *stencil = nullptr;       // device [8]: {diag, x, y, z off-diagonal entries} of a C0 row, [4] = claimed flag
+  int32_t *seg = nullptr;          // [nseg][6] {first row, end row, offset of the +y, -y, +z, -z neighbour rows}
+  int32_t nseg = 0;
+  int32_t *slice_seg = nullptr;    // [ceil(nu / 64)][16] slice records: {runs in the slice, first run, two runs inline}
+  int32_t *sell_rows = nullptr;    // [nslices * 64] row held by SELL slot (slice, lane), -1: padding
+  int64_t n_sell_rows = 0;
+  double *cscale = nullptr;        // [n] x = cscale * y when the iteration ends (1 for unscaled columns, else 1 / diag)
+  double *pvec = nullptr;          // [2 n] phat / shat of the library-owned workspace when no box preconditioner holds them
   std::vector<hipEvent_t> prof_ev[2];  // event pairs of the sampled launches: [0] SpMV, [1] sine-transform y pass
   int prof_used[2] = {0, 0}, prof_seen[2] = {0, 0};
 };
@@ -174,5 +194,15 @@ int phx_end_timing(phx_mesh *m, int slot);
 int phx_mesh_build_edges(phx_mesh *m);
 
 int phx_system_build_empty(phx_system *s);  // phx_solve.hip
+// row slots of the assembly as the SELL builder of structured systems reads them (phx_assemble.hip: Slots)
+struct phx_slot_view {
+  const int32_t *cols;
+  const double *vals;
+  int W;
+  const uint8_t *clean;   // clean[row] = c > 0: the row's c entries sit at slots 0 .. c-1
+  const int64_t *off;     // per-row slot offsets (nullptr: row * W)
+  const uint8_t *wlog;
+};
+int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t nent);  // phx_solve.hip
 struct phx_box_precond;
 void phx_box_precond_destroy(phx_box_precond *bp);  // phx_solve.hip

@@ -798,6 +798,8 @@ extern "C" int phx_set_option(phx_mesh *m, int option, int64_t value) {
     case PHX_OPT_HAS_EXTERIOR: m->has_exterior_override = (int)value; return PHX_OK;
     case PHX_OPT_SPMV_VALUE_INDEX: m->spmv_value_index = value != 0; return PHX_OK;
     case PHX_OPT_ALLOW_EMPTY: m->allow_empty = value != 0; return PHX_OK;
+    case PHX_OPT_EXPORT_CSR: m->export_csr = value != 0; return PHX_OK;
+    case PHX_OPT_STRUCTURED: m->structured = value != 0; return PHX_OK;
     case PHX_OPT_PRECOND:
       PHX_REQUIRE(value >= 0 && value <= 2, PHX_ERR_VALUE, "unknown preconditioner %lld", (long long)value);
       m->precond = (int)value;

@@ -433,8 +433,8 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
     double da[8], db[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      da[i] = qa[i] >= 0 ? dscale[qa[i]] : 0.0;
-      db[i] = qb[i] >= 0 ? dscale[qb[i]] : 0.0;
+      da[i] = qa[i] >= 0 ? (dscale ? dscale[qa[i]] : 1.0) : 0.0;
+      db[i] = qb[i] >= 0 ? (dscale ? dscale[qb[i]] : 1.0) : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -538,7 +538,6 @@ struct phx_box_precond {
   int32_t *gmap = nullptr;   // [plane * m2] solver position of the u DoF, -1 none
   double *dscale = nullptr;  // [n] diag of A in solver order (weighted systems: sqrt(diag A * diag K_box))
   double *iscale = nullptr;  // [n] weighted systems only: sqrt(diag K_box / diag A), applied to the input
-  double *vec = nullptr;     // [2 n] preconditioned directions of the library-owned workspace
   const uint8_t *own_ptr = nullptr;  // ownership mask the maps were built for
   int32_t *rest = nullptr;   // solver positions of the rows outside the u block (identity part of P)
   int64_t nrest = 0;
@@ -549,7 +548,7 @@ struct phx_box_precond {
 
 static void box_precond_free(phx_box_precond *bp) {
   if (!bp) return;
-  (void)phx_free(bp->G); (void)phx_free(bp->gmap); (void)phx_free(bp->dscale); (void)phx_free(bp->iscale); (void)phx_free(bp->vec);
+  (void)phx_free(bp->G); (void)phx_free(bp->gmap); (void)phx_free(bp->dscale); (void)phx_free(bp->iscale);
   (void)phx_free(bp->rest);
   for (int a = 0; a < 3; ++a) (void)phx_free(bp->lam[a]);
   delete bp;
@@ -586,7 +585,8 @@ static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const
     g.L[a] = L[a];
     g.m[a] = L[a] - 1;
     g.c[a] = c[a];
-    PHX_CHECK(dst_get_plan(device, L[a], f32, &bp->plan[a]));
+    // no transform runs along a tridiagonal z axis: its length is free (L[2] >= 2)
+    if (a < 2 || !bp->ztri) PHX_CHECK(dst_get_plan(device, L[a], f32, &bp->plan[a]));
   }
   g.pitch = L[0];
   g.plane = g.pitch * g.m[1];
@@ -850,10 +850,15 @@ static int box_precond_setup(phx_system *s) {
   PHX_HIP(phx_free(dbb));
   if (hbb[3] < 0) { s->precond_veto = false; return PHX_OK; }  // no (owned) active u DoF here: nothing to precondition
   int L[3], lo[3];
+  bool ztri = true;
+  if (const char *e = getenv("PHX_Z_TRIDIAG")) ztri = atoi(e) != 0;
   for (int a = 0; a < 3; ++a) {
     const int extent = hbb[3 + a] - hbb[a] + 1;
-    L[a] = dst_pick_length(extent + 2 * PHX_PRECOND_MARGIN + 1);
-    if (L[a] < 0) return PHX_OK;  // larger than the longest transform: stay with Jacobi
+    // z (tridiagonal solve, no transform): exactly extent + margins planes; a 2-D lattice keeps its one real plane
+    const bool free_len = a == 2 && ztri;
+    if (free_len) L[a] = m->gdim == 3 ? extent + 2 * PHX_PRECOND_MARGIN + 1 : 2;
+    else L[a] = dst_pick_length(extent + 2 * PHX_PRECOND_MARGIN + 1);
+    if (L[a] < 0 || L[a] > 1025) return PHX_OK;  // larger than the longest transform / column: stay with Jacobi
     lo[a] = hbb[a] - 1 - (L[a] - 1 - extent) / 2;
   }
   phx_box_precond *bp = new phx_box_precond();
@@ -868,8 +873,7 @@ static int box_precond_setup(phx_system *s) {
   for (int a = 0; a < 3; ++a) bp->lo[a] = lo[a];
   const int64_t tot = bp->g.plane * bp->g.m[2];
   if (phx_malloc(&bp->gmap, sizeof(int32_t) * (size_t)tot) != hipSuccess ||
-      phx_malloc(&bp->dscale, sizeof(double) * (size_t)s->n) != hipSuccess ||
-      phx_malloc(&bp->vec, sizeof(double) * (size_t)s->n * 2) != hipSuccess) {
+      (!s->u_unscaled && phx_malloc(&bp->dscale, sizeof(double) * (size_t)s->n) != hipSuccess)) {
     box_precond_free(bp);
     return PHX_ERR_HIP;
   }
@@ -886,7 +890,7 @@ static int box_precond_setup(phx_system *s) {
     const double *cc = m->gdim == 3 ? c3 : c2;
     k_dscale_weighted<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(
         s->n, s->perm, s->diag, 2.0 * (cc[0] + cc[1] + cc[2]), bp->dscale, bp->iscale);
-  } else {
+  } else if (!s->u_unscaled) {   // unscaled u columns: P = K_box^-1 itself, nothing to multiply on the way out
     k_dscale<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(s->n, s->perm, s->diag, bp->dscale);
   }
   if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
@@ -894,7 +898,6 @@ static int box_precond_setup(phx_system *s) {
   // entries of phat / shat (u rows this rank does not own) are never written and stay zero.
   rc = phx_select_indices(st, s->n, SelNotU{s->perm, (int32_t)s->nu}, &bp->rest, &bp->nrest);
   if (rc != PHX_OK) { box_precond_free(bp); return rc; }
-  if (hipMemsetAsync(bp->vec, 0, sizeof(double) * (size_t)s->n * 2, st) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
   bp->own_ptr = s->own;
   s->precond = bp;
   s->precond_state = 1;
@@ -918,8 +921,13 @@ static int box_precond_apply(phx_system *s, const double *vin, double *vout) {
 // (x fastest, no padding in `f`) in f64 (f32 = 0) or f32 transforms; u overwrites f.
 extern "C" int phx_box_poisson_solve(int device, const int *L, const double *h, int f32, double *f_host) {
   PHX_HIP(hipSetDevice(device));
-  for (int a = 0; a < 3; ++a)
-    PHX_REQUIRE(dst_pick_length(L[a]) == L[a], PHX_ERR_VALUE, "L[%d] = %d is not a supported transform length", a, L[a]);
+  {
+    bool ztri = true;
+    if (const char *e = getenv("PHX_Z_TRIDIAG")) ztri = atoi(e) != 0;
+    for (int a = 0; a < 3; ++a)
+      PHX_REQUIRE(dst_pick_length(L[a]) == L[a] || (a == 2 && ztri && L[a] >= 2 && L[a] <= 1025), PHX_ERR_VALUE,
+                  "L[%d] = %d is not a supported transform length", a, L[a]);
+  }
   phx_box_precond *bp = new phx_box_precond();
   const double c[3] = {h[1] * h[2] / h[0], h[0] * h[2] / h[1], h[0] * h[1] / h[2]};
   int rc = box_grid_setup(bp, device, L, c, f32 != 0);
@@ -955,7 +963,7 @@ extern "C" int phx_box_poisson_solve(int device, const int *L, const double *h, 
 // Timing aid (tools/dst_bench.py): average microseconds of the x, y, z (solve) passes on a zero lattice.
 extern "C" int phx_box_dst_bench(int device, const int *L, int f32, int reps, double *out_us3) {
   PHX_HIP(hipSetDevice(device));
-  for (int a = 0; a < 3; ++a)
+  for (int a = 0; a < 2; ++a)
     PHX_REQUIRE(dst_pick_length(L[a]) == L[a], PHX_ERR_VALUE, "L[%d] = %d is not a supported transform length", a, L[a]);
   phx_box_precond *bp = new phx_box_precond();
   const double c[3] = {1.0, 1.0, 1.0};

@@ -21,6 +21,7 @@
 #include "phx_select.h"
 
 #define SELL_C 64
+#define SELL_S 16   // rows per slice of the stored rows of a structured system (four lanes per row)
 // Rows per length-sorting window.  Measured on the 256^3 system (2.9 M rows): no sort 180 us,
 // 512 -> 113 us, 4096 -> 184 us, 32768 -> 122 us, one global window -> 81 us per SpMV; the stable
 // global sort keeps the 7-point interior rows in natural order and only moves the few long
@@ -281,6 +282,427 @@ int phx_system_build_sell(phx_system *s) {
   return PHX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Structured systems (phx_common.h): stencil segments over the rows of C0, SELL over the stored rows, built
+// straight from the row slots of the assembly.  Solver order = active order (perm = identity).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t sv_base(const phx_slot_view &sv, int64_t row, int *W) {
+  if (sv.off) { *W = 1 << sv.wlog[row]; return sv.off[row]; }
+  *W = sv.W;
+  return row * sv.W;
+}
+
+// per stored row (one wavefront each, over the compacted list): entries the SELL copy keeps (non-zero, or the
+// diagonal), the diagonal itself, the structural count.  A C0 row in the list (C0 rows next to a non-C0 row are
+// stored, not applied) has no slots unless the CSR is exported: its row IS the stencil row.
+__global__ void __launch_bounds__(256)
+k_slot_row_meta(int64_t ns, const int32_t *__restrict__ list, phx_slot_view sv, const uint8_t *__restrict__ c0,
+                int32_t nent, const int32_t *__restrict__ du, const int32_t *__restrict__ dp, int gdim,
+                int32_t *__restrict__ len, int32_t *__restrict__ nstruct, double *__restrict__ diag) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (i >= ns) return;
+  const int32_t row = list[i];
+  if (c0[row]) {
+    if (lane == 0) { len[i] = gdim == 3 ? 7 : 5; nstruct[i] = gdim == 3 ? 15 : 7; }
+    return;
+  }
+  int W;
+  const int64_t base = sv_base(sv, row, &W);
+  const int nclean = sv.clean ? sv.clean[row] : 0;
+  const int limit = nclean ? nclean : W;
+  int st = 0, keep = 0;
+  for (int k = lane; k < limit; k += 64) {
+    const int32_t cc = sv.cols[base + k];
+    if (cc == -1) continue;
+    const int32_t col = cc < nent ? du[cc] : dp[cc - nent];
+    const double v = sv.vals[base + k];
+    ++st;
+    if (col == row) { diag[row] = v; ++keep; }
+    else if (v != 0.0) ++keep;
+  }
+  for (int o = 32; o > 0; o >>= 1) { st += __shfl_xor(st, o); keep += __shfl_xor(keep, o); }
+  if (lane == 0) { len[i] = keep; nstruct[i] = st; }
+}
+
+// totals[0] += sum a, totals[1] += sum b (one atomic pair per block; per-row atomics on a few addresses cost
+// 2.7 ms for 6e5 rows)
+__global__ void __launch_bounds__(256)
+k_sum2_i32(int64_t n, const int32_t *__restrict__ a, const int32_t *__restrict__ b,
+           unsigned long long *__restrict__ totals) {
+  __shared__ unsigned long long red[2][4];
+  unsigned long long sa = 0, sb = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    sa += (unsigned long long)a[i];
+    sb += (unsigned long long)b[i];
+  }
+  for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sa; red[1][threadIdx.x >> 6] = sb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&totals[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(&totals[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+struct SelStored { const uint8_t *c0; __host__ __device__ bool operator()(const int32_t &i) const { return c0[i] == 0; } };
+
+__global__ void k_stored_keys(int64_t ns, const int32_t *__restrict__ list, const int32_t *__restrict__ len,
+                              uint32_t *__restrict__ keys) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < ns) keys[i] = (uint32_t)(1023 - min(len[i], 1023));   // ascending key = descending length
+}
+
+__global__ void k_fill_i32(int64_t n, int32_t *__restrict__ a, int32_t v, int iota) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) a[i] = iota ? (int32_t)i : v;
+}
+
+// one wavefront per stored row: the kept entries of its slots, sorted by column (lanes of a slice then gather
+// neighbouring x entries at equal k), go to consecutive k of its SELL lane; columns become solver positions.
+// A stored C0 row is written from the stencil coefficients.  Rows of up to 64 slots (P1).
+__global__ void __launch_bounds__(256)
+k_sell_fill_slots(int64_t ns, const int32_t *__restrict__ rows, phx_slot_view sv, const uint8_t *__restrict__ c0,
+                  int32_t nent, const int32_t *__restrict__ du, const int32_t *__restrict__ dp, int64_t nu, int gdim,
+                  const double *__restrict__ stencil, const double *__restrict__ diag,
+                  const int32_t *__restrict__ iperm, const int64_t *__restrict__ slice_ptr,
+                  int32_t *__restrict__ scol, double *__restrict__ sval, double *__restrict__ sraw,
+                  const int64_t *__restrict__ full, int64_t n0, int64_t n01) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  if (i >= ns) return;
+  const int32_t row = rows[i];
+  const int64_t sl = i / SELL_S, li = i % SELL_S;
+  const int64_t sb = slice_ptr[sl];
+  const int width = (int)((slice_ptr[sl + 1] - sb) / SELL_S);
+  int32_t c = 0x7fffffff;   // ACTIVE column index while sorting
+  double v = 0.0;
+  if (c0[row]) {
+    // lattice Laplacian row: lanes 0..6 = self, -x, +x, -y, +y, -z, +z
+    const int64_t vtx = full[row];
+    const int nent7 = gdim == 3 ? 7 : 5;
+    if (lane < nent7) {
+      const int64_t off = lane == 0 ? 0 : (lane <= 2 ? 1 : (lane <= 4 ? n0 : n01));
+      const int64_t w = (lane & 1) ? vtx - off : vtx + off;   // odd lanes: minus side (lane 0: off = 0)
+      c = du[w];
+      v = stencil[lane == 0 ? 0 : (lane + 1) / 2];
+    }
+  } else {
+    int W;
+    const int64_t base = sv_base(sv, row, &W);
+    const int nclean = sv.clean ? sv.clean[row] : 0;
+    const int limit = nclean ? nclean : W;
+    if (lane < limit) {
+      const int32_t cc = sv.cols[base + lane];
+      if (cc != -1) {
+        const int32_t col = cc < nent ? du[cc] : dp[cc - nent];
+        const double vv = sv.vals[base + lane];
+        if (vv != 0.0 || col == row) { c = col; v = vv; }
+      }
+    }
+  }
+  // bitonic sort by column across the wavefront (invalid lanes carry INT_MAX and sink to the end)
+  for (int k = 2; k <= 64; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int32_t oc = __shfl_xor(c, j);
+      const double ov = __shfl_xor(v, j);
+      const bool up = ((lane & k) == 0);
+      const bool lower = ((lane & j) == 0);
+      const bool take = (lower == up) ? (oc < c) : (oc > c);
+      if (take) { c = oc; v = ov; }
+    }
+  if (lane < width) {
+    const int64_t o = sb + (int64_t)lane * SELL_S + li;
+    if (c != 0x7fffffff) {
+      scol[o] = iperm[c];
+      sraw[o] = v;
+      sval[o] = c < nu ? v : v / diag[c];   // u columns unscaled, p columns A D^-1
+    } else {
+      scol[o] = iperm[row]; sraw[o] = 0.0; sval[o] = 0.0;
+    }
+  }
+}
+
+// slots of the last slice that hold no row: padding entries pointing at row 0 with value 0
+__global__ void k_sell_pad_tail(int64_t ns, int64_t nslices, const int64_t *__restrict__ slice_ptr,
+                                int32_t *__restrict__ scol, double *__restrict__ sval, double *__restrict__ sraw) {
+  const int64_t i = ns + threadIdx.x;
+  if (i >= nslices * SELL_S) return;
+  const int64_t sl = i / SELL_S, li = i % SELL_S, sb = slice_ptr[sl];
+  const int width = (int)((slice_ptr[sl + 1] - sb) / SELL_S);
+  for (int k = 0; k < width; ++k) {
+    const int64_t o = sb + (int64_t)k * SELL_S + li;
+    scol[o] = 0; sval[o] = 0.0; sraw[o] = 0.0;
+  }
+}
+
+// widths of the 16-row slices of a structured system, rounded up to the four lanes a row is spread over
+__global__ void k_slice_widths16(int64_t nslices, int64_t n, const uint32_t *__restrict__ sorted_keys,
+                                 int64_t *__restrict__ widths) {
+  const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (s > nslices) return;
+  if (s == nslices) { widths[s] = 0; return; }
+  int w = 0;
+  for (int r = 0; r < SELL_S; ++r) {
+    const int64_t pos = s * SELL_S + r;
+    if (pos < n) w = max(w, 1023 - (int)(sorted_keys[pos] & 0x3ff));
+  }
+  w = (w + 3) & ~3;
+  widths[s] = (int64_t)w * SELL_S;
+}
+
+// C0 rows whose six (2-D: four) axis neighbours are C0 rows as well: the rows the stencil blocks apply
+__global__ void k_c0_interior(int64_t nu, const uint8_t *__restrict__ c0, const int64_t *__restrict__ full,
+                              const int32_t *__restrict__ du, int64_t n0, int64_t n01, int has_z,
+                              uint8_t *__restrict__ c0i) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= nu) return;
+  bool ok = c0[r] != 0;
+  if (ok) {   // every neighbour of a C0 vertex is active: its whole star is tagged inside
+    const int64_t v = full[r];
+    ok = c0[du[v - 1]] && c0[du[v + 1]] && c0[du[v - n0]] && c0[du[v + n0]];
+    if (ok && has_z) ok = c0[du[v - n01]] && c0[du[v + n01]];
+  }
+  c0i[r] = ok ? 1 : 0;
+}
+
+// solver order: the C0 rows in lattice order, then the other u rows, then the p rows (active order).  Keeping the
+// rows near Gamma_h together makes the x entries their SELL rows gather a compact range that stays in L2.
+__global__ void k_build_perm(int64_t n, int64_t nu, const uint8_t *__restrict__ c0, const int32_t *__restrict__ rank,
+                             int32_t nc0all, int32_t *__restrict__ perm, int32_t *__restrict__ iperm) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int32_t pos = (int32_t)r;
+  if (r < nu) pos = c0[r] ? rank[r] : nc0all + ((int32_t)r - rank[r]);
+  iperm[r] = pos;
+  perm[pos] = (int32_t)r;
+}
+
+// run starts / ends of stencil rows along x lines, in SOLVER positions q < nc0all (C0 rows keep their lattice
+// order there: two of them are x neighbours iff their vertices are consecutive)
+__global__ void k_seg_flags(int64_t nq, const int32_t *__restrict__ perm, const uint8_t *__restrict__ c0i,
+                            const int64_t *__restrict__ full, uint8_t *__restrict__ fs, uint8_t *__restrict__ fe) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int32_t r = perm[q];
+  const bool in = c0i[r] != 0;
+  bool prev = false, next = false;
+  if (in && q > 0) { const int32_t rp = perm[q - 1]; prev = c0i[rp] && full[rp] + 1 == full[r]; }
+  if (in && q + 1 < nq) { const int32_t rn = perm[q + 1]; next = c0i[rn] && full[r] + 1 == full[rn]; }
+  fs[q] = in && !prev;
+  fe[q] = in && !next;
+}
+
+__global__ void k_seg_fill(int64_t nq, const int32_t *__restrict__ perm, const int32_t *__restrict__ iperm,
+                           const uint8_t *__restrict__ fs, const uint8_t *__restrict__ fe,
+                           const int32_t *__restrict__ is, const int32_t *__restrict__ ie,
+                           const int64_t *__restrict__ full, const int32_t *__restrict__ du, int64_t n0, int64_t n01,
+                           int has_z, int32_t *__restrict__ seg) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  if (fs[q]) {
+    int32_t *sg = seg + 6 * (int64_t)is[q];
+    const int64_t v = full[perm[q]];
+    sg[0] = (int32_t)q;
+    sg[2] = iperm[du[v + n0]] - (int32_t)q;
+    sg[3] = iperm[du[v - n0]] - (int32_t)q;
+    sg[4] = has_z ? iperm[du[v + n01]] - (int32_t)q : 0;
+    sg[5] = has_z ? iperm[du[v - n01]] - (int32_t)q : 0;
+  }
+  if (fe[q]) seg[6 * (int64_t)ie[q] + 1] = (int32_t)(q + 1);
+}
+
+// slice record of 64 consecutive positions: {runs intersecting the slice (3 = more than two), index of the first,
+// the first two runs inline}
+__global__ void k_slice_seg(int64_t nw, int nseg, const int32_t *__restrict__ seg, int32_t *__restrict__ srec) {
+  const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (w >= nw) return;
+  int lo = 0, hi = nseg;   // first run whose end lies beyond position 64 w
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((int64_t)seg[6 * (int64_t)mid + 1] > w * 64) hi = mid; else lo = mid + 1;
+  }
+  int32_t *rec = srec + 16 * w;
+  for (int j = 0; j < 16; ++j) rec[j] = 0;
+  int cnt = 0;
+  for (int k = lo; k < nseg && (int64_t)seg[6 * (int64_t)k] < (w + 1) * 64 && cnt < 3; ++k) {
+    if (cnt < 2)
+      for (int j = 0; j < 6; ++j) rec[2 + 6 * cnt + j] = seg[6 * (int64_t)k + j];
+    ++cnt;
+  }
+  rec[0] = cnt;
+  rec[1] = lo;
+}
+
+__global__ void k_cscale(int64_t n, int64_t nu, const int32_t *__restrict__ perm, const double *__restrict__ diag,
+                         double *__restrict__ cs) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) cs[i] = i < nu ? 1.0 : 1.0 / diag[perm[i]];
+}
+
+__global__ void k_map_i32(int64_t n, const int32_t *__restrict__ map, int32_t *__restrict__ a) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n && a[i] >= 0) a[i] = map[a[i]];
+}
+
+struct U8AsI32 { __host__ __device__ int32_t operator()(const uint8_t &a) const { return (int32_t)a; } };
+static int scan_u8(hipStream_t st, const uint8_t *flags, int32_t *out, int64_t n, int32_t *total) {
+  hipcub::TransformInputIterator<int32_t, U8AsI32, const uint8_t *> it(flags, U8AsI32());
+  size_t bytes = 0;
+  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, (int)n, st));
+  void *tmp = nullptr;
+  PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, out, (int)n, st));
+  int32_t last = 0;
+  uint8_t lastf = 0;
+  PHX_HIP(hipMemcpyAsync(&last, out + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  PHX_HIP(hipMemcpyAsync(&lastf, flags + (n - 1), 1, hipMemcpyDeviceToHost, st));
+  PHX_HIP(hipStreamSynchronize(st));
+  PHX_HIP(phx_free(tmp));
+  *total = last + (int32_t)lastf;
+  return PHX_OK;
+}
+
+int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t nent) {
+  phx_mesh *m = s->mesh;
+  hipStream_t st = m->stream;
+  const int64_t n = s->n, nu = s->nu;
+  const dim3 block(256), gn((unsigned)phx_div_up(n, 256)), gu((unsigned)phx_div_up(std::max<int64_t>(nu, 1), 256));
+  const int64_t n0 = m->box_n[0] + 1, n01 = n0 * (m->box_n[1] + 1);
+  const int has_z = m->gdim == 3 ? 1 : 0;
+  // ---- solver order: C0 rows (lattice order), other u rows, p rows
+  int32_t *rank = nullptr, nc0all = 0;
+  uint8_t *c0i = nullptr;   // [n] rows the stencil applies: C0 rows whose axis neighbours are C0 rows too
+  PHX_HIP(phx_malloc(&rank, sizeof(int32_t) * (size_t)std::max<int64_t>(nu, 1)));
+  PHX_HIP(phx_malloc(&c0i, (size_t)n));
+  PHX_HIP(hipMemsetAsync(c0i, 0, (size_t)n, st));
+  if (nu > 0) {
+    PHX_CHECK(scan_u8(st, s->c0, rank, nu, &nc0all));
+    k_c0_interior<<<gu, block, 0, st>>>(nu, s->c0, s->full_of_active, s->dof_of_vertex_u, n0, n01, has_z, c0i);
+  }
+  PHX_HIP(phx_malloc(&s->perm, sizeof(int32_t) * (size_t)n));
+  PHX_HIP(phx_malloc(&s->iperm, sizeof(int32_t) * (size_t)n));
+  k_build_perm<<<gn, block, 0, st>>>(n, nu, s->c0, rank, nc0all, s->perm, s->iperm);
+  // ---- stored rows (everything the stencil does not apply): kept entries, diagonal
+  int32_t *list = nullptr;
+  int64_t ns = 0;
+  PHX_CHECK(phx_select_indices(st, n, SelStored{c0i}, &list, &ns));   // synchronises
+  PHX_HIP(phx_free(rank));
+  int32_t *len = nullptr, *nstruct = nullptr;
+  unsigned long long *dtot = nullptr, htot[2] = {0, 0};
+  PHX_HIP(phx_malloc(&len, sizeof(int32_t) * (size_t)std::max<int64_t>(ns, 1)));
+  PHX_HIP(phx_malloc(&nstruct, sizeof(int32_t) * (size_t)std::max<int64_t>(ns, 1)));
+  PHX_HIP(phx_malloc(&dtot, sizeof(htot)));
+  PHX_HIP(hipMemsetAsync(dtot, 0, sizeof(htot), st));
+  if (ns > 0) {
+    PHX_REQUIRE_GRID(ns * 64, "stored-row scan");
+    k_slot_row_meta<<<dim3((unsigned)phx_div_up(ns * 64, 256)), block, 0, st>>>(
+        ns, list, sv, s->c0, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, m->gdim, len, nstruct, s->diag);
+    k_sum2_i32<<<dim3((unsigned)std::min<int64_t>(phx_div_up(ns, 256), 512)), block, 0, st>>>(ns, nstruct, len, dtot);
+  }
+  PHX_HIP(hipMemcpyAsync(htot, dtot, sizeof(htot), hipMemcpyDeviceToHost, st));
+  PHX_HIP(hipStreamSynchronize(st));
+  PHX_HIP(phx_free(dtot)); PHX_HIP(phx_free(nstruct));
+  s->n_sell_rows = ns;
+  s->nc0 = n - ns;
+  const int per_c0 = m->gdim == 3 ? 7 : 5, struct_c0 = m->gdim == 3 ? 15 : 7;
+  if (!s->rowptr) s->nnz = (int64_t)htot[0] + (int64_t)struct_c0 * s->nc0;     // structural entries (dolfinx pattern)
+  s->sell_true_nnz = (int64_t)htot[1] + (int64_t)per_c0 * s->nc0;              // non-zeros one SpMV applies
+  PHX_HIP(phx_malloc(&s->cscale, sizeof(double) * (size_t)n));
+  k_cscale<<<gn, block, 0, st>>>(n, nu, s->perm, s->diag, s->cscale);
+  // ---- SELL over the stored rows, longest first (stable: equal lengths keep their lattice order)
+  s->nslices = phx_div_up(ns, SELL_S);   // slices of 16 rows, four lanes per row (k_spmv_sell)
+  PHX_HIP(phx_malloc(&s->slice_ptr, sizeof(int64_t) * (size_t)(s->nslices + 1)));
+  PHX_HIP(phx_malloc(&s->sell_rows, sizeof(int32_t) * (size_t)std::max<int64_t>(s->nslices * SELL_S, 1)));
+  int32_t *rows_active = nullptr;   // the same list in active numbering (the slots are indexed by it)
+  PHX_HIP(phx_malloc(&rows_active, sizeof(int32_t) * (size_t)std::max<int64_t>(s->nslices * SELL_S, 1)));
+  if (ns > 0) {
+    uint32_t *keys = nullptr, *keys2 = nullptr;
+    PHX_HIP(phx_malloc(&keys, sizeof(uint32_t) * (size_t)ns));
+    PHX_HIP(phx_malloc(&keys2, sizeof(uint32_t) * (size_t)ns));
+    const dim3 gs((unsigned)phx_div_up(ns, 256));
+    k_stored_keys<<<gs, block, 0, st>>>(ns, list, len, keys);
+    k_fill_i32<<<dim3((unsigned)phx_div_up(s->nslices * SELL_S, 256)), block, 0, st>>>(s->nslices * SELL_S, rows_active, -1, 0);
+    size_t bytes = 0;
+    PHX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys2, list, rows_active, (int)ns, 0, 10, st));
+    void *tmp = nullptr;
+    PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
+    PHX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys, keys2, list, rows_active, (int)ns, 0, 10, st));
+    PHX_HIP(hipMemcpyAsync(s->sell_rows, rows_active, sizeof(int32_t) * (size_t)(s->nslices * SELL_S), hipMemcpyDeviceToDevice, st));
+    k_map_i32<<<dim3((unsigned)phx_div_up(s->nslices * SELL_S, 256)), block, 0, st>>>(s->nslices * SELL_S, s->iperm, s->sell_rows);
+    int64_t *widths = nullptr;
+    PHX_HIP(phx_malloc(&widths, sizeof(int64_t) * (size_t)(s->nslices + 1)));
+    k_slice_widths16<<<dim3((unsigned)phx_div_up(s->nslices + 1, 256)), block, 0, st>>>(s->nslices, ns, keys2, widths);
+    size_t b2 = 0;
+    PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, widths, s->slice_ptr, (int)(s->nslices + 1), st));
+    void *t2 = nullptr;
+    PHX_HIP(phx_malloc(&t2, b2 ? b2 : 16));
+    PHX_HIP(hipcub::DeviceScan::ExclusiveSum(t2, b2, widths, s->slice_ptr, (int)(s->nslices + 1), st));
+    PHX_HIP(hipMemcpyAsync(&s->sell_nnz, s->slice_ptr + s->nslices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PHX_HIP(hipStreamSynchronize(st));
+    PHX_HIP(phx_free(tmp)); PHX_HIP(phx_free(t2)); PHX_HIP(phx_free(widths)); PHX_HIP(phx_free(keys)); PHX_HIP(phx_free(keys2));
+  } else {
+    PHX_HIP(hipMemsetAsync(s->slice_ptr, 0, sizeof(int64_t), st));
+    s->sell_nnz = 0;
+  }
+  const size_t ne = (size_t)std::max<int64_t>(s->sell_nnz, 1);
+  PHX_HIP(phx_malloc(&s->sell_col, sizeof(int32_t) * ne));
+  PHX_HIP(phx_malloc(&s->sell_val, sizeof(double) * ne));
+  PHX_HIP(phx_malloc(&s->sell_val_raw, sizeof(double) * ne));
+  PHX_HIP(phx_malloc(&s->sell_kind, (size_t)std::max<int64_t>(s->nslices, 1) * 2));
+  s->sell_kind_raw = s->sell_kind + std::max<int64_t>(s->nslices, 1);
+  PHX_HIP(hipMemsetAsync(s->sell_kind, 0, (size_t)std::max<int64_t>(s->nslices, 1) * 2, st));
+  s->sell_stream_bytes = 0;
+  if (ns > 0) {
+    const dim3 gf((unsigned)phx_div_up(ns * 64, 256));
+    k_sell_fill_slots<<<gf, block, 0, st>>>(ns, rows_active, sv, s->c0, nent, s->dof_of_vertex_u, s->dof_of_vertex_p, nu,
+                                            m->gdim, s->stencil, s->diag, s->iperm, s->slice_ptr, s->sell_col, s->sell_val,
+                                            s->sell_val_raw, s->full_of_active, n0, n01);
+    if (ns < s->nslices * SELL_S)
+      k_sell_pad_tail<<<1, 64, 0, st>>>(ns, s->nslices, s->slice_ptr, s->sell_col, s->sell_val, s->sell_val_raw);
+    PHX_HIP(hipGetLastError());
+    // the stored rows (near Gamma_h) hold few repeated values: no dictionary coding here
+    s->sell_stream_bytes = 12 * s->sell_nnz + 8 * s->nslices + 4 * s->nslices * SELL_S;
+  }
+  PHX_HIP(hipStreamSynchronize(st));
+  PHX_HIP(phx_free(len)); PHX_HIP(phx_free(list)); PHX_HIP(phx_free(rows_active));
+  // ---- stencil runs over the positions of the C0 rows
+  s->nseg = 0;
+  s->nstencil_pos = nc0all;
+  if (s->nc0 > 0 && nc0all > 0) {
+    const int64_t nq = nc0all;
+    uint8_t *fs = nullptr, *fe = nullptr;
+    int32_t *is = nullptr, *ie = nullptr;
+    PHX_HIP(phx_malloc(&fs, (size_t)nq)); PHX_HIP(phx_malloc(&fe, (size_t)nq));
+    PHX_HIP(phx_malloc(&is, sizeof(int32_t) * (size_t)nq)); PHX_HIP(phx_malloc(&ie, sizeof(int32_t) * (size_t)nq));
+    const dim3 gq((unsigned)phx_div_up(nq, 256));
+    k_seg_flags<<<gq, block, 0, st>>>(nq, s->perm, c0i, s->full_of_active, fs, fe);
+    int32_t nstart = 0, nend = 0;
+    PHX_CHECK(scan_u8(st, fs, is, nq, &nstart));
+    PHX_CHECK(scan_u8(st, fe, ie, nq, &nend));
+    PHX_REQUIRE(nstart == nend, PHX_ERR_HIP, "stencil runs: %d starts, %d ends", nstart, nend);
+    s->nseg = nstart;
+    PHX_HIP(phx_malloc(&s->seg, sizeof(int32_t) * 6 * (size_t)std::max(nstart, 1)));
+    k_seg_fill<<<gq, block, 0, st>>>(nq, s->perm, s->iperm, fs, fe, is, ie, s->full_of_active, s->dof_of_vertex_u,
+                                     n0, n01, has_z, s->seg);
+    const int64_t nw = phx_div_up(nq, 64);
+    PHX_HIP(phx_malloc(&s->slice_seg, sizeof(int32_t) * 16 * (size_t)nw));
+    k_slice_seg<<<dim3((unsigned)phx_div_up(nw, 256)), block, 0, st>>>(nw, s->nseg, s->seg, s->slice_seg);
+    PHX_HIP(hipGetLastError());
+    PHX_HIP(hipStreamSynchronize(st));
+    PHX_HIP(phx_free(fs)); PHX_HIP(phx_free(fe)); PHX_HIP(phx_free(is)); PHX_HIP(phx_free(ie));
+    s->sell_stream_bytes += 24 * (int64_t)s->nseg + 64 * nw;
+  }
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipStreamSynchronize(st));
+  PHX_HIP(phx_free(c0i));
+  // solver workspace: 9 vectors + scalars
+  PHX_HIP(phx_malloc(&s->work, sizeof(double) * (size_t)n * 9));
+  PHX_HIP(phx_malloc(&s->scal, sizeof(double) * PHX_SCAL_DOUBLES));
+  PHX_HIP(hipHostMalloc(&s->scal_h, sizeof(double) * 16));
+  return PHX_OK;
+}
+
 // Workspace of a system without any active DoF (a slab that does not touch the domain): it takes part in
 // every collective of a multi-GPU solve with zero contributions.
 int phx_system_build_empty(phx_system *s) {
@@ -302,6 +724,15 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+struct StencilArgs {
+  int64_t nu;             // solver positions the stencil slices cover (the C0 rows)
+  const int32_t *seg;     // [nseg][6]
+  int nseg;
+  const int32_t *srec;    // [ceil(nu / 64)][16] slice records
+  const double *st;       // {diag, x, y, z entries} of a C0 row
+  int64_t chunk;          // stencil blocks per XCD
+};
+
 template <int DOTS>
 __global__ void __launch_bounds__(256)
 k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
@@ -309,7 +740,7 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
             const double *__restrict__ x, double *__restrict__ y,
             const uint8_t *__restrict__ own, const double *__restrict__ d0,
             double *__restrict__ out0, double *__restrict__ out1, int xcd_group,
-            const uint8_t *__restrict__ kind) {
+            const uint8_t *__restrict__ kind, const int32_t *__restrict__ rows, int64_t nb_sell, StencilArgs sa) {
   __shared__ double vi_dict[4][VI_MAX];
   const int lane = threadIdx.x & 63;
   // Optional XCD-aware block -> slice map (PHX_OPT_SPMV_XCD_GROUP): blocks b and b+8 share an XCD and
@@ -318,7 +749,7 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
   int64_t bid = blockIdx.x;
   if (xcd_group > 0) {
     const int64_t super = 8 * (int64_t)xcd_group, sg = bid / super;
-    if ((sg + 1) * super <= (int64_t)gridDim.x) {
+    if ((sg + 1) * super <= nb_sell) {
       const int64_t rem = bid - sg * super;
       bid = sg * super + (rem & 7) * xcd_group + (rem >> 3);
     }
@@ -326,7 +757,113 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
   const int64_t s = bid * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   double acc = 0.0;
   int64_t row = -1;
-  if (s < nslices) {
+  double p0 = 0.0, p1 = 0.0;   // this lane's share of (y, d0) and (y, y)
+#define PHX_DOT_ACC(a_, r_) \
+  do { if (DOTS > 0) { p0 = __builtin_fma((a_), d0[(r_)], p0); if (DOTS > 1) p1 = __builtin_fma((a_), (a_), p1); } } while (0)
+  if (blockIdx.x >= nb_sell) {
+    // ---- rows of C0 of a structured system (blocks behind the SELL blocks of the same launch):
+    // y_i = d x_i + cx (x_{i-1} + x_{i+1}) + cy (x_{i+oy+} + x_{i+oy-}) + cz (x_{i+oz+} + x_{i+oz-}), the row of the
+    // lattice Laplacian, over runs of consecutive rows of one x line (`seg`: {first, end, offsets of the +y, -y,
+    // +z, -z neighbour rows}, constant along a run because active rows are numbered in lattice order).  A
+    // wavefront takes FOUR slices of 64 consecutive u rows (one slice per wave is latency bound: 21.5 us for
+    // 2.4e6 rows); a slice record carries its first two runs inline (one wave-uniform 64-byte load), further
+    // runs are looked up in `seg`.  A lane whose row lies in no run belongs to a stored row and leaves it to the
+    // SELL blocks.  Nothing of the matrix is read: seven coalesced x streams per slice.
+    constexpr int U = 4;
+    const int64_t bl = blockIdx.x - nb_sell;                       // nb_sell is a multiple of 8
+    const int64_t sb_ = (bl & 7) * sa.chunk + (bl >> 3);           // XCD (bl % 8) takes the blocks of its eighth
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t w0 = (sb_ * (int64_t)(blockDim.x >> 6) + wave) * U;
+    bool live[U];
+    int32_t oyp[U], oym[U], ozp[U], ozm[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t w = w0 + u, r = w * 64 + lane;
+      live[u] = false;
+      oyp[u] = oym[u] = ozp[u] = ozm[u] = 0;
+      if (w * 64 < sa.nu) {
+        // {runs in this slice (3: more than two), first run, run A[6], run B[6]}: wave-uniform, scalar loads
+        const int32_t *rec = sa.srec + 16 * w;
+        const int cnt = rec[0];
+        const bool inA = cnt >= 1 && r >= rec[2] && r < rec[3];
+        const bool inB = cnt >= 2 && r >= rec[8] && r < rec[9];
+        live[u] = inA || inB;
+        oyp[u] = inA ? rec[4] : rec[10];
+        oym[u] = inA ? rec[5] : rec[11];
+        ozp[u] = inA ? rec[6] : rec[12];
+        ozm[u] = inA ? rec[7] : rec[13];
+        if (!live[u] && cnt >= 3) {
+          int k = rec[1] + 2;
+          while (k < sa.nseg && sa.seg[6 * (int64_t)k + 1] <= r) ++k;
+          if (k < sa.nseg && r >= sa.seg[6 * (int64_t)k]) {
+            const int32_t *sg = sa.seg + 6 * (int64_t)k;
+            live[u] = true;
+            oyp[u] = sg[2]; oym[u] = sg[3]; ozp[u] = sg[4]; ozm[u] = sg[5];
+          }
+        }
+        if (r >= sa.nu) live[u] = false;
+      }
+    }
+    double xv[U][7];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = (w0 + u) * 64 + lane;
+      if (live[u]) {
+        xv[u][0] = x[r]; xv[u][1] = x[r - 1]; xv[u][2] = x[r + 1];
+        xv[u][3] = x[r + oyp[u]]; xv[u][4] = x[r + oym[u]];
+        const bool hz = ozp[u] != 0;
+        xv[u][5] = hz ? x[r + ozp[u]] : 0.0; xv[u][6] = hz ? x[r + ozm[u]] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = (w0 + u) * 64 + lane;
+      if (live[u]) {
+        double a2 = __builtin_fma(sa.st[1], xv[u][1] + xv[u][2], sa.st[0] * xv[u][0]);
+        a2 = __builtin_fma(sa.st[2], xv[u][3] + xv[u][4], a2);
+        a2 = __builtin_fma(sa.st[3], xv[u][5] + xv[u][6], a2);
+        if (own && !own[r]) a2 = 0.0;
+        y[r] = a2;
+        PHX_DOT_ACC(a2, r);
+      }
+    }
+  } else if (rows) {
+    // ---- stored rows of a structured system: SELL-16 with FOUR lanes per row.  Entry k of row r of a slice sits
+    // at base + 16 k + r, so with lane = 16 (k mod 4) + r every wave-instruction still reads 64 consecutive
+    // entries; the four partial sums of a row meet in two shuffles.  The stored rows are few and long (4.9e5 rows
+    // of 24-60 entries at 256^3): one lane per row left 7600 wavefronts for the whole chip and the loop latency
+    // bound (55 us); a quarter of the trip count and four times the waves.
+    if (s < nslices) {
+      const int64_t base = slice_ptr[s];
+      const int trips = (int)((slice_ptr[s + 1] - base) >> 6);   // width / 4
+      const int32_t *c = scol + base + lane;
+      const double *v = sval + base + lane;
+      // four trips (16 entries of a row) per round, their column / value loads in flight before the first gather.
+      // Measured at 256^3 (SELL part alone): 4 trips 44 us; 16 trips with clamped indices 81 us -- the rows average
+      // 6.5 trips and the kernel is bound by vector-memory instructions (gathers of 64 scattered doubles), not by
+      // latency: redundant clamped loads cost their full price.
+      int j = 0;
+      for (; j + 4 <= trips; j += 4) {
+        int32_t cc[4];
+        double vv[4], xs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { cc[q] = NT_LOAD(&c[(j + q) * 64]); vv[q] = NT_LOAD(&v[(j + q) * 64]); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xs[q] = x[cc[q]];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_fma(vv[q], xs[q], acc);
+      }
+      for (; j < trips; ++j) acc = __builtin_fma(NT_LOAD(&v[j * 64]), x[NT_LOAD(&c[j * 64])], acc);
+      acc += __shfl_xor(acc, 16);
+      acc += __shfl_xor(acc, 32);
+      const int32_t rr = rows[s * 16 + (lane & 15)];
+      if (lane < 16 && rr >= 0) {
+        if (own && !own[rr]) acc = 0.0;
+        y[rr] = acc;
+        PHX_DOT_ACC(acc, rr);
+      }
+    }
+  } else if (s < nslices) {
     const int64_t base = slice_ptr[s];
     const int width = (int)((slice_ptr[s + 1] - base) >> 6);
     const int32_t *c = scol + base + lane;
@@ -394,22 +931,18 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
       acc = __builtin_fma(v3, x[c3], acc);
     }
     for (; k < width; ++k) acc = __builtin_fma(NT_LOAD(&v[k * SELL_C]), x[NT_LOAD(&c[k * SELL_C])], acc);
+    // structured systems: the slices run over a list of stored rows (-1: padding of the last slice)
     row = s * SELL_C + lane;
     if (row < n) {
       if (own && !own[row]) acc = 0.0;  // ghost rows stay zero; the halo exchange refreshes them
       y[row] = acc;
-    } else {
-      row = -1;
+      PHX_DOT_ACC(acc, row);
     }
   }
+#undef PHX_DOT_ACC
   if (DOTS > 0) {
     // DOTS == 1: out0 += (y, d0);  DOTS == 2: also out1 += (y, y)
     __shared__ double red[2][4];
-    double p0 = 0.0, p1 = 0.0;
-    if (row >= 0) {
-      p0 = acc * d0[row];
-      if (DOTS > 1) p1 = acc * acc;
-    }
     p0 = wave_sum(p0);
     if (DOTS > 1) p1 = wave_sum(p1);
     const int w = threadIdx.x >> 6;
@@ -593,12 +1126,13 @@ __global__ void k_gather(int64_t n, const int32_t *__restrict__ perm, const doub
 // solution back to FULL numbering: x_full[full_of_active[perm[pos]]] = y[pos] / diag[perm[pos]]
 __global__ void k_scatter_solution(int64_t n, const int32_t *__restrict__ perm,
                                    const int64_t *__restrict__ full_of_active,
-                                   const double *__restrict__ diag, const double *__restrict__ y,
-                                   double *__restrict__ xfull) {
+                                   const double *__restrict__ diag, const double *__restrict__ cscale,
+                                   const double *__restrict__ y, double *__restrict__ xfull) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t r = perm[i];
-  xfull[full_of_active[r]] = y[i] / diag[r];
+  // x = S y: the column scaling folded into the stored values (1 / diag, or 1 for unscaled u columns)
+  xfull[full_of_active[r]] = cscale ? y[i] * cscale[i] : y[i] / diag[r];
 }
 
 static inline dim3 vec_grid(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(phx_div_up(n, 256), 2048))); }
@@ -606,17 +1140,36 @@ static inline dim3 vec_grid(int64_t n) { return dim3((unsigned)std::max<int64_t>
 static int launch_spmv(phx_system *s, const double *vals, const double *x, double *y, int dots,
                        const double *d0, double *o0, double *o1) {
   hipStream_t st = s->mesh->stream;
-  if (s->nslices == 0) return PHX_OK;  // empty system (a slab outside the domain): the dot-product slots stay zero
-  const dim3 block(256), grid((unsigned)phx_div_up(s->nslices, 4));
+  if (s->n == 0) return PHX_OK;  // empty system (a slab outside the domain): the dot-product slots stay zero
+  const dim3 block(256);
   const uint8_t *own = s->own;
   const int xg = s->mesh->spmv_xcd_group;
   const uint8_t *kinds = vals == s->sell_val ? s->sell_kind : s->sell_kind_raw;
+  const int32_t *rows = s->structured ? s->sell_rows : nullptr;
+  // structured systems: the stencil blocks (rows of C0; u columns are unscaled in both value streams) ride behind
+  // the SELL blocks of the same launch
+  StencilArgs sa{0, nullptr, 0, nullptr, nullptr, 0};
+  int64_t nb_sell = phx_div_up(s->nslices, 4);
+  static const int part = getenv("PHX_SPMV_PART") ? atoi(getenv("PHX_SPMV_PART")) : 0;  // timing aid: 1 SELL only, 2 stencil only
+  if (part == 2) nb_sell = 0;
+  int64_t nb = nb_sell;
+  if (s->structured && s->nseg > 0 && part != 1) {
+    // the stencil blocks start at a multiple of 8 so that blockIdx % 8 (the XCD a block lands on) is theirs to
+    // use: XCD k walks the k-th contiguous eighth of the rows, whose x entries then stay in ITS 4 MiB L2
+    // (round-robin placement had every L2 fetch the whole vector: 3.5 x the bytes, 44 % hits)
+    nb_sell = (nb_sell + 7) & ~(int64_t)7;
+    const int64_t nbst = phx_div_up(phx_div_up(s->nstencil_pos, 64), 16);   // four waves per block, four slices per wave
+    sa = StencilArgs{s->nstencil_pos, s->seg, s->nseg, s->slice_seg, s->stencil, (nbst + 7) / 8};
+    nb = nb_sell + 8 * sa.chunk;
+  }
+  if (nb == 0) return PHX_OK;
+  const dim3 g2((unsigned)nb);
   if (dots == 0)
-    k_spmv_sell<0><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds);
+    k_spmv_sell<0><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa);
   else if (dots == 1)
-    k_spmv_sell<1><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds);
+    k_spmv_sell<1><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa);
   else
-    k_spmv_sell<2><<<grid, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds);
+    k_spmv_sell<2><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
 }
@@ -675,6 +1228,14 @@ static int prof_collect(phx_system *s, double *avg_s, int *count, int c = 0) {
 
 #include "phx_precond.inc.hip"
 
+// Structured systems without the box preconditioner (configured out, vetoed, box too long): their u columns are
+// unscaled, so the Jacobi scaling of the u block is applied here: P = D_u^-1 on u rows, the identity elsewhere
+// (diag is stored in active order: through perm).
+__global__ void k_jacobi_u(int64_t n, int64_t nu, const int32_t *__restrict__ perm, const double *__restrict__ diag,
+                           const double *__restrict__ vin, double *__restrict__ vout) {
+  GRID_STRIDE(i, n) vout[i] = i < nu ? vin[i] / diag[perm[i]] : vin[i];
+}
+
 // phat / shat are the preconditioned directions P p, P s the two SpMVs act on; without a preconditioner
 // beyond the Jacobi scaling folded into the SELL values they ARE p and s.
 struct KrVecs {
@@ -684,10 +1245,10 @@ static inline KrVecs kr_vecs(phx_system *s) {
   double *w = s->kr_work ? s->kr_work : s->work;
   const int64_t n = s->n;
   KrVecs V{w, w + n, w + 2 * n, w + 3 * n, w + 4 * n, w + 5 * n, w + 6 * n, w + 7 * n, w + 2 * n, w + 4 * n};
-  if (s->precond_state == 1) {
+  if (s->precond_state == 1 || s->u_unscaled) {
     // attached workspaces (multi-GPU drivers, 10 n doubles) carry the two extra vectors themselves
-    V.phat = s->kr_work ? w + 8 * n : s->precond->vec;
-    V.shat = s->kr_work ? w + 9 * n : s->precond->vec + n;
+    V.phat = s->kr_work ? w + 8 * n : s->pvec;
+    V.shat = s->kr_work ? w + 9 * n : s->pvec + n;
   }
   return V;
 }
@@ -709,6 +1270,11 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       s->precond_state = 0;
     }
     if (s->precond_state == 0) PHX_CHECK(box_precond_setup(s));
+    if ((s->precond_state == 1 || s->u_unscaled) && n > 0 && !s->kr_work) {
+      // phat / shat: rows the preconditioner never writes (u rows another rank owns) stay zero
+      if (!s->pvec) PHX_HIP(phx_malloc(&s->pvec, sizeof(double) * (size_t)n * 2));
+      PHX_HIP(hipMemsetAsync(s->pvec, 0, sizeof(double) * (size_t)n * 2, st));
+    }
   }
   const KrVecs V = kr_vecs(s);
   double *S = kr_scal(s);
@@ -747,9 +1313,11 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       break;
     case 7:  // phat = P p   (before the halo exchange of phat and phase 2)
       if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.p, V.phat));
+      else if (s->u_unscaled && n > 0) k_jacobi_u<<<vec_grid(n), block, 0, st>>>(n, s->nu, s->perm, s->diag, V.p, V.phat);
       break;
     case 8:  // shat = P s   (before the halo exchange of shat and phase 4)
       if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.sv, V.shat));
+      else if (s->u_unscaled && n > 0) k_jacobi_u<<<vec_grid(n), block, 0, st>>>(n, s->nu, s->perm, s->diag, V.sv, V.shat);
       break;
     default:
       phx_set_error("unknown Krylov phase %d", phase);
@@ -777,7 +1345,7 @@ extern "C" int phx_krylov_finish(phx_system *s, double *x_out, int loc) {
   PHX_HIP(hipMemsetAsync(xfull, 0, sizeof(double) * (size_t)s->nfull, st));
   if (n > 0)
     k_scatter_solution<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, st>>>(
-        n, s->perm, s->full_of_active, s->diag, V.y, xfull);
+        n, s->perm, s->full_of_active, s->diag, s->cscale, V.y, xfull);
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(st));
   if (owned) {
@@ -790,7 +1358,8 @@ extern "C" int phx_krylov_finish(phx_system *s, double *x_out, int loc) {
 // after phase 0: 1 when the system is preconditioned beyond Jacobi (phases 7 / 8 then fill phat / shat,
 // the vectors a multi-GPU driver must halo-exchange instead of p / s)
 extern "C" int phx_krylov_precond_active(const phx_system *s, int *active) {
-  *active = s->precond_state == 1 ? 1 : 0;
+  // 1: the SpMV inputs are phat / shat (box preconditioner, or the u-block Jacobi of a structured system)
+  *active = (s->precond_state == 1 || s->u_unscaled) ? 1 : 0;
   return PHX_OK;
 }
 

@@ -227,16 +227,19 @@ class DistributedSolver:
         pc = float(head[R_OFF + R_RR]) == 0.0
         if not pc:
             b.precond_disable()
-        vp, vs = (self.phat, self.shat) if pc else (self.p, self.s)
+        # the SpMV inputs are phat / shat whenever the system keeps them apart from p / s: box preconditioner,
+        # or the u-block Jacobi of a structured system (the same on every rank: all slabs are built alike)
+        hat = pc or getattr(b, "precond_active", lambda: False)()
+        vp, vs = (self.phat, self.shat) if hat else (self.p, self.s)
         check_every = 2 if pc else self.check_every
         while bb != 0.0 and it < self.max_iter:
-            if pc:
+            if hat:
                 b.phase(7)
             self.halo_exchange(vp)
             b.phase(2)
             self._allreduce(R_RV, R_RV + 1)
             b.phase(3)
-            if pc:
+            if hat:
                 b.phase(8)
             self.halo_exchange(vs)
             b.phase(4)

@@ -89,18 +89,23 @@ class PhiFEMSolver:
         locs = {L.ptr(a)[1] for a in (phi_h, f_h, u_D)}
         if len(locs) != 1:
             raise ValueError("phi_h, f_h and u_D must all live on the host or all on the device")
+        self._keep = (phi_h, f_h, u_D)   # inputs stay alive as long as the system they were read for
+        self._sys = self._assemble_raw()
+        return self.info()
+
+    def _assemble_raw(self):
+        phi_h, f_h, u_D = self._keep
+        loc = L.ptr(phi_h)[1]
         h = C.c_void_p()
         if self.degree == 1:
             L.check(L.lib.phx_assemble_poisson_wd(
                 self.mesh._h, self.pen_coef, self.stab_coef, L.ptr(phi_h)[0], L.ptr(f_h)[0],
-                L.ptr(u_D)[0], locs.pop(), C.byref(h)))
+                L.ptr(u_D)[0], loc, C.byref(h)))
         else:
             L.check(L.lib.phx_assemble_poisson_wd_p2(
                 self.mesh._h, self.pen_coef, self.stab_coef, L.ptr(phi_h)[0], self.levelset_degree,
-                L.ptr(f_h)[0], L.ptr(u_D)[0], locs.pop(), C.byref(h)))
-        self._sys = h
-        self._keep = (phi_h, f_h, u_D)   # device inputs stay alive as long as the system they were read for
-        return self.info()
+                L.ptr(f_h)[0], L.ptr(u_D)[0], loc, C.byref(h)))
+        return h
 
     @property
     def ndofs(self):
@@ -108,14 +113,19 @@ class PhiFEMSolver:
         return self.mesh.nv if self.degree == 1 else self.mesh.nv + self.mesh.ne
 
     def info(self):
-        i = (C.c_int64 * 11)()
+        i = (C.c_int64 * 13)()
         L.check(L.lib.phx_system_info(self._sys, i))
         keys = ("n_active", "n_active_u", "nnz", "n_full", "sell_padded_nnz", "slot_capacity",
-                "sell_nnz", "n_slices", "indexed_slices", "spmv_matrix_bytes", "indexed_slices_lds")
+                "sell_nnz", "n_slices", "indexed_slices", "spmv_matrix_bytes", "indexed_slices_lds",
+                "stencil_rows", "stencil_runs")
         return dict(zip(keys, (int(v) for v in i)))
 
     def export_csr(self):
-        """(scipy-style rowptr, col, val, rhs, dof) of the active system, for inspection/tests."""
+        """(scipy-style rowptr, col, val, rhs, dof) of the active system, for inspection/tests.
+
+        The CSR copy is LAZY: P1 systems on Kuhn boxes are assembled straight into the solver formats
+        (stencil-coded interior rows + SELL, PHX_OPT_STRUCTURED) and never form it; the first export
+        re-assembles the same inputs once with PHX_OPT_EXPORT_CSR set and reads the CSR of that system."""
         i = self.info()
         n, nnz = i["n_active"], i["nnz"]
         rowptr = np.empty(n + 1, dtype=np.int64)
@@ -123,8 +133,20 @@ class PhiFEMSolver:
         val = np.empty(nnz, dtype=np.float64)
         rhs = np.empty(n, dtype=np.float64)
         dof = np.empty(n, dtype=np.int64)
-        L.check(L.lib.phx_system_export(self._sys, *(a.ctypes.data_as(C.c_void_p)
-                                                     for a in (rowptr, col, val, rhs, dof))))
+        args = [a.ctypes.data_as(C.c_void_p) for a in (rowptr, col, val, rhs, dof)]
+        rc = L.lib.phx_system_export(self._sys, *args)
+        if rc == L.ERR_VALUE and hasattr(self, "_assemble_raw") and getattr(self, "_keep", None) is not None:
+            L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_EXPORT_CSR, 1))
+            try:
+                h = self._assemble_raw()
+            finally:
+                L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_EXPORT_CSR, 0))
+            try:
+                L.check(L.lib.phx_system_export(h, *args))
+            finally:
+                L.lib.phx_system_destroy(h)
+        else:
+            L.check(rc)
         return rowptr, col, val, rhs, dof
 
     def solve(self, rtol=1e-8, max_iter=20000, out=None, profile_spmv=False, strict=False):

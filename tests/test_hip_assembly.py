@@ -86,7 +86,11 @@ def test_matrix_and_rhs_vs_oracle(P, d, n, box):
     y = s.spmv(xv)
     yo = Ao @ xv
     assert np.abs(y - yo).max() <= 1e-12 * np.abs(yo).max()
-    assert info["sell_nnz"] <= info["nnz"] and info["sell_padded_nnz"] >= info["sell_nnz"]
+    # sell_nnz: non-zeros one SpMV applies; sell_padded_nnz: SELL entries stored (the rows applied from the
+    # stencil of a structured system store nothing)
+    per_row = 5 if d == 2 else 7
+    assert info["sell_nnz"] <= info["nnz"]
+    assert info["sell_padded_nnz"] + per_row * info["stencil_rows"] >= info["sell_nnz"]
 
 
 @pytest.mark.parametrize("d,n", [(2, 32), (3, 10)])
@@ -276,6 +280,8 @@ def test_value_indexed_slices_are_bit_identical(P, d, n):
     bit-identical in both -- the gathered interior rows, which are the ones that get indexed."""
     from phifem_amd import _lib as L
     work, phi, f, uex, A, b, act = setup_problem(P, d, n)
+    # every row stored: the interior rows this test is about are not stored at all by structured systems
+    L.check(L.lib.phx_set_option(work._h, L.OPT_STRUCTURED, 0))
     rng = np.random.default_rng(5)
     ys, sols, infos, mats = [], [], [], []
     for flag in (1, 0):
@@ -304,3 +310,49 @@ def test_value_indexed_slices_are_bit_identical(P, d, n):
     assert np.abs(ys[0] - ys[1]).max() <= 1e-13 * scale
     assert np.abs(ys[0] - M0 @ x).max() <= 1e-13 * scale
     assert np.abs(sols[0] - sols[1]).max() <= 1e-8 * np.abs(sols[1]).max()
+
+
+@pytest.mark.parametrize("d,n", [(3, 20), (3, 27), (2, 64), (2, 100), (3, 12)])
+def test_structured_interior_rows_match_the_stored_matrix(P, d, n):
+    """Structured systems (default on Kuhn boxes): the translation-invariant interior rows are applied from a
+    stencil over runs of consecutive rows and never stored.  The product y = A x of that operator must equal
+    the CSR matrix (exported from a re-assembly with PHX_OPT_EXPORT_CSR) applied to the same x, the stored-everything
+    system (PHX_OPT_STRUCTURED = 0) must give the same product and solution, and the CSR itself still matches the
+    oracle.  Floating-point tolerance: 1e-13 of |A| |x| (different summation order within a row)."""
+    from phifem_amd import _lib as L
+    work, phi, f, uex, A, b, act = setup_problem(P, d, n)
+    rng = np.random.default_rng(17)
+    s = P.PhiFEMSolver(work)
+    info = s.assemble(phi, f, uex)
+    assert info["stencil_rows"] > 0 and info["stencil_runs"] > 0, info
+    assert info["stencil_rows"] + info["n_slices"] * 16 >= info["n_active"]   # stored rows: SELL slices of 16
+    x = rng.standard_normal(info["n_active"])
+    y = s.spmv(x)
+    M, rhs, dof = hip_matrix(s)          # lazy CSR: re-assembled with the export option
+    assert M.nnz == info["nnz"]          # the structural count is known without the CSR
+    scale = np.abs(M).max() * np.abs(x).max()
+    assert np.abs(y - M @ x).max() <= 1e-13 * scale
+    w = s.solve(rtol=1e-11)
+    assert s.stats["converged"] and s.stats["precond"] == "box-dst"
+    # the same problem with every row stored
+    L.check(L.lib.phx_set_option(work._h, L.OPT_STRUCTURED, 0))
+    try:
+        s2 = P.PhiFEMSolver(work)
+        info2 = s2.assemble(phi, f, uex)
+        assert info2["stencil_rows"] == 0 and info2["nnz"] == info["nnz"]
+        y2 = s2.spmv(x)
+        w2 = s2.solve(rtol=1e-11)
+    finally:
+        L.check(L.lib.phx_set_option(work._h, L.OPT_STRUCTURED, 1))
+    assert np.abs(y - y2).max() <= 1e-13 * scale
+    assert np.abs(w - w2).max() <= 1e-8 * np.abs(w2).max()
+    # and without the box preconditioner the unscaled u columns get their Jacobi scaling as a preconditioner
+    L.check(L.lib.phx_set_option(work._h, L.OPT_PRECOND, 0))
+    try:
+        s3 = P.PhiFEMSolver(work)
+        s3.assemble(phi, f, uex)
+        w3 = s3.solve(rtol=1e-11, max_iter=50000)
+        assert s3.stats["converged"] and s3.stats["precond"] == "jacobi"
+    finally:
+        L.check(L.lib.phx_set_option(work._h, L.OPT_PRECOND, 1))
+    assert np.abs(w - w3).max() <= 1e-7 * np.abs(w).max()
