@@ -287,6 +287,23 @@ int phx_solve(phx_system *s, int method, double rtol, int64_t max_iter, double *
  * phases 7 / 8 compute from p / s (rank-local block preconditioner on the owned rows). */
 int phx_krylov_attach(phx_system *s, double *work, double *scal, const uint8_t *own);
 int phx_krylov_precond_active(const phx_system *s, int *active);
+/* --- slab-exact preconditioner of a z-partitioned box -----------------------------------------------------
+ * Every rank holds whole x-y planes of ONE global lattice box around the active vertices of ALL ranks: sine
+ * transforms in x and y stay rank-local, the tridiagonal z solves continue across ranks through two carries per
+ * lattice column and rank (one all-gather per application).  Protocol, after phx_krylov_attach:
+ *   phx_precond_local_bbox   -> out6 = min / max GLOBAL vertex indices of this rank's owned active u DoFs
+ *                               (INT64_MAX / -1 when it owns none); the driver reduces MIN / MAX over the ranks
+ *   phx_precond_setup_global -> builds this rank's share; zb[nranks + 1]: rank r owns the global vertex planes
+ *                               [zb[r], zb[r+1]);  *ncol = 0: not applicable (every rank gets the same answer)
+ *   phx_precond_set_carry_buffers -> send[2 ncol], recv[nranks * 2 ncol] doubles on the device (caller-owned)
+ *   per application: phase 7 (or 8), all-gather send -> recv over the ranks, phase 9 (or 10).
+ * phx_precond_dist_info: out4 = {active, doubles per rank in the all-gather, planes held here, planes of the
+ * global column}. */
+int phx_precond_local_bbox(phx_system *s, int64_t *out6);
+int phx_precond_setup_global(phx_system *s, const int64_t *bbox6, int nranks, int rank, const int64_t *zb,
+                             int64_t *ncol);
+int phx_precond_set_carry_buffers(phx_system *s, double *send, double *recv);
+int phx_precond_dist_info(const phx_system *s, int64_t *out4);
 /* Multi-GPU drivers choose the preconditioner collectively: phase 0 leaves this rank's veto in scal[8 + 5]
  * (1: box preconditioner configured out or impossible here; 0: built, or the rank owns no u row); the driver
  * all-reduces scal[8 + 4 .. 8 + 5] (SUM) after phase 0 and, when the vetoes add up to > 0, calls this on
@@ -297,7 +314,9 @@ int phx_krylov_precond_disable(phx_system *s);
  * launches sampled, bytes per lattice value (4: f32 transforms, 8: f64)}. */
 int phx_precond_info(phx_system *s, double *out);
 /* phase 0 begin, 1 begin2, 2 v=A phat, 3 s-update, 4 t=A shat, 5 x/r-update, 6 p-update + roll,
- * 7 phat = P p, 8 shat = P s (no-ops without a preconditioner) */
+ * 7 phat = P p, 8 shat = P s (no-ops without a preconditioner); with the slab-exact preconditioner
+ * (phx_precond_setup_global) 7 / 8 run its first half and 9 / 10 the second, the driver all-gathering the
+ * carry buffer in between */
 int phx_krylov_phase(phx_system *s, int phase);
 int phx_krylov_finish(phx_system *s, double *x, int loc);
 /* reset != 0: arm the SpMV event profile; else collect {average seconds, launches timed}. */

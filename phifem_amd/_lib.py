@@ -65,6 +65,10 @@ SIGNATURES = {
     "phx_krylov_precond_active": ([_vp, _pi], _i),
     "phx_krylov_precond_disable": ([_vp], _i),
     "phx_precond_info": ([_vp, _pd], _i),
+    "phx_precond_local_bbox": ([_vp, _pi64], _i),
+    "phx_precond_setup_global": ([_vp, _pi64, _i, _i, _pi64, _pi64], _i),
+    "phx_precond_set_carry_buffers": ([_vp, _vp, _vp], _i),
+    "phx_precond_dist_info": ([_vp, _pi64], _i),
     "phx_krylov_attach": ([_vp, _vp, _vp, _vp], _i),
     "phx_krylov_phase": ([_vp, _i], _i),
     "phx_krylov_finish": ([_vp, _vp, _i], _i),

@@ -91,6 +91,7 @@ struct phx_mesh {
   bool c2e_is_alias = false;
   int64_t box_n[3] = {0, 0, 0};
   double box_h[3] = {0.0, 0.0, 0.0};  // exact lattice spacing (hi - lo) / n_global per axis
+  int64_t box_off[3] = {0, 0, 0};     // cube offset of this (slab of a) box in the global box
   int64_t *v2c_ptr = nullptr;  // [nv+1]
   int32_t *v2c_idx = nullptr;  // [nc*nvpc]
   bool is_box = false;

@@ -14,6 +14,7 @@ struct NcclApi {
   int (*Send)(const void *, size_t, int, int, phx_nccl_comm, hipStream_t);
   int (*Recv)(void *, size_t, int, int, phx_nccl_comm, hipStream_t);
   int (*AllReduce)(const void *, void *, size_t, int, int, phx_nccl_comm, hipStream_t);
+  int (*AllGather)(const void *, void *, size_t, int, phx_nccl_comm, hipStream_t);
   int (*GroupStart)();
   int (*GroupEnd)();
   const char *(*GetErrorString)(int);
@@ -39,6 +40,7 @@ static int nccl_bind() {
   BIND(Send, "ncclSend");
   BIND(Recv, "ncclRecv");
   BIND(AllReduce, "ncclAllReduce");
+  BIND(AllGather, "ncclAllGather");
   BIND(GroupStart, "ncclGroupStart");
   BIND(GroupEnd, "ncclGroupEnd");
   BIND(GetErrorString, "ncclGetErrorString");
@@ -132,6 +134,20 @@ static int halo_exchange(phx_system *s, phx_comm *c, const HaloSpec &H, double *
   return PHX_OK;
 }
 
+// slab-exact preconditioner: the zero-inflow carries of every rank's tridiagonal z recurrences (2 doubles per
+// lattice column and rank) between the two halves of an application
+static int allgather_carries(phx_system *s, phx_comm *c) {
+  phx_box_precond *bp = s->precond;
+  const size_t count = (size_t)(2 * bp->g.pitch * bp->g.m[1]);
+  PHX_REQUIRE(bp->carry_send && bp->carry_recv, PHX_ERR_VALUE, "carry buffers of the slab-exact preconditioner are not set");
+  if (c->nranks == 1) {
+    PHX_HIP(hipMemcpyAsync(bp->carry_recv, bp->carry_send, sizeof(double) * count, hipMemcpyDeviceToDevice, s->mesh->stream));
+    return PHX_OK;
+  }
+  PHX_NCCL(g_nccl.AllGather(bp->carry_send, bp->carry_recv, count, PHX_NCCL_FLOAT64, c->comm, s->mesh->stream));
+  return PHX_OK;
+}
+
 static int allreduce_R(phx_system *s, phx_comm *c, int lo, int hi) {
   if (c->nranks == 1) return PHX_OK;
   double *R = kr_scal(s) + R_OFF + lo;
@@ -176,16 +192,19 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     if (!pc_all) PHX_CHECK(phx_krylov_precond_disable(s));
     const KrVecs V = kr_vecs(s);  // after the vote: the preconditioner decides where phat / shat live
     const int check_every = pc_all ? 2 : 8;
+    const bool exact = s->precond_state == 1 && s->precond->dist;   // the same on every rank (set up from all-reduced numbers)
     const double bb = s->scal_h[S_BB];
     int64_t it = 0;
     double relres = bb == 0.0 ? 0.0 : 1.0;
     while (bb != 0.0 && it < max_iter) {
       PHX_CHECK(phx_krylov_phase(s, 7));
+      if (exact) { PHX_CHECK(allgather_carries(s, c)); PHX_CHECK(phx_krylov_phase(s, 9)); }
       PHX_CHECK(halo_exchange(s, c, H, V.phat));
       PHX_CHECK(phx_krylov_phase(s, 2));
       PHX_CHECK(allreduce_R(s, c, R_RV, R_RV + 1));
       PHX_CHECK(phx_krylov_phase(s, 3));
       PHX_CHECK(phx_krylov_phase(s, 8));
+      if (exact) { PHX_CHECK(allgather_carries(s, c)); PHX_CHECK(phx_krylov_phase(s, 10)); }
       PHX_CHECK(halo_exchange(s, c, H, V.shat));
       PHX_CHECK(phx_krylov_phase(s, 4));
       PHX_CHECK(allreduce_R(s, c, R_TS, R_TT + 1));

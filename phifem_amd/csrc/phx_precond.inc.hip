@@ -25,6 +25,8 @@
 
 #include <map>
 
+#define PHX_PRECOND_MARGIN 4   // lattice planes between the active vertices and the Dirichlet faces of the box
+
 struct DstPlan {
   int L = 0, nstage = 0, pairs = 0, tp = 0;  // pairs per block, threads per pair (L / 8)
   int slot = 0;                 // lanes reserved per pair: tp, or 32 / 64 when the pair lives inside one wave
@@ -97,7 +99,8 @@ static int dst_get_plan(int device, int L, bool f32, DstPlan *out) {
   while ((2 * P.pairs * ZLEN(L) + 2 * L) * el <= budget && 2 * P.pairs * P.slot <= max_threads &&
          2 * P.pairs <= max_pairs)
     P.pairs *= 2;
-  P.scr = 2 * (P.tp + (P.tp + 7) / 8 + 1);  // in complex values of the transform type; the scan runs in f64
+  // scan scratch, in complex values of the transform type (the scan runs in f64); none in wave mode (shuffles)
+  P.scr = P.wave ? 0 : 2 * (P.tp + (P.tp + 7) / 8 + 1);
   P.tab_off = P.pairs * (ZLEN(L) + P.scr);            // LDS copies of the tables: twiddles, then sines
   P.lds_elems = P.tab_off + L + (L / 2 + 2 + 1) / 2;
   std::vector<double2> tw((size_t)L);
@@ -287,9 +290,8 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
     }
   }
   psync<WAVE>();
-  C2<double> *tot = reinterpret_cast<C2<double> *>(scr), *gt = tot + tp;
+  C2<double> run = mk<double>(0.0, 0.0);
   if (live) {
-    C2<double> run = mk<double>(0.0, 0.0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k = 4 * t + i;
@@ -303,19 +305,35 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
       run = cadd(run, mk<double>((double)R.x, (double)R.y));
       c[i] = run;
     }
-    tot[t] = run;
   }
-  psync<WAVE>();
-  if (live && t < (tp + 7) / 8) {
-    C2<double> g = mk<double>(0.0, 0.0);
-    for (int q = 8 * t; q < min(8 * t + 8, tp); ++q) g = cadd(g, tot[q]);
-    gt[t] = g;
+  C2<double> E = mk<double>(0.0, 0.0);   // sum of the totals of the threads before this one
+  if constexpr (WAVE) {
+    // the pair sits inside one wavefront: prefix sum of the per-thread totals by shuffles -- no scratch in LDS
+    // (which lets a fifth block fit a CU at L = 192), no synchronisation.  Idle lanes carry zeros.
+    C2<double> inc = run;
+    for (int d = 1; d < P.slot; d <<= 1) {
+      const double ux = __shfl_up(inc.x, d, P.slot), uy = __shfl_up(inc.y, d, P.slot);
+      if (t >= d) { inc.x += ux; inc.y += uy; }
+    }
+    // exclusive prefix = the inclusive one of the lane below (no subtraction: that would cost the low bits)
+    const double ex = __shfl_up(inc.x, 1, P.slot), ey = __shfl_up(inc.y, 1, P.slot);
+    E = t == 0 ? mk<double>(0.0, 0.0) : mk<double>(ex, ey);
+  } else {
+    C2<double> *tot = reinterpret_cast<C2<double> *>(scr), *gt = tot + tp;
+    if (live) tot[t] = run;
+    psync<WAVE>();
+    if (live && t < (tp + 7) / 8) {
+      C2<double> g = mk<double>(0.0, 0.0);
+      for (int q = 8 * t; q < min(8 * t + 8, tp); ++q) g = cadd(g, tot[q]);
+      gt[t] = g;
+    }
+    psync<WAVE>();
+    if (live) {
+      for (int g = 0; g < (t >> 3); ++g) E = cadd(E, gt[g]);
+      for (int q = t & ~7; q < t; ++q) E = cadd(E, tot[q]);
+    }
   }
-  psync<WAVE>();
   if (live) {
-    C2<double> E = mk<double>(0.0, 0.0);
-    for (int g = 0; g < (t >> 3); ++g) E = cadd(E, gt[g]);
-    for (int q = t & ~7; q < t; ++q) E = cadd(E, tot[q]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const C2<double> F = cadd(E, c[i]);
@@ -358,11 +376,28 @@ struct BoxGrid {
 template <typename T, int IO, bool WAVE>
 __global__ void __launch_bounds__(1024)
 k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gmap,
-        const double *__restrict__ vin, double *__restrict__ vout, const double *__restrict__ dscale) {
+        const double *__restrict__ vin, double *__restrict__ vout, const double *__restrict__ dscale,
+        const uint8_t *__restrict__ line_any) {
   extern __shared__ double2 zs_raw[];
   C2<T> *zs = reinterpret_cast<C2<T> *>(zs_raw);
   const int pr = threadIdx.x / P.slot, t = threadIdx.x % P.slot;  // slot >= tp lanes per pair
   const int64_t nlines = (int64_t)g.m[1] * g.m[2];
+  if ((IO == 1 || IO == 2) && line_any) {
+    // x lines that hold no active vertex (63 % of the lattice lies outside the domain): their input is zero (IO = 1)
+    // and their output is never gathered (IO = 2).  A block whose lines are all of that kind skips the transform:
+    // the forward pass only clears its lines, the backward pass does nothing.  Uniform over the block.
+    const int64_t l0 = (int64_t)blockIdx.x * P.pairs * 2, l1 = min(l0 + 2 * P.pairs, nlines);
+    bool any = false;
+    for (int64_t l = l0; l < l1; ++l) any |= line_any[l] != 0;
+    if (!any) {
+      if (IO == 1)
+        for (int64_t l = l0; l < l1; ++l) {
+          T *row = G + ((l % g.m[1]) * g.pitch + (l / g.m[1]) * g.plane);
+          for (int k = threadIdx.x; k < g.m[0]; k += blockDim.x) row[k] = T(0);
+        }
+      return;
+    }
+  }
   const int64_t line0 = ((int64_t)blockIdx.x * P.pairs + pr) * 2;
   const bool live = line0 < nlines && t < P.tp;
   C2<T> *w = zs + (size_t)pr * ZLEN(P.L);
@@ -543,12 +578,24 @@ struct phx_box_precond {
   int64_t nrest = 0;
   double *lam[3] = {nullptr, nullptr, nullptr};
   int lo[3] = {0, 0, 0};     // lattice index of the lower Dirichlet face
+  // slab-exact mode (multi-GPU): this rank holds `g.m[2]` planes of a GLOBAL column of zN planes starting at the
+  // 1-based global index zk0; carries of the tridiagonal recurrences cross ranks through one all-gather
+  bool dist = false;
+  int zN = 0, zk0 = 1, nranks = 1, rank = 0;
+  int planes[16] = {0};      // planes held by every rank
+  bool carry_borrowed = false;    // carry_send / carry_recv belong to the driver (torch tensors)
+  double *carry_send = nullptr;   // [2][ncol]  {Wl, Yl} of this rank (zero-inflow carries)
+  double *carry_recv = nullptr;   // [nranks][2][ncol]
+  double *tri_in = nullptr;       // [3][ncol]  {W_in, Y_in, y1}
+  uint8_t *line_any = nullptr;  // [m1 * m2] x line holds at least one mapped lattice point (nullptr: all do)
   bool ztri = true;          // z direction: tridiagonal solve (default) or forward / inverse sine transform in LDS
 };
 
 static void box_precond_free(phx_box_precond *bp) {
   if (!bp) return;
-  (void)phx_free(bp->G); (void)phx_free(bp->gmap); (void)phx_free(bp->dscale); (void)phx_free(bp->iscale);
+  (void)phx_free(bp->G); (void)phx_free(bp->gmap); (void)phx_free(bp->dscale); (void)phx_free(bp->iscale); (void)phx_free(bp->line_any);
+  if (!bp->carry_borrowed) { (void)phx_free(bp->carry_send); (void)phx_free(bp->carry_recv); }
+  (void)phx_free(bp->tri_in);
   (void)phx_free(bp->rest);
   for (int a = 0; a < 3; ++a) (void)phx_free(bp->lam[a]);
   delete bp;
@@ -603,20 +650,30 @@ static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const
   return PHX_OK;
 }
 
+static TriArgs box_tri_args(const phx_box_precond *bp) {
+  const BoxGrid &g = bp->g;
+  TriArgs a;
+  memset(&a, 0, sizeof(a));
+  a.m0 = g.m[0]; a.m1 = g.m[1]; a.pitch = (int)g.pitch; a.plane = g.plane;
+  a.nloc = g.m[2];
+  a.k0 = bp->dist ? bp->zk0 : 1;
+  a.N = bp->dist ? bp->zN : g.m[2];
+  a.cz = g.c[2]; a.scale_xy = (2.0 / g.L[0]) * (2.0 / g.L[1]);
+  a.lamx = g.lam[0]; a.lamy = g.lam[1];
+  if (bp->dist) {
+    const int64_t ncol = g.pitch * g.m[1];
+    a.wl = bp->carry_send; a.yl = bp->carry_send + ncol;
+    a.w_in = bp->tri_in; a.y_in = bp->tri_in + ncol; a.y1 = bp->tri_in + 2 * ncol;
+  }
+  return a;
+}
+
 // z pass on G: tridiagonal solve per (kx, ky) column, or forward sine transform, 1 / lambda, inverse in LDS
 template <typename T>
 static int box_pass_z_t(phx_box_precond *bp, hipStream_t st) {
   const BoxGrid &g = bp->g;
   T *G = static_cast<T *>(bp->G);
-  if (bp->ztri) {
-    TriArgs a;
-    memset(&a, 0, sizeof(a));
-    a.m0 = g.m[0]; a.m1 = g.m[1]; a.pitch = (int)g.pitch; a.plane = g.plane;
-    a.nloc = g.m[2]; a.k0 = 1; a.N = g.m[2];
-    a.cz = g.c[2]; a.scale_xy = (2.0 / g.L[0]) * (2.0 / g.L[1]);
-    a.lamx = g.lam[0]; a.lamy = g.lam[1];
-    return tri_launch<T, 0>(a, G, st);
-  }
+  if (bp->ztri) return tri_launch<T, 0>(box_tri_args(bp), G, st);
   const DstPlan &pz = bp->plan[2];
   const int W = 2 * pz.pairs, ncb = (g.m[0] + W - 1) / W;
   const dim3 grid((unsigned)((int64_t)ncb * g.m[1])), block((unsigned)(pz.pairs * pz.slot));
@@ -627,27 +684,54 @@ static int box_pass_z_t(phx_box_precond *bp, hipStream_t st) {
   return PHX_OK;
 }
 
+template <typename T>
+static int box_pass_y_t(phx_box_precond *bp, hipStream_t st, phx_system *prof) {
+  const BoxGrid &g = bp->g;
+  if (g.m[2] <= 0) return PHX_OK;
+  const DstPlan &py = bp->plan[1];
+  T *G = static_cast<T *>(bp->G);
+  const size_t el = sizeof(T) * 2;
+  const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
+  const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.slot));
+  if (prof) PHX_CHECK(prof_begin(prof, 1));
+  if (py.wave) k_dst_s<T, 1, false, true><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
+  else k_dst_s<T, 1, false, false><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
+  if (prof) PHX_CHECK(prof_end(prof, 1));
+  PHX_HIP(hipGetLastError());
+  return PHX_OK;
+}
+
+// slab-exact mode, first half of the middle passes: y transform, then the zero-inflow carries of this rank's
+// planes into carry_send (the driver all-gathers them into carry_recv)
+template <typename T>
+static int box_middle_A_t(phx_box_precond *bp, hipStream_t st, phx_system *prof) {
+  PHX_CHECK(box_pass_y_t<T>(bp, st, prof));
+  return tri_launch<T, 1>(box_tri_args(bp), static_cast<T *>(bp->G), st);
+}
+// second half: interface recurrences over the gathered carries, z solve with inflows, inverse y transform
+template <typename T>
+static int box_middle_B_t(phx_box_precond *bp, hipStream_t st, phx_system *prof) {
+  const BoxGrid &g = bp->g;
+  const int64_t ncol = g.pitch * g.m[1];
+  TriArgs a = box_tri_args(bp);
+  TriRanks R;
+  memset(&R, 0, sizeof(R));
+  R.nranks = bp->nranks; R.rank = bp->rank;
+  for (int r = 0; r < bp->nranks; ++r) R.planes[r] = bp->planes[r];
+  if (a.cz != 0.0)
+    k_tri_interface<<<dim3((unsigned)phx_div_up(ncol, 256)), dim3(256), 0, st>>>(a, R, bp->carry_recv, ncol, bp->tri_in,
+                                                                                bp->tri_in + ncol, bp->tri_in + 2 * ncol);
+  PHX_HIP(hipGetLastError());
+  if (g.m[2] > 0) PHX_CHECK((tri_launch<T, 2>(a, static_cast<T *>(bp->G), st)));
+  return box_pass_y_t<T>(bp, st, prof);
+}
+
 // the three middle passes (y, z solve, y) on G
 template <typename T>
 static int box_solve_middle_t(phx_box_precond *bp, hipStream_t st, phx_system *prof) {
-  const BoxGrid &g = bp->g;
-  const DstPlan &py = bp->plan[1];
-  T *G = static_cast<T *>(bp->G);
-  const size_t el = sizeof(T) * 2;  // LDS bytes per complex value
-  for (int pass = 0; pass < 3; ++pass) {
-    if (pass == 1) {
-      PHX_CHECK(box_pass_z_t<T>(bp, st));
-    } else {
-      const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
-      const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.slot));
-      if (prof) PHX_CHECK(prof_begin(prof, 1));
-      if (py.wave) k_dst_s<T, 1, false, true><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
-      else k_dst_s<T, 1, false, false><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
-      if (prof) PHX_CHECK(prof_end(prof, 1));
-    }
-  }
-  PHX_HIP(hipGetLastError());
-  return PHX_OK;
+  PHX_CHECK(box_pass_y_t<T>(bp, st, prof));
+  PHX_CHECK(box_pass_z_t<T>(bp, st));
+  return box_pass_y_t<T>(bp, st, prof);
 }
 static int box_solve_middle(phx_box_precond *bp, hipStream_t st, phx_system *prof = nullptr) {
   return bp->f32 ? box_solve_middle_t<float>(bp, st, prof) : box_solve_middle_t<double>(bp, st, prof);
@@ -657,14 +741,15 @@ template <typename T, int IO>
 static int box_pass_x_t(phx_box_precond *bp, hipStream_t st, const double *vin, double *vout) {
   const BoxGrid &g = bp->g;
   const DstPlan &px = bp->plan[0];
+  if (g.m[2] <= 0) return PHX_OK;
   const int64_t npairs = ((int64_t)g.m[1] * g.m[2] + 1) / 2;
   const dim3 grid((unsigned)phx_div_up(npairs, px.pairs)), block((unsigned)(px.pairs * px.slot));
   if (px.wave)
     k_dst_x<T, IO, true><<<grid, block, (size_t)px.lds_elems * sizeof(T) * 2, st>>>(
-        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, IO == 1 ? bp->iscale : bp->dscale);
+        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, IO == 1 ? bp->iscale : bp->dscale, bp->line_any);
   else
     k_dst_x<T, IO, false><<<grid, block, (size_t)px.lds_elems * sizeof(T) * 2, st>>>(
-        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, IO == 1 ? bp->iscale : bp->dscale);
+        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, IO == 1 ? bp->iscale : bp->dscale, bp->line_any);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
 }
@@ -800,6 +885,18 @@ __global__ void k_box_gmap(BoxGrid g, int lo0, int lo1, int lo2, int64_t n0, int
   gmap[e] = q;
 }
 
+// one wavefront per x line: does any lattice point of the line carry a DoF?
+__global__ void k_line_any(BoxGrid g, const int32_t *__restrict__ gmap, uint8_t *__restrict__ line_any) {
+  const int64_t l = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (l >= (int64_t)g.m[1] * g.m[2]) return;
+  const int32_t *row = gmap + ((l % g.m[1]) * g.pitch + (l / g.m[1]) * g.plane);
+  bool any = false;
+  for (int k = lane; k < g.m[0]; k += 64) any |= row[k] >= 0;
+  const unsigned long long b = __ballot(any);
+  if (lane == 0) line_any[l] = b != 0ull;
+}
+
 struct SelNotU { const int32_t *perm; int32_t nu; __host__ __device__ bool operator()(const int32_t &i) const { return perm[i] >= nu; } };
 
 __global__ void k_copy_list(int64_t n, const int32_t *__restrict__ list, const double *__restrict__ vin,
@@ -827,27 +924,100 @@ __global__ void k_dscale_weighted(int64_t n, const int32_t *__restrict__ perm, c
 
 // Builds the preconditioner of system `s` (state 1) or marks it not applicable (state -1).
 #define PHX_PRECOND_MARGIN 4
-static int box_precond_setup(phx_system *s) {
+// lattice bounding box of this rank's (owned) active u DoFs in LOCAL lattice coordinates; hbb[3] < 0: none
+static int box_local_bbox(phx_system *s, bool p2, int hbb[6]) {
   phx_mesh *m = s->mesh;
-  s->precond_state = -1;
-  s->precond_veto = true;   // until built, or found to have nothing to build (multi-GPU vote, phx_solve.hip)
-  const bool p2 = s->u_p2_block && m->is_box && m->edges != nullptr;
-  const bool p1 = (m->is_box || m->on_box_lattice) && s->u_vertex_block;
-  if (!m->precond || (!p1 && !p2)) return PHX_OK;
   hipStream_t st = m->stream;
-  const int64_t n0 = m->box_n[0] + 1, n1 = m->box_n[1] + 1, n2 = m->gdim == 3 ? m->box_n[2] + 1 : 1;
-  int *dbb = nullptr, hbb[6] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1};
-  PHX_HIP(phx_malloc(&dbb, sizeof(hbb)));
-  PHX_HIP(hipMemcpyAsync(dbb, hbb, sizeof(hbb), hipMemcpyHostToDevice, st));
+  const int64_t n0 = m->box_n[0] + 1, n1 = m->box_n[1] + 1;
+  int *dbb = nullptr;
+  const int init[6] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1};
+  for (int i = 0; i < 6; ++i) hbb[i] = init[i];
+  PHX_HIP(phx_malloc(&dbb, sizeof(init)));
+  PHX_HIP(hipMemcpyAsync(dbb, init, sizeof(init), hipMemcpyHostToDevice, st));
   if (p2)
     k_active_bbox_p2<<<dim3((unsigned)std::min<int64_t>(phx_div_up(s->nent, 256), 1024)), dim3(256), 0, st>>>(
         s->nent, m->nv, n0, n1, m->edges, s->dof_of_vertex_u, s->iperm, s->own, dbb);
   else
     k_active_bbox<<<dim3((unsigned)std::min<int64_t>(phx_div_up(m->nv, 256), 1024)), dim3(256), 0, st>>>(
         m->nv, n0, n1, s->dof_of_vertex_u, s->iperm, s->own, m->v2lat, dbb);
-  PHX_HIP(hipMemcpyAsync(hbb, dbb, sizeof(hbb), hipMemcpyDeviceToHost, st));
+  PHX_HIP(hipMemcpyAsync(hbb, dbb, sizeof(init), hipMemcpyDeviceToHost, st));
   PHX_HIP(hipStreamSynchronize(st));
   PHX_HIP(phx_free(dbb));
+  return PHX_OK;
+}
+
+// Builds the lattice of transform lengths L (interior points L - 1) whose lower Dirichlet face sits at the LOCAL
+// lattice index lo, with its maps and scalings, and installs it as the preconditioner of `s` (state 1).
+static int box_precond_build(phx_system *s, bool p2, const int L[3], const int lo[3], phx_box_precond **out) {
+  phx_mesh *m = s->mesh;
+  hipStream_t st = m->stream;
+  const int64_t n0 = m->box_n[0] + 1, n1 = m->box_n[1] + 1, n2 = m->gdim == 3 ? m->box_n[2] + 1 : 1;
+  phx_box_precond *bp = new phx_box_precond();
+  // 2-D: the lattice gets a dummy third axis with coefficient 0 (one real plane; the z pass only scales)
+  // P2: the lattice has spacing h / 2
+  const double hs = p2 ? 0.5 : 1.0;
+  const double h[3] = {hs * m->box_h[0], hs * m->box_h[1], hs * m->box_h[2]};
+  const double c3[3] = {h[1] * h[2] / h[0], h[0] * h[2] / h[1], h[0] * h[1] / h[2]};
+  const double c2[3] = {h[1] / h[0], h[0] / h[1], 0.0};
+  int rc = box_grid_setup(bp, m->device, L, m->gdim == 3 ? c3 : c2, m->precond == 2);
+  if (rc != PHX_OK) { box_precond_free(bp); return rc; }
+  for (int a = 0; a < 3; ++a) bp->lo[a] = lo[a];
+  const int64_t tot = bp->g.plane * bp->g.m[2];
+  if (phx_malloc(&bp->gmap, sizeof(int32_t) * (size_t)std::max<int64_t>(tot, 1)) != hipSuccess ||
+      (!s->u_unscaled && phx_malloc(&bp->dscale, sizeof(double) * (size_t)std::max<int64_t>(s->n, 1)) != hipSuccess)) {
+    box_precond_free(bp);
+    return PHX_ERR_HIP;
+  }
+  if (tot > 0) {
+    if (p2) {
+      if (hipMemsetAsync(bp->gmap, 0xff, sizeof(int32_t) * (size_t)tot, st) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+      k_box_gmap_p2<<<dim3((unsigned)phx_div_up(s->nent, 256)), dim3(256), 0, st>>>(
+          bp->g, lo[0], lo[1], lo[2], s->nent, m->nv, n0, n1, m->edges, s->dof_of_vertex_u, s->iperm, s->own, bp->gmap);
+    } else {
+      k_box_gmap<<<dim3((unsigned)phx_div_up(tot, 256)), dim3(256), 0, st>>>(
+          bp->g, lo[0], lo[1], lo[2], n0, n1, n2, s->dof_of_vertex_u, s->iperm, s->own, m->lat2v, bp->gmap);
+    }
+    const int64_t nlines = (int64_t)bp->g.m[1] * bp->g.m[2];
+    if (phx_malloc(&bp->line_any, (size_t)nlines) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+    k_line_any<<<dim3((unsigned)phx_div_up(nlines * 64, 256)), dim3(256), 0, st>>>(bp->g, bp->gmap, bp->line_any);
+  }
+  if (s->n > 0) {
+    if (s->u_weighted) {
+      if (phx_malloc(&bp->iscale, sizeof(double) * (size_t)s->n) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+      const double *cc = m->gdim == 3 ? c3 : c2;
+      k_dscale_weighted<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(
+          s->n, s->perm, s->diag, 2.0 * (cc[0] + cc[1] + cc[2]), bp->dscale, bp->iscale);
+    } else if (!s->u_unscaled) {   // unscaled u columns: P = K_box^-1 itself, nothing to multiply on the way out
+      k_dscale<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(s->n, s->perm, s->diag, bp->dscale);
+    }
+    if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+    // rows outside the u block (active rows are numbered u first): P is the identity there.  The other
+    // entries of phat / shat (u rows this rank does not own) are never written and stay zero.
+    rc = phx_select_indices(st, s->n, SelNotU{s->perm, (int32_t)s->nu}, &bp->rest, &bp->nrest);
+    if (rc != PHX_OK) { box_precond_free(bp); return rc; }
+  }
+  if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+  bp->own_ptr = s->own;
+  *out = bp;
+  return PHX_OK;
+}
+
+static inline bool box_precond_kinds(const phx_system *s, bool *p2) {
+  const phx_mesh *m = s->mesh;
+  *p2 = s->u_p2_block && m->is_box && m->edges != nullptr;
+  const bool p1 = (m->is_box || m->on_box_lattice) && s->u_vertex_block;
+  return m->precond != 0 && (p1 || *p2);
+}
+
+// Builds the (rank-local) preconditioner of system `s` (state 1) or marks it not applicable (state -1).
+static int box_precond_setup(phx_system *s) {
+  phx_mesh *m = s->mesh;
+  s->precond_state = -1;
+  s->precond_veto = true;   // until built, or found to have nothing to build (multi-GPU vote, phx_solve.hip)
+  bool p2;
+  if (!box_precond_kinds(s, &p2)) return PHX_OK;
+  int hbb[6];
+  PHX_CHECK(box_local_bbox(s, p2, hbb));
   if (hbb[3] < 0) { s->precond_veto = false; return PHX_OK; }  // no (owned) active u DoF here: nothing to precondition
   int L[3], lo[3];
   bool ztri = true;
@@ -861,59 +1031,124 @@ static int box_precond_setup(phx_system *s) {
     if (L[a] < 0 || L[a] > 1025) return PHX_OK;  // larger than the longest transform / column: stay with Jacobi
     lo[a] = hbb[a] - 1 - (L[a] - 1 - extent) / 2;
   }
-  phx_box_precond *bp = new phx_box_precond();
-  // 2-D: the lattice gets a dummy third axis with coefficient 0 (one real plane; the z passes are the identity)
-  // P2: the lattice has spacing h / 2
-  const double hs = p2 ? 0.5 : 1.0;
-  const double h[3] = {hs * m->box_h[0], hs * m->box_h[1], hs * m->box_h[2]};
-  const double c3[3] = {h[1] * h[2] / h[0], h[0] * h[2] / h[1], h[0] * h[1] / h[2]};
-  const double c2[3] = {h[1] / h[0], h[0] / h[1], 0.0};
-  int rc = box_grid_setup(bp, m->device, L, m->gdim == 3 ? c3 : c2, m->precond == 2);
-  if (rc != PHX_OK) { box_precond_free(bp); return rc; }
-  for (int a = 0; a < 3; ++a) bp->lo[a] = lo[a];
-  const int64_t tot = bp->g.plane * bp->g.m[2];
-  if (phx_malloc(&bp->gmap, sizeof(int32_t) * (size_t)tot) != hipSuccess ||
-      (!s->u_unscaled && phx_malloc(&bp->dscale, sizeof(double) * (size_t)s->n) != hipSuccess)) {
-    box_precond_free(bp);
-    return PHX_ERR_HIP;
-  }
-  if (p2) {
-    if (hipMemsetAsync(bp->gmap, 0xff, sizeof(int32_t) * (size_t)tot, st) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
-    k_box_gmap_p2<<<dim3((unsigned)phx_div_up(s->nent, 256)), dim3(256), 0, st>>>(
-        bp->g, lo[0], lo[1], lo[2], s->nent, m->nv, n0, n1, m->edges, s->dof_of_vertex_u, s->iperm, s->own, bp->gmap);
-  } else {
-    k_box_gmap<<<dim3((unsigned)phx_div_up(tot, 256)), dim3(256), 0, st>>>(
-        bp->g, lo[0], lo[1], lo[2], n0, n1, n2, s->dof_of_vertex_u, s->iperm, s->own, m->lat2v, bp->gmap);
-  }
-  if (s->u_weighted) {
-    if (phx_malloc(&bp->iscale, sizeof(double) * (size_t)s->n) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
-    const double *cc = m->gdim == 3 ? c3 : c2;
-    k_dscale_weighted<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(
-        s->n, s->perm, s->diag, 2.0 * (cc[0] + cc[1] + cc[2]), bp->dscale, bp->iscale);
-  } else if (!s->u_unscaled) {   // unscaled u columns: P = K_box^-1 itself, nothing to multiply on the way out
-    k_dscale<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(s->n, s->perm, s->diag, bp->dscale);
-  }
-  if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
-  // rows outside the u block (active rows are numbered u first): P is the identity there.  The other
-  // entries of phat / shat (u rows this rank does not own) are never written and stay zero.
-  rc = phx_select_indices(st, s->n, SelNotU{s->perm, (int32_t)s->nu}, &bp->rest, &bp->nrest);
-  if (rc != PHX_OK) { box_precond_free(bp); return rc; }
-  bp->own_ptr = s->own;
+  phx_box_precond *bp = nullptr;
+  PHX_CHECK(box_precond_build(s, p2, L, lo, &bp));
   s->precond = bp;
   s->precond_state = 1;
   s->precond_veto = false;
   return PHX_OK;
 }
 
-// vout = P vin:  u rows: D K_box^-1 (the SELL copy holds A D^-1, so P = D M^-1), all other rows: identity
-static int box_precond_apply(phx_system *s, const double *vin, double *vout) {
+// ---- slab-exact preconditioner of a partitioned box (multi-GPU) -------------------------------------------------
+// Every rank holds whole x-y planes of ONE global lattice box: the sine transforms in x and y are rank-local, and
+// the tridiagonal recurrences in z (phx_tridiag.inc.hip) continue across ranks through two carries per (kx, ky)
+// column and rank -- one all-gather of 16 bytes x columns per application, issued by the driver between the two
+// halves (phases 7 / 9 and 8 / 10).  The result is K_box^-1 of the GLOBAL box, not a block-Jacobi over slabs
+// (whose iteration count grew from 51 to 78-97 on 2-8 thin slabs).
+extern "C" int phx_precond_local_bbox(phx_system *s, int64_t *out6) {
+  PHX_HIP(hipSetDevice(s->mesh->device));
+  for (int a = 0; a < 3; ++a) { out6[a] = INT64_MAX; out6[3 + a] = -1; }
+  bool p2;
+  if (!box_precond_kinds(s, &p2) || p2 || s->n == 0) return PHX_OK;
+  int hbb[6];
+  PHX_CHECK(box_local_bbox(s, false, hbb));
+  if (hbb[3] < 0) return PHX_OK;
+  for (int a = 0; a < 3; ++a) {   // GLOBAL vertex indices
+    out6[a] = hbb[a] + s->mesh->box_off[a];
+    out6[3 + a] = hbb[3 + a] + s->mesh->box_off[a];
+  }
+  return PHX_OK;
+}
+
+// bbox6: min / max GLOBAL vertex indices of the active u DoFs of ALL ranks; zb[nranks + 1]: rank r owns the global
+// vertex planes [zb[r], zb[r+1]).  *ncol_out: columns (kx, ky) of the lattice = doubles per carry array, 0 when the
+// preconditioner cannot be built (a transform longer than 1024, a rank with more than 1024 planes, P2, ...): then
+// every rank -- they all see the same numbers -- keeps Jacobi.
+extern "C" int phx_precond_setup_global(phx_system *s, const int64_t *bbox6, int nranks, int rank, const int64_t *zb,
+                                        int64_t *ncol_out) {
+  phx_mesh *m = s->mesh;
+  PHX_HIP(hipSetDevice(m->device));
+  *ncol_out = 0;
+  if (s->precond_state == 1) { phx_box_precond_destroy(s->precond); s->precond = nullptr; }
+  s->precond_state = -1;
+  s->precond_veto = true;
+  bool p2;
+  const bool kinds = s->n > 0 ? box_precond_kinds(s, &p2) : (m->precond != 0 && m->is_box);
+  PHX_REQUIRE(nranks >= 1 && nranks <= 16 && rank >= 0 && rank < nranks, PHX_ERR_VALUE, "bad rank layout");
+  if (!kinds || (s->n > 0 && p2) || m->gdim != 3 || bbox6[5] < 0) return PHX_OK;
+  int L[3], lo_g[3];
+  for (int a = 0; a < 2; ++a) {
+    const int extent = (int)(bbox6[3 + a] - bbox6[a] + 1);
+    L[a] = dst_pick_length(extent + 2 * PHX_PRECOND_MARGIN + 1);
+    if (L[a] < 0) return PHX_OK;
+    lo_g[a] = (int)bbox6[a] - 1 - (L[a] - 1 - extent) / 2;
+  }
+  const int zext = (int)(bbox6[5] - bbox6[2] + 1), N = zext + 2 * PHX_PRECOND_MARGIN;
+  lo_g[2] = (int)bbox6[2] - 1 - PHX_PRECOND_MARGIN;
+  int planes[16], k0r = 1, first_local = 0;
+  for (int r = 0; r < nranks; ++r) {
+    const int64_t kf = r == 0 ? lo_g[2] + 1 : std::max<int64_t>(zb[r], lo_g[2] + 1);
+    const int64_t ke = r == nranks - 1 ? lo_g[2] + N + 1 : std::min<int64_t>(zb[r + 1], lo_g[2] + N + 1);
+    planes[r] = (int)std::max<int64_t>(0, ke - kf);
+    if (planes[r] > 1024) return PHX_OK;
+    if (r == rank) { k0r = (int)(kf - lo_g[2]); first_local = (int)kf; }
+  }
+  L[2] = planes[rank] + 1;
+  const int lo[3] = {lo_g[0] - (int)m->box_off[0], lo_g[1] - (int)m->box_off[1], first_local - 1 - (int)m->box_off[2]};
+  phx_box_precond *bp = nullptr;
+  PHX_CHECK(box_precond_build(s, false, L, lo, &bp));
+  bp->dist = true;
+  bp->zN = N; bp->zk0 = k0r; bp->nranks = nranks; bp->rank = rank;
+  for (int r = 0; r < nranks; ++r) bp->planes[r] = planes[r];
+  const int64_t ncol = bp->g.pitch * bp->g.m[1];
+  if (phx_malloc(&bp->tri_in, sizeof(double) * 3 * (size_t)ncol) != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
+  PHX_HIP(hipMemsetAsync(bp->tri_in, 0, sizeof(double) * 3 * (size_t)ncol, m->stream));
+  s->precond = bp;
+  s->precond_state = 1;
+  s->precond_veto = false;
+  *ncol_out = ncol;
+  return PHX_OK;
+}
+
+// the all-gather buffers of the carries (caller-owned device memory, alive as long as the system's preconditioner):
+// send[2 ncol], recv[nranks][2 ncol]
+extern "C" int phx_precond_set_carry_buffers(phx_system *s, double *send, double *recv) {
+  PHX_REQUIRE(s->precond_state == 1 && s->precond->dist, PHX_ERR_VALUE, "no slab-exact preconditioner is set up");
+  s->precond->carry_send = send;
+  s->precond->carry_recv = recv;
+  s->precond->carry_borrowed = true;
+  return PHX_OK;
+}
+
+// out[4] = {slab-exact preconditioner active (0/1), doubles each rank contributes to the all-gather, planes held here,
+//           planes of the global column}
+extern "C" int phx_precond_dist_info(const phx_system *s, int64_t *out4) {
+  for (int i = 0; i < 4; ++i) out4[i] = 0;
+  if (s->precond_state != 1 || !s->precond->dist) return PHX_OK;
+  const phx_box_precond *bp = s->precond;
+  out4[0] = 1; out4[1] = 2 * bp->g.pitch * bp->g.m[1]; out4[2] = bp->g.m[2]; out4[3] = bp->zN;
+  return PHX_OK;
+}
+
+// vout = P vin:  u rows: K_box^-1 (times D where the SELL copy holds A D^-1), all other rows: identity.
+// part 0: everything (rank-local preconditioner); parts 1 / 2: the halves of the slab-exact preconditioner before /
+// after the all-gather of the carries.
+static int box_precond_apply(phx_system *s, const double *vin, double *vout, int part = 0) {
   phx_box_precond *bp = s->precond;
   hipStream_t st = s->mesh->stream;
-  if (bp->nrest > 0)
-    k_copy_list<<<dim3((unsigned)phx_div_up(bp->nrest, 256)), dim3(256), 0, st>>>(bp->nrest, bp->rest, vin, vout);
-  PHX_CHECK(box_pass_x<1>(bp, st, vin, nullptr));
-  PHX_CHECK(box_solve_middle(bp, st, s));
-  PHX_CHECK(box_pass_x<2>(bp, st, nullptr, vout));
+  if (part == 0 && bp->dist) {
+    phx_set_error("the slab-exact preconditioner is applied in two halves around an all-gather");
+    return PHX_ERR_VALUE;
+  }
+  if (part != 2) {
+    if (bp->nrest > 0)
+      k_copy_list<<<dim3((unsigned)phx_div_up(bp->nrest, 256)), dim3(256), 0, st>>>(bp->nrest, bp->rest, vin, vout);
+    PHX_CHECK(box_pass_x<1>(bp, st, vin, nullptr));
+  }
+  if (part == 0) PHX_CHECK(box_solve_middle(bp, st, s));
+  else if (part == 1) PHX_CHECK(bp->f32 ? box_middle_A_t<float>(bp, st, s) : box_middle_A_t<double>(bp, st, s));
+  else PHX_CHECK(bp->f32 ? box_middle_B_t<float>(bp, st, s) : box_middle_B_t<double>(bp, st, s));
+  if (part != 1) PHX_CHECK(box_pass_x<2>(bp, st, nullptr, vout));
   return PHX_OK;
 }
 

@@ -1312,12 +1312,18 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       k_update_p<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.r, V.v, V.p, V.rhat, S);
       break;
     case 7:  // phat = P p   (before the halo exchange of phat and phase 2)
-      if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.p, V.phat));
+      if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.p, V.phat, s->precond->dist ? 1 : 0));
       else if (s->u_unscaled && n > 0) k_jacobi_u<<<vec_grid(n), block, 0, st>>>(n, s->nu, s->perm, s->diag, V.p, V.phat);
       break;
     case 8:  // shat = P s   (before the halo exchange of shat and phase 4)
-      if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.sv, V.shat));
+      if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.sv, V.shat, s->precond->dist ? 1 : 0));
       else if (s->u_unscaled && n > 0) k_jacobi_u<<<vec_grid(n), block, 0, st>>>(n, s->nu, s->perm, s->diag, V.sv, V.shat);
+      break;
+    case 9:   // slab-exact preconditioner: second half of phase 7, after the all-gather of the carries
+      if (s->precond_state == 1 && s->precond->dist) PHX_CHECK(box_precond_apply(s, V.p, V.phat, 2));
+      break;
+    case 10:  // ... of phase 8
+      if (s->precond_state == 1 && s->precond->dist) PHX_CHECK(box_precond_apply(s, V.sv, V.shat, 2));
       break;
     default:
       phx_set_error("unknown Krylov phase %d", phase);

@@ -70,6 +70,34 @@ class HipBackend:
 
     def precond_disable(self):
         self.L.check(self.L.lib.phx_krylov_precond_disable(self.sys))
+        self.exact = False
+
+    exact = False   # slab-exact preconditioner set up (phx_precond_setup_global)
+
+    def setup_exact_precond(self, dist, rank, world, zb, stage_cpu=False):
+        """Slab-exact box preconditioner (include/phifem_hip.h): one global lattice box around the active
+        vertices of all ranks, sine transforms in x / y rank-local, the tridiagonal z solves continued across
+        ranks through one all-gather of two carries per lattice column.  Collective; every rank ends up with the
+        same answer (`self.exact`)."""
+        L, torch = self.L, self.torch
+        bb = (C.c_int64 * 6)()
+        L.check(L.lib.phx_precond_local_bbox(self.sys, bb))
+        ctl = torch.device("cpu") if (stage_cpu or dist.get_backend() != "nccl") else self.dev
+        lo = torch.tensor([bb[0], bb[1], bb[2]], dtype=torch.int64, device=ctl)
+        hi = torch.tensor([bb[3], bb[4], bb[5]], dtype=torch.int64, device=ctl)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        g = (C.c_int64 * 6)(*[int(v) for v in lo.tolist() + hi.tolist()])
+        zbc = (C.c_int64 * (world + 1))(*[int(z) for z in zb])
+        ncol = C.c_int64(0)
+        L.check(L.lib.phx_precond_setup_global(self.sys, g, world, rank, zbc, C.byref(ncol)))
+        self.exact = ncol.value > 0
+        if self.exact:
+            self.carry_send = torch.zeros(2 * ncol.value, dtype=torch.float64, device=self.dev)
+            self.carry_recv = torch.zeros(world * 2 * ncol.value, dtype=torch.float64, device=self.dev)
+            L.check(L.lib.phx_precond_set_carry_buffers(self.sys, C.c_void_p(self.carry_send.data_ptr()),
+                                                        C.c_void_p(self.carry_recv.data_ptr())))
+        return self.exact
 
     def finish(self, out):
         self.L.check(self.L.lib.phx_krylov_finish(self.sys, C.c_void_p(out.data_ptr()), self.L.DEVICE))
@@ -209,6 +237,19 @@ class DistributedSolver:
         if self.world > 1:
             self.dist.all_reduce(self.scal[R_OFF + lo:R_OFF + hi])
 
+    def _allgather_carries(self):
+        """Slab-exact preconditioner: all-gather of the tridiagonal carries between its two halves."""
+        b = self.b
+        if self.world == 1:
+            b.carry_recv.copy_(b.carry_send)
+        elif self.stage_cpu:
+            send = b.carry_send.cpu()
+            recv = self.torch.empty(self.world * send.numel(), dtype=send.dtype)
+            self.dist.all_gather_into_tensor(recv, send)
+            b.carry_recv.copy_(recv)
+        else:
+            self.dist.all_gather_into_tensor(b.carry_recv, b.carry_send)
+
     def solve(self, out, profile_spmv=False):
         b = self.b
         if profile_spmv:
@@ -230,17 +271,24 @@ class DistributedSolver:
         # the SpMV inputs are phat / shat whenever the system keeps them apart from p / s: box preconditioner,
         # or the u-block Jacobi of a structured system (the same on every rank: all slabs are built alike)
         hat = pc or getattr(b, "precond_active", lambda: False)()
+        exact = bool(pc and getattr(b, "exact", False))
         vp, vs = (self.phat, self.shat) if hat else (self.p, self.s)
         check_every = 2 if pc else self.check_every
         while bb != 0.0 and it < self.max_iter:
             if hat:
                 b.phase(7)
+                if exact:
+                    self._allgather_carries()
+                    b.phase(9)
             self.halo_exchange(vp)
             b.phase(2)
             self._allreduce(R_RV, R_RV + 1)
             b.phase(3)
             if hat:
                 b.phase(8)
+                if exact:
+                    self._allgather_carries()
+                    b.phase(10)
             self.halo_exchange(vs)
             b.phase(4)
             self._allreduce(R_TS, R_TT + 1)
@@ -259,7 +307,7 @@ class DistributedSolver:
         b.synchronize()
         dt = time.perf_counter() - t0
         st = {"iterations": it, "relres": relres, "seconds": dt, "n_owned": self.n_owned,
-              "converged": bool(relres <= self.rtol), "precond_all": pc}
+              "converged": bool(relres <= self.rtol), "precond_all": pc, "precond_exact": exact}
         if profile_spmv:
             prof = b.profile(False)
             if prof:
@@ -383,6 +431,12 @@ class DistributedKrylov:
         ds = DistributedSolver(backend, self.dist, self.torch, prob.rank, prob.world, plane,
                                lay["k0"], lay["P0"], lay["P1"], lay["k1"] - lay["k0"] + 1,
                                rtol=prob.rtol, max_iter=prob.max_iter)
+        # slab-exact preconditioner (collective): PHIFEM_PRECOND_EXACT=0 keeps the rank-local block Jacobi
+        import os
+        if os.environ.get("PHIFEM_PRECOND_EXACT", "1") != "0":
+            n_per = lay["L1"] - lay["L0"]
+            zb = [r * n_per for r in range(prob.world)] + [lay["nz"] + 1]
+            backend.setup_exact_precond(self.dist, prob.rank, prob.world, zb, stage_cpu=ds.stage_cpu)
         if self.native is None:
             self._init_native()
             if self.native:
@@ -401,4 +455,5 @@ class DistributedKrylov:
         self.torch.cuda.synchronize(self.dev)
         return {"iterations": int(st[0]), "relres": st[1], "seconds": time.perf_counter() - t0,
                 "n_owned": ds.n_owned, "spmv_avg_s": st[4], "spmv_timed": int(st[5]),
-                "converged": bool(st[6]), "precond_all": bool(st[7])}
+                "converged": bool(st[6]), "precond_all": bool(st[7]),
+                "precond_exact": bool(st[7]) and backend.exact}

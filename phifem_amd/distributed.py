@@ -109,6 +109,7 @@ class SlabProblem:
         return {
             "n_active_owned": n_owned, "iterations": st["iterations"], "relres": st["relres"],
             "converged": bool(st.get("converged", st["relres"] <= self.rtol)),
+            "precond_exact": bool(st.get("precond_exact", False)),
             "stage_s": {"tag": t["tag_cells"] + t["tag_facets"], "assemble": t["assemble"],
                         "solve": st["seconds"]},
             "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),

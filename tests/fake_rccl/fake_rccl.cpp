@@ -1,6 +1,6 @@
 // fake_rccl.cpp -- TEST INFRASTRUCTURE (never shipped, never loaded by the product unless PHX_RCCL_LIB names it).
 //
-// A host-staged stand-in for the nine RCCL entry points phifem_amd/csrc/phx_dist.inc.hip binds with dlopen.
+// A host-staged stand-in for the ten RCCL entry points phifem_amd/csrc/phx_dist.inc.hip binds with dlopen.
 // RCCL refuses two ranks on one device, and the test box has exactly one GPU, so the library's NATIVE
 // multi-GPU loop (phx_solve_distributed: pack kernel -> ncclSend/ncclRecv group -> unpack kernel,
 // ncclAllReduce of the batched dot products) could otherwise only ever run with a one-rank communicator.
@@ -175,6 +175,20 @@ int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op,
   }
   barrier(c);   // nobody overwrites its deposit before everyone has read it
   if (hipMemcpy(recv, out, count * 8, hipMemcpyHostToDevice) != hipSuccess) return fail("H2D");
+  return 0;
+}
+
+// every rank deposits its block in its own diagonal mailbox, all ranks read all blocks
+int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t st) {
+  FakeComm *c = (FakeComm *)comm;
+  const size_t bytes = count * dtype_bytes(dtype);
+  if (bytes > MBOX_BYTES) return fail("all-gather block larger than the mailbox");
+  if (hipStreamSynchronize(st) != hipSuccess) return fail("stream sync");
+  if (hipMemcpy(c->sh->mbox[c->rank][c->rank], send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail("D2H");
+  barrier(c);
+  for (int r = 0; r < c->nranks; ++r)
+    if (hipMemcpy((char *)recv + (size_t)r * bytes, c->sh->mbox[r][r], bytes, hipMemcpyHostToDevice) != hipSuccess) return fail("H2D");
+  barrier(c);
   return 0;
 }
 

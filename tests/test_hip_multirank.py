@@ -156,12 +156,13 @@ def test_elasticity_slabs_match_single_mesh(world, tmp_path):
 _FAKE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfake_rccl.so")
 
 
-def _worker_native(rank, world, n, nxy, port, outdir, native):
+def _worker_native(rank, world, n, nxy, port, outdir, native, exact=True):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["PHIFEM_NATIVE_LOOP"] = "1" if native else "0"
+    os.environ["PHIFEM_PRECOND_EXACT"] = "1" if exact else "0"
     os.environ["PHX_RCCL_LIB"] = _FAKE
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -182,7 +183,7 @@ def _worker_native(rank, world, n, nxy, port, outdir, native):
         np.savez(os.path.join(outdir, f"r{rank}.npz"), gid=gid[owned], u=w[:nv][owned],
                  p=w[nv:][owned], it=res["iterations"], relres=res["relres"],
                  n_owned=res["n_active_owned"], path=prob.dk.path, converged=res["converged"],
-                 precond=res["precond"])
+                 precond=res["precond"], exact=bool(res.get("precond_exact", False)))
     finally:
         dist.destroy_process_group()
 
@@ -221,17 +222,27 @@ def _collect(tmp_path, world, nvg):
 
 
 @pytest.mark.skipif(not os.path.exists(_FAKE), reason="tests/fake_rccl/libfake_rccl.so not built (build())")
-@pytest.mark.parametrize("world", [2, 3])
-def test_native_loop_multi_rank_matches_single_mesh(world, tmp_path):
+@pytest.mark.parametrize("world,native,exact", [(2, True, True), (3, True, True), (2, False, True), (4, False, True),
+                                                (2, True, False)])
+def test_native_loop_multi_rank_matches_single_mesh(world, native, exact, tmp_path):
+    """exact = True: the slab-exact preconditioner (x / y sine transforms rank-local, tridiagonal z solves continued
+    across the ranks through one all-gather): the SAME operator as the single-mesh preconditioner, so the
+    iteration count must be the single-mesh count (+- the rounding of a different summation order).
+    exact = False: rank-local block Jacobi over the slabs (more iterations)."""
     import torch.multiprocessing as mp
     n = 20
-    mp.spawn(_worker_native, args=(world, n, None, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    mp.spawn(_worker_native, args=(world, n, None, _free_port(), str(tmp_path), native, exact), nprocs=world, join=True)
     mesh, info, wref, st = _single_mesh(n, world)
     u, p, rows = _collect(tmp_path, world, mesh.nv)
-    assert all(str(d["path"]) == "native" for d in rows), "the library's own loop did not run"
+    assert all(str(d["path"]) == ("native" if native else "python") for d in rows), "the wrong loop ran"
     assert all(bool(d["converged"]) and d["relres"] <= 1e-11 for d in rows)
     assert len({int(d["it"]) for d in rows}) == 1, "ranks stopped at different iterations"
     assert all(str(d["precond"]) == "box-dst" for d in rows)
+    assert all(bool(d["exact"]) == exact for d in rows)
+    its = int(rows[0]["it"])
+    print(f"world {world} native {native} exact {exact}: {its} iterations, single mesh {st['iterations']}")
+    if exact:
+        assert abs(its - st["iterations"]) <= max(3, st["iterations"] // 10), (its, st["iterations"])
     assert sum(int(d["n_owned"]) for d in rows) == info["n_active"]
     scale = np.abs(wref).max()
     assert np.abs(u - wref[:mesh.nv]).max() <= 1e-7 * scale
@@ -246,7 +257,7 @@ def test_empty_end_slabs_on_the_gpu(native, tmp_path):
     and in the native loop."""
     import torch.multiprocessing as mp
     world, n, nxy = 4, 10, 16
-    mp.spawn(_worker_native, args=(world, n, nxy, _free_port(), str(tmp_path), native), nprocs=world, join=True)
+    mp.spawn(_worker_native, args=(world, n, nxy, _free_port(), str(tmp_path), native, True), nprocs=world, join=True)
     mesh, info, wref, st = _single_mesh(n, world, nxy)
     u, p, rows = _collect(tmp_path, world, mesh.nv)
     owned = [int(d["n_owned"]) for d in rows]

@@ -1,0 +1,11 @@
+#!/bin/bash
+set -o pipefail
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
+timeout -k 10 900 python -m pytest tests/test_hip_precond.py tests/test_hip_assembly.py -x -q > $O/r2_t7.log 2>&1; echo "pytest rc=$?"; tail -5 $O/r2_t7.log
+timeout -k 10 120 python tools/dst_bench.py 192 192 182 0 50
+timeout -k 10 120 python tools/dst_bench.py 256 256 256 0 50
+timeout -k 10 400 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/r2_bench7.json 2> $O/r2_bench7.err; echo "bench rc=$?"; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r2_bench7.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['config']['iterations'], d['config']['stage_ms'], d['roofline']['avg_launch_us'], d['roofline_other']['avg_launch_us'], d['roofline_other']['frac'])
+PY
