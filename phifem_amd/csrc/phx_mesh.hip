@@ -363,6 +363,62 @@ static int build_boundary_list(phx_mesh *m) {
   return PHX_OK;
 }
 
+// Does a caller-supplied simplicial mesh sit on a uniform tensor lattice -- what dolfinx's create_rectangle /
+// create_box (the meshes every reference demo builds, demo/weak-dirichlet/flower/main.py:45-46) hand over, in
+// whatever vertex order?  Then vertex v <-> lattice point (i, j, k), and the fictitious-domain preconditioner
+// applies to it as it does to a sub-mesh of a generated box (on_box_lattice + the two vertex maps).
+// Conditions: per axis the coordinates take n_a + 1 equispaced values (1e-9 of the extent), prod (n_a + 1) = nv,
+// vertex -> lattice point is a bijection, and every cell lies inside one lattice cube.  Host work, O(nv log nv).
+static bool detect_lattice(int gdim, int nvpc, int64_t nv, const double *coords, int64_t nc, const int32_t *cells,
+                           int64_t n_out[3], double h_out[3], std::vector<int32_t> &v2lat, std::vector<int32_t> &lat2v) {
+  if (nv < 8 || nv >= INT32_MAX) return false;
+  double lo[3] = {0, 0, 0}, h[3] = {0, 0, 0};
+  int64_t n[3] = {1, 1, 1};
+  std::vector<double> tmp((size_t)nv);
+  for (int a = 0; a < gdim; ++a) {
+    for (int64_t v = 0; v < nv; ++v) tmp[(size_t)v] = coords[v * gdim + a];
+    std::sort(tmp.begin(), tmp.end());
+    const double ext = tmp.back() - tmp.front();
+    if (!(ext > 0.0)) return false;
+    const double tol = 1e-9 * ext;
+    int64_t distinct = 1;
+    for (int64_t v = 1; v < nv; ++v) if (tmp[(size_t)v] - tmp[(size_t)v - 1] > tol) ++distinct;
+    if (distinct < 2) return false;
+    n[a] = distinct - 1;
+    lo[a] = tmp.front();
+    h[a] = ext / (double)n[a];
+  }
+  int64_t prod = 1;
+  for (int a = 0; a < gdim; ++a) prod *= n[a] + 1;
+  if (prod != nv) return false;
+  v2lat.assign((size_t)nv, -1);
+  lat2v.assign((size_t)nv, -1);
+  const int64_t s1 = n[0] + 1, s2 = (n[0] + 1) * (n[1] + 1);
+  for (int64_t v = 0; v < nv; ++v) {
+    int64_t id = 0;
+    for (int a = 0; a < gdim; ++a) {
+      const double q = (coords[v * gdim + a] - lo[a]) / h[a];
+      const int64_t i = (int64_t)llround(q);
+      if (fabs(q - (double)i) > 1e-6 || i < 0 || i > n[a]) return false;
+      id += i * (a == 0 ? 1 : (a == 1 ? s1 : s2));
+    }
+    if (lat2v[(size_t)id] != -1) return false;
+    lat2v[(size_t)id] = (int32_t)v;
+    v2lat[(size_t)v] = (int32_t)id;
+  }
+  for (int64_t c = 0; c < nc; ++c) {   // a cell may not span more than one lattice cube
+    int64_t mn[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, mx[3] = {-1, -1, -1};
+    for (int k = 0; k < nvpc; ++k) {
+      int64_t id = v2lat[(size_t)cells[c * nvpc + k]];
+      const int64_t idx[3] = {id % s1, gdim == 3 ? (id / s1) % (n[1] + 1) : id / s1, gdim == 3 ? id / s2 : 0};
+      for (int a = 0; a < gdim; ++a) { mn[a] = std::min(mn[a], idx[a]); mx[a] = std::max(mx[a], idx[a]); }
+    }
+    for (int a = 0; a < gdim; ++a) if (mx[a] - mn[a] > 1) return false;
+  }
+  for (int a = 0; a < 3; ++a) { n_out[a] = a < gdim ? n[a] : 1; h_out[a] = a < gdim ? h[a] : 0.0; }
+  return true;
+}
+
 extern "C" int phx_mesh_create(int gdim, int cell_type, int64_t nv, const double *coords,
                                int64_t nc, const int32_t *cells, int device, phx_mesh **out) {
   phx_cell_info ci;
@@ -387,6 +443,19 @@ extern "C" int phx_mesh_create(int gdim, int cell_type, int64_t nv, const double
   PHX_HIP(hipMemcpy(m->f2c, f2c.data(), sizeof(int32_t) * (size_t)nf * 2, hipMemcpyHostToDevice));
   PHX_CHECK(build_boundary_list(m));
   PHX_CHECK(phx_mesh_alloc_common(m));
+  if (cell_type == PHX_TRIANGLE || cell_type == PHX_TETRAHEDRON) {
+    std::vector<int32_t> v2lat, lat2v;
+    int64_t ln[3];
+    double lh[3];
+    if (detect_lattice(gdim, ci.nvpc, nv, coords, nc, cells, ln, lh, v2lat, lat2v)) {
+      m->on_box_lattice = true;
+      for (int a = 0; a < 3; ++a) { m->box_n[a] = ln[a]; m->box_h[a] = lh[a]; }
+      PHX_HIP(phx_malloc(&m->v2lat, sizeof(int32_t) * (size_t)nv));
+      PHX_HIP(phx_malloc(&m->lat2v, sizeof(int32_t) * (size_t)nv));
+      PHX_HIP(hipMemcpy(m->v2lat, v2lat.data(), sizeof(int32_t) * (size_t)nv, hipMemcpyHostToDevice));
+      PHX_HIP(hipMemcpy(m->lat2v, lat2v.data(), sizeof(int32_t) * (size_t)nv, hipMemcpyHostToDevice));
+    }
+  }
   PHX_HIP(hipStreamSynchronize(m->stream));
   *out = m;
   return PHX_OK;

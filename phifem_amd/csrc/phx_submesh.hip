@@ -66,6 +66,18 @@ extern "C" int phx_submesh_create(phx_mesh *m, phx_mesh **sub_out) {
     PHX_HIP(phx_malloc(&s->lat2v, sizeof(int32_t) * (size_t)m->nv));
     PHX_HIP(hipMemcpy(s->v2lat, v_map.data(), sizeof(int32_t) * v_map.size(), hipMemcpyHostToDevice));
     PHX_HIP(hipMemcpy(s->lat2v, renum.data(), sizeof(int32_t) * (size_t)m->nv, hipMemcpyHostToDevice));
+  } else if (m->on_box_lattice && !m->is_submesh) {
+    // parent = a caller-supplied mesh on a tensor lattice (phx_mesh_create): compose its vertex maps
+    std::vector<int32_t> pv2l((size_t)m->nv);
+    PHX_HIP(hipMemcpy(pv2l.data(), m->v2lat, sizeof(int32_t) * (size_t)m->nv, hipMemcpyDeviceToHost));
+    std::vector<int32_t> sv2l(v_map.size()), l2sv((size_t)m->nv, -1);
+    for (size_t i = 0; i < v_map.size(); ++i) { sv2l[i] = pv2l[(size_t)v_map[i]]; l2sv[(size_t)sv2l[i]] = (int32_t)i; }
+    s->on_box_lattice = true;
+    for (int a = 0; a < 3; ++a) { s->box_n[a] = m->box_n[a]; s->box_h[a] = m->box_h[a]; }
+    PHX_HIP(phx_malloc(&s->v2lat, sizeof(int32_t) * sv2l.size()));
+    PHX_HIP(phx_malloc(&s->lat2v, sizeof(int32_t) * l2sv.size()));
+    PHX_HIP(hipMemcpy(s->v2lat, sv2l.data(), sizeof(int32_t) * sv2l.size(), hipMemcpyHostToDevice));
+    PHX_HIP(hipMemcpy(s->lat2v, l2sv.data(), sizeof(int32_t) * l2sv.size(), hipMemcpyHostToDevice));
   }
   s->c_map_h = (int32_t *)malloc(sizeof(int32_t) * c_map.size());
   s->v_map_h = (int32_t *)malloc(sizeof(int32_t) * v_map.size());

@@ -149,6 +149,16 @@ class PhiFEMSolver:
             L.check(rc)
         return rowptr, col, val, rhs, dof
 
+    def export_rhs_dof(self):
+        """(rhs, dof) of the active system without the matrix: right-hand side in active numbering and the map
+        active row -> full DoF index (works at sizes where the CSR copy would not fit the host)."""
+        n = self.info()["n_active"]
+        rhs = np.empty(n, dtype=np.float64)
+        dof = np.empty(n, dtype=np.int64)
+        L.check(L.lib.phx_system_export(self._sys, None, None, None, rhs.ctypes.data_as(C.c_void_p),
+                                        dof.ctypes.data_as(C.c_void_p)))
+        return rhs, dof
+
     def solve(self, rtol=1e-8, max_iter=20000, out=None, profile_spmv=False, strict=False):
         """Replaces the KSP/MUMPS block of main.py:162-182.  Returns the mixed solution in the
         full numbering [u (nv), p (nv)] with inactive DoFs at zero; `out` may be a device

@@ -151,3 +151,41 @@ def test_preconditioner_on_submesh_of_a_box(P, d, n):
     assert res[1][1]["relres"] <= 1e-9
     assert res[1][1]["iterations"] < 0.6 * res[0][1]["iterations"]
     assert np.abs(res[1][0] - res[0][0]).max() <= 1e-6 * np.abs(res[0][0]).max()
+
+
+@pytest.mark.parametrize("d,n", [(3, 16), (2, 48)])
+def test_caller_supplied_lattice_mesh_gets_the_box_preconditioner(P, d, n):
+    """a mesh that arrives as arrays (what a dolfinx caller hands over after create_box /
+    create_rectangle) with its vertices on a tensor lattice -- in ANY vertex order -- is recognised
+    by phx_mesh_create and gets the fictitious-domain preconditioner: same iteration count as the generated box
+    (+- 2: different summation orders), not the ~4x larger Jacobi count; same solution."""
+    import warnings
+    from phifem_amd.mesh_scripts import NodalFunction
+    box = P.create_box([-1.5] * d, [1.5] * d, [n] * d)
+    x, cells = box.x, box.cells
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(x.shape[0])          # new vertex id -> old vertex id
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(perm.size)
+    xs = x[perm]
+    cs = inv[cells][rng.permutation(cells.shape[0])].astype(np.int32)
+    mesh = P.Mesh.from_arrays("tetrahedron" if d == 3 else "triangle", xs, cs)
+
+    def run(m, xx):
+        phi = (xx ** 2).sum(axis=1) - 1.0
+        uex = np.prod(np.sin(xx), axis=1)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            P.compute_tags_measures(m, NodalFunction(phi), 1, box_mode=True, single_layer_cut=True)
+        s = P.PhiFEMSolver(m)
+        s.assemble(phi, float(d) * uex, uex)
+        w = s.solve(rtol=1e-10, max_iter=20000)
+        return w, s.stats
+    w_box, st_box = run(box, x)
+    w_arr, st_arr = run(mesh, xs)
+    assert st_box["precond"] == "box-dst" and st_arr["precond"] == "box-dst"
+    assert abs(st_arr["iterations"] - st_box["iterations"]) <= 2, (st_arr["iterations"], st_box["iterations"])
+    nv = x.shape[0]
+    # vertex perm[i] of the box is vertex i of the shuffled mesh
+    assert np.abs(w_arr[:nv] - w_box[:nv][perm]).max() <= 1e-7 * np.abs(w_box).max()
+    assert np.abs(w_arr[nv:] - w_box[nv:][perm]).max() <= 1e-7 * np.abs(w_box).max()
