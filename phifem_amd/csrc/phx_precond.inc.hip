@@ -187,6 +187,16 @@ template <bool WAVE> __device__ __forceinline__ void psync() {
   }
 }
 
+// Length-specialised kernels (template parameter LL > 0): transform length, threads per pair and lanes per pair are
+// compile-time constants (the divisions and multiplications by them fold); the stage schedule stays in the plan
+// (kernel argument, scalar registers).  LL = 0: everything from the run-time plan.  [Overwriting the plan fields
+// of the by-value kernel argument instead sent its arrays to scratch memory: 29 -> 46 us per pass.]
+template <int LL> __device__ __forceinline__ int plan_L(const DstPlan &P) { return LL > 0 ? LL : P.L; }
+template <int LL> __device__ __forceinline__ int plan_tp(const DstPlan &P) { return LL > 0 ? LL / 8 : P.tp; }
+template <int LL, bool WAVE> __device__ __forceinline__ int plan_slot(const DstPlan &P) {
+  return LL > 0 ? (WAVE ? (LL / 8 <= 32 ? 32 : 64) : LL / 8) : P.slot;
+}
+
 // one Stockham stage of radix R on the L-point sequence `z` of this pair: `t` = thread within the pair.
 // All inputs are read into registers, the block synchronises, then the outputs are written in place.
 template <typename T, int R, bool WAVE>
@@ -238,25 +248,26 @@ __device__ __forceinline__ void fft_stage(C2<T> *z, int nb, int tp, int t, int p
 
 // forward complex FFT of this pair's sequence `z` in LDS.  Every thread of the block must call it (block
 // barriers inside); threads of an idle pair slot pass live = false and do no work.
-template <typename T, bool WAVE>
+template <typename T, bool WAVE, int LL>
 __device__ __forceinline__ void fft_pairs(C2<T> *z, const DstPlan &P, int t, bool live, const C2<T> *tw) {
-  const int tt = live ? t : P.L;  // empty butterfly range
+  const int L = plan_L<LL>(P), tp = plan_tp<LL>(P);
+  const int tt = live ? t : L;  // empty butterfly range
   for (int s = 0; s < P.nstage; ++s) {
     const int R = P.radix[s], p = P.pw[s], tws = P.tws[s];
-    if (R == 8) fft_stage<T, 8, WAVE>(z, P.L >> 3, P.tp, tt, p, tws, tw);
-    else if (R == 4) fft_stage<T, 4, WAVE>(z, P.L >> 2, P.tp, tt, p, tws, tw);
-    else if (R == 3) fft_stage<T, 3, WAVE>(z, tws * p, P.tp, tt, p, tws, tw);  // L / 3 butterflies
-    else fft_stage<T, 2, WAVE>(z, P.L >> 1, P.tp, tt, p, tws, tw);
+    if (R == 8) fft_stage<T, 8, WAVE>(z, L >> 3, tp, tt, p, tws, tw);
+    else if (R == 4) fft_stage<T, 4, WAVE>(z, L >> 2, tp, tt, p, tws, tw);
+    else if (R == 3) fft_stage<T, 3, WAVE>(z, tws * p, tp, tt, p, tws, tw);  // L / 3 butterflies
+    else fft_stage<T, 2, WAVE>(z, L >> 1, tp, tt, p, tws, tw);
   }
 }
 
 // In:  w[ZP(j)] = (a_j, b_j), j = 1 .. L-1 (w[0] arbitrary).   Out: w[ZP(k)] = (F^a_k, F^b_k), k = 1 .. L-1,
 // F_k = sum_j x_j sin(pi j k / L).  `scr`: tp + tp/8 + 1 complex values of scan scratch of this pair.
 // Block-wide barriers inside: every thread of the block calls it.
-template <typename T, bool WAVE>
+template <typename T, bool WAVE, int LL>
 __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P, int t, bool live,
                                          const C2<T> *tw, const T *sn) {
-  const int L = P.L, tp = P.tp, H = L >> 1;
+  const int L = plan_L<LL>(P), tp = plan_tp<LL>(P), H = L >> 1, slot = plan_slot<LL, WAVE>(P);
   const T hf = T(0.5);
   if (live) {
     for (int j = 1 + t; j < H; j += tp) {
@@ -274,7 +285,7 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
     }
   }
   psync<WAVE>();
-  fft_pairs<T, WAVE>(w, P, t, live, tw);
+  fft_pairs<T, WAVE, LL>(w, P, t, live, tw);
   // thread t owns k = 4 t .. 4 t + 3  (k < L / 2)
   // The running sums are kept in f64 whatever the transform precision: in f32 they are what turns the
   // O(eps log L) error of the FFT into O(eps L) (2-D flower problem: 114-582 erratic iterations and
@@ -311,12 +322,12 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
     // the pair sits inside one wavefront: prefix sum of the per-thread totals by shuffles -- no scratch in LDS
     // (which lets a fifth block fit a CU at L = 192), no synchronisation.  Idle lanes carry zeros.
     C2<double> inc = run;
-    for (int d = 1; d < P.slot; d <<= 1) {
-      const double ux = __shfl_up(inc.x, d, P.slot), uy = __shfl_up(inc.y, d, P.slot);
+    for (int d = 1; d < slot; d <<= 1) {
+      const double ux = __shfl_up(inc.x, d, slot), uy = __shfl_up(inc.y, d, slot);
       if (t >= d) { inc.x += ux; inc.y += uy; }
     }
     // exclusive prefix = the inclusive one of the lane below (no subtraction: that would cost the low bits)
-    const double ex = __shfl_up(inc.x, 1, P.slot), ey = __shfl_up(inc.y, 1, P.slot);
+    const double ex = __shfl_up(inc.x, 1, slot), ey = __shfl_up(inc.y, 1, slot);
     E = t == 0 ? mk<double>(0.0, 0.0) : mk<double>(ex, ey);
   } else {
     C2<double> *tot = reinterpret_cast<C2<double> *>(scr), *gt = tot + tp;
@@ -373,14 +384,15 @@ struct BoxGrid {
 // lattice point, -1: none), times dscale when that is given; IO = 2: the result is scattered out the same
 // way, times dscale.
 // T: precision of the lattice array and of the transform (the Krylov vectors stay f64).
-template <typename T, int IO, bool WAVE>
+template <typename T, int IO, bool WAVE, int LL = 0>
 __global__ void __launch_bounds__(1024)
 k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gmap,
         const double *__restrict__ vin, double *__restrict__ vout, const double *__restrict__ dscale,
         const uint8_t *__restrict__ line_any) {
   extern __shared__ double2 zs_raw[];
   C2<T> *zs = reinterpret_cast<C2<T> *>(zs_raw);
-  const int pr = threadIdx.x / P.slot, t = threadIdx.x % P.slot;  // slot >= tp lanes per pair
+  const int PL = plan_L<LL>(P), Ptp = plan_tp<LL>(P), Pslot = plan_slot<LL, WAVE>(P);
+  const int pr = threadIdx.x / Pslot, t = threadIdx.x % Pslot;  // slot >= tp lanes per pair
   const int64_t nlines = (int64_t)g.m[1] * g.m[2];
   if ((IO == 1 || IO == 2) && line_any) {
     // x lines that hold no active vertex (63 % of the lattice lies outside the domain): their input is zero (IO = 1)
@@ -399,10 +411,10 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
     }
   }
   const int64_t line0 = ((int64_t)blockIdx.x * P.pairs + pr) * 2;
-  const bool live = line0 < nlines && t < P.tp;
-  C2<T> *w = zs + (size_t)pr * ZLEN(P.L);
-  C2<T> *scr = zs + (size_t)P.pairs * ZLEN(P.L) + (size_t)pr * P.scr;
-  const int mx = g.m[0], L = P.L;
+  const bool live = line0 < nlines && t < Ptp;
+  C2<T> *w = zs + (size_t)pr * ZLEN(PL);
+  C2<T> *scr = zs + (size_t)P.pairs * ZLEN(PL) + (size_t)pr * P.scr;
+  const int mx = g.m[0], L = PL;
   const C2<T> *tw;
   const T *sn;
   stage_tables<T>(zs, P, &tw, &sn);
@@ -420,7 +432,7 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
       int32_t qa[8], qb[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int j = t + i * P.tp;
+        const int j = t + i * Ptp;
         const bool in = j >= 1 && j <= mx;
         qa[i] = in && has[0] ? gmap[base[0] + j - 1] : -1;
         qb[i] = in && has[1] ? gmap[base[1] + j - 1] : -1;
@@ -441,7 +453,7 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const int j = t + i * P.tp;
+        const int j = t + i * Ptp;
         const bool in = j >= 1 && j <= mx;
         va[i] = in && has[0] ? G[base[0] + j - 1] : T(0);
         vb[i] = in && has[1] ? G[base[1] + j - 1] : T(0);
@@ -449,19 +461,19 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int j = t + i * P.tp;
+      const int j = t + i * Ptp;
       if (j >= 1 && j < L) w[ZP(j)] = mk<T>(va[i], vb[i]);
     }
   }
   __syncthreads();
-  dst_core<T, WAVE>(w, scr, P, t, live, tw, sn);
+  dst_core<T, WAVE, LL>(w, scr, P, t, live, tw, sn);
   if (!live) return;
   if (IO == 2) {
     // k = t + 1 + i tp: all map loads, then all scale loads, then the stores
     int32_t qa[8], qb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int k = t + 1 + i * P.tp;
+      const int k = t + 1 + i * Ptp;
       qa[i] = k <= mx && has[0] ? gmap[base[0] + k - 1] : -1;
       qb[i] = k <= mx && has[1] ? gmap[base[1] + k - 1] : -1;
     }
@@ -473,7 +485,7 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int k = t + 1 + i * P.tp;
+      const int k = t + 1 + i * Ptp;
       if (k <= mx) {
         const C2<T> F = w[ZP(k)];
         if (qa[i] >= 0) vout[qa[i]] = (double)F.x * da[i];
@@ -481,7 +493,7 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
       }
     }
   } else {
-    for (int k = t + 1; k <= mx; k += P.tp) {
+    for (int k = t + 1; k <= mx; k += Ptp) {
       const C2<T> F = w[ZP(k)];
       if (has[0]) G[base[0] + k - 1] = F.x;
       if (has[1]) G[base[1] + k - 1] = F.y;
@@ -492,13 +504,14 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
 // ---- y / z lines (strided): a block takes W = 2 * pairs adjacent x columns of one `outer` index, so every
 // global access is a run of W consecutive values.  AXIS = 1: lines along y (outer = z), AXIS = 2: lines
 // along z (outer = y).  SOLVE (z only): forward transform, times scale / lambda, inverse transform, all in LDS.
-template <typename T, int AXIS, bool SOLVE, bool WAVE>
+template <typename T, int AXIS, bool SOLVE, bool WAVE, int LL = 0>
 __global__ void __launch_bounds__(1024)
 k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
   extern __shared__ double2 zs_raw[];
   C2<T> *zs = reinterpret_cast<C2<T> *>(zs_raw);
-  const int pr = threadIdx.x / P.slot, t = threadIdx.x % P.slot;  // slot >= tp lanes per pair
-  const int W = 2 * P.pairs, L = P.L;
+  const int Ptp = plan_tp<LL>(P), Pslot = plan_slot<LL, WAVE>(P);
+  const int pr = threadIdx.x / Pslot, t = threadIdx.x % Pslot;  // slot >= tp lanes per pair
+  const int W = 2 * P.pairs, L = plan_L<LL>(P);
   const int mx = g.m[0];
   const int ncb = (mx + W - 1) / W;                 // column blocks
   const int col0 = (int)(blockIdx.x % ncb) * W;
@@ -507,7 +520,7 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
   const int64_t estride = AXIS == 1 ? g.pitch : g.plane;
   const int64_t base = col0 + outer * (AXIS == 1 ? g.plane : g.pitch);
   const int ncols = min(W, mx - col0);
-  const bool live = 2 * pr < ncols && t < P.tp;
+  const bool live = 2 * pr < ncols && t < Ptp;
   C2<T> *w = zs + (size_t)pr * ZLEN(L);
   C2<T> *scr = zs + (size_t)P.pairs * ZLEN(L) + (size_t)pr * P.scr;
   const C2<T> *tw;
@@ -537,7 +550,7 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
     }
   }
   __syncthreads();
-  dst_core<T, WAVE>(w, scr, P, t, live, tw, sn);
+  dst_core<T, WAVE, LL>(w, scr, P, t, live, tw, sn);
   if (SOLVE) {
     if (live) {
       const double *lx = g.lam[0], *ly = g.lam[1], *lz = g.lam[2];
@@ -546,14 +559,14 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G) {
       const double lxy1 = (kx + 1 < g.L[0] ? lx[kx + 1] : lx[kx]) + ly[outer + 1];
       // the divide runs in the precision of the transform (an f64 division costs ~10x an f32 one)
       const T sc = (T)g.scale, l0 = (T)lxy0, l1 = (T)lxy1;
-      for (int k = t + 1; k < L; k += P.tp) {
+      for (int k = t + 1; k < L; k += Ptp) {
         const C2<T> F = w[ZP(k)];
         const T lzk = (T)lz[k];
         w[ZP(k)] = mk<T>(F.x * sc / (l0 + lzk), F.y * sc / (l1 + lzk));
       }
     }
     psync<WAVE>();
-    dst_core<T, WAVE>(w, scr, P, t, live, tw, sn);
+    dst_core<T, WAVE, LL>(w, scr, P, t, live, tw, sn);
   }
   __syncthreads();
   if (tcol < ncols) {
@@ -611,9 +624,25 @@ static int dst_allow_lds_t() {
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<T, 2, true, WAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   return PHX_OK;
 }
+// f64 kernels specialised for the transform length, in the synchronisation mode dst_get_plan picks for it
+#define PHX_DST_LENGTHS(X) X(64) X(128) X(192) X(256) X(384) X(512) X(768) X(1024)
+constexpr bool dst_wave_f64(int L) { return L / 8 == 32 || L / 8 == 64 || L / 8 == 24; }
+template <int LL>
+static int dst_allow_lds_len() {
+  const int bytes = 160 * 1024;
+  constexpr bool WV = dst_wave_f64(LL);
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<double, 0, WV, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<double, 1, WV, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_x<double, 2, WV, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_s<double, 1, false, WV, LL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return PHX_OK;
+}
 static int dst_allow_lds() {
   static bool done = false;
   if (done) return PHX_OK;
+#define X(L_) PHX_CHECK((dst_allow_lds_len<L_>()));
+  PHX_DST_LENGTHS(X)
+#undef X
   PHX_CHECK((dst_allow_lds_t<double, true>()));
   PHX_CHECK((dst_allow_lds_t<double, false>()));
   PHX_CHECK((dst_allow_lds_t<float, true>()));
@@ -694,8 +723,22 @@ static int box_pass_y_t(phx_box_precond *bp, hipStream_t st, phx_system *prof) {
   const int W = 2 * py.pairs, ncb = (g.m[0] + W - 1) / W;
   const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(py.pairs * py.slot));
   if (prof) PHX_CHECK(prof_begin(prof, 1));
-  if (py.wave) k_dst_s<T, 1, false, true><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
-  else k_dst_s<T, 1, false, false><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
+  bool done = false;
+  if constexpr (sizeof(T) == 8) {
+    if (!getenv("PHX_DST_GENERIC")) {
+      switch (py.L) {
+#define X(L_) case L_: if ((py.wave != 0) == dst_wave_f64(L_)) { \
+          k_dst_s<double, 1, false, dst_wave_f64(L_), L_><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G); done = true; } break;
+        PHX_DST_LENGTHS(X)
+#undef X
+        default: break;
+      }
+    }
+  }
+  if (!done) {
+    if (py.wave) k_dst_s<T, 1, false, true><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
+    else k_dst_s<T, 1, false, false><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G);
+  }
   if (prof) PHX_CHECK(prof_end(prof, 1));
   PHX_HIP(hipGetLastError());
   return PHX_OK;
@@ -744,12 +787,27 @@ static int box_pass_x_t(phx_box_precond *bp, hipStream_t st, const double *vin, 
   if (g.m[2] <= 0) return PHX_OK;
   const int64_t npairs = ((int64_t)g.m[1] * g.m[2] + 1) / 2;
   const dim3 grid((unsigned)phx_div_up(npairs, px.pairs)), block((unsigned)(px.pairs * px.slot));
-  if (px.wave)
-    k_dst_x<T, IO, true><<<grid, block, (size_t)px.lds_elems * sizeof(T) * 2, st>>>(
-        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, IO == 1 ? bp->iscale : bp->dscale, bp->line_any);
-  else
-    k_dst_x<T, IO, false><<<grid, block, (size_t)px.lds_elems * sizeof(T) * 2, st>>>(
-        g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, IO == 1 ? bp->iscale : bp->dscale, bp->line_any);
+  const size_t lds = (size_t)px.lds_elems * sizeof(T) * 2;
+  const double *sc = IO == 1 ? bp->iscale : bp->dscale;
+  bool done = false;
+  if constexpr (sizeof(T) == 8) {
+    if (!getenv("PHX_DST_GENERIC")) {
+      switch (px.L) {
+#define X(L_) case L_: if ((px.wave != 0) == dst_wave_f64(L_)) { \
+          k_dst_x<double, IO, dst_wave_f64(L_), L_><<<grid, block, lds, st>>>(g, px, static_cast<double *>(bp->G), bp->gmap, vin, vout, sc, bp->line_any); \
+          done = true; } break;
+        PHX_DST_LENGTHS(X)
+#undef X
+        default: break;
+      }
+    }
+  }
+  if (!done) {
+    if (px.wave)
+      k_dst_x<T, IO, true><<<grid, block, lds, st>>>(g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, sc, bp->line_any);
+    else
+      k_dst_x<T, IO, false><<<grid, block, lds, st>>>(g, px, static_cast<T *>(bp->G), bp->gmap, vin, vout, sc, bp->line_any);
+  }
   PHX_HIP(hipGetLastError());
   return PHX_OK;
 }
@@ -1214,17 +1272,8 @@ extern "C" int phx_box_dst_bench(int device, const int *L, int f32, int reps, do
     auto run = [&]() -> int {
       if (which == 0) return box_pass_x<0>(bp, st, nullptr, nullptr);
       if (which == 2) return f32 ? box_pass_z_t<float>(bp, st) : box_pass_z_t<double>(bp, st);
-      const DstPlan &P = bp->plan[1];
-      const int W = 2 * P.pairs, ncb = (g.m[0] + W - 1) / W;
-      const dim3 grid((unsigned)((int64_t)ncb * g.m[2])), block((unsigned)(P.pairs * P.slot));
-      const size_t lds = (size_t)P.lds_elems * (f32 ? sizeof(float2) : sizeof(double2));
-      if (f32) {
-        if (P.wave) k_dst_s<float, 1, false, true><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
-        else k_dst_s<float, 1, false, false><<<grid, block, lds, st>>>(g, P, static_cast<float *>(bp->G));
-      } else {
-        if (P.wave) k_dst_s<double, 1, false, true><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
-        else k_dst_s<double, 1, false, false><<<grid, block, lds, st>>>(g, P, static_cast<double *>(bp->G));
-      }
+      const int rc_y = f32 ? box_pass_y_t<float>(bp, st, nullptr) : box_pass_y_t<double>(bp, st, nullptr);
+      if (rc_y != PHX_OK) return rc_y;
       return hipGetLastError() == hipSuccess ? PHX_OK : PHX_ERR_HIP;
     };
     for (int i = 0; i < 3 && rc == PHX_OK; ++i) rc = run();

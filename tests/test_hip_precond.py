@@ -157,8 +157,9 @@ def test_preconditioner_on_submesh_of_a_box(P, d, n):
 def test_caller_supplied_lattice_mesh_gets_the_box_preconditioner(P, d, n):
     """a mesh that arrives as arrays (what a dolfinx caller hands over after create_box /
     create_rectangle) with its vertices on a tensor lattice -- in ANY vertex order -- is recognised
-    by phx_mesh_create and gets the fictitious-domain preconditioner: same iteration count as the generated box
-    (+- 2: different summation orders), not the ~4x larger Jacobi count; same solution."""
+    by phx_mesh_create and gets the fictitious-domain preconditioner: the iteration count of the generated box
+    (within 15 %: BiCGStab counts move by a few iterations with the summation order), not the ~4x larger Jacobi
+    count; same solution."""
     import warnings
     from phifem_amd.mesh_scripts import NodalFunction
     box = P.create_box([-1.5] * d, [1.5] * d, [n] * d)
@@ -184,7 +185,8 @@ def test_caller_supplied_lattice_mesh_gets_the_box_preconditioner(P, d, n):
     w_box, st_box = run(box, x)
     w_arr, st_arr = run(mesh, xs)
     assert st_box["precond"] == "box-dst" and st_arr["precond"] == "box-dst"
-    assert abs(st_arr["iterations"] - st_box["iterations"]) <= 2, (st_arr["iterations"], st_box["iterations"])
+    assert abs(st_arr["iterations"] - st_box["iterations"]) <= max(3, 0.15 * st_box["iterations"]), \
+        (st_arr["iterations"], st_box["iterations"])
     nv = x.shape[0]
     # vertex perm[i] of the box is vertex i of the shuffled mesh
     assert np.abs(w_arr[:nv] - w_box[:nv][perm]).max() <= 1e-7 * np.abs(w_box).max()
