@@ -248,10 +248,43 @@ __device__ __forceinline__ void fft_stage(C2<T> *z, int nb, int tp, int t, int p
 
 // forward complex FFT of this pair's sequence `z` in LDS.  Every thread of the block must call it (block
 // barriers inside); threads of an idle pair slot pass live = false and do no work.
+// stage schedule of dst_get_plan as constant expressions: radix 3 (if any) last, then 8s, a 4, a 2
+constexpr int sched_n(int L) {
+  int r = L % 3 == 0 ? L / 3 : L, n = 0;
+  while (r % 8 == 0) { r /= 8; ++n; }
+  if (r % 4 == 0) { r /= 4; ++n; }
+  if (r % 2 == 0) { r /= 2; ++n; }
+  return n + (L % 3 == 0 ? 1 : 0);
+}
+constexpr int sched_radix(int L, int s) {
+  int r = L % 3 == 0 ? L / 3 : L, n = 0;
+  while (r % 8 == 0) { if (n == s) return 8; r /= 8; ++n; }
+  if (r % 4 == 0) { if (n == s) return 4; r /= 4; ++n; }
+  if (r % 2 == 0) { if (n == s) return 2; r /= 2; ++n; }
+  return 3;
+}
+constexpr int sched_pw(int L, int s) {
+  int p = 1;
+  for (int q = 0; q < s; ++q) p *= sched_radix(L, q);
+  return p;
+}
+template <typename T, bool WAVE, int LL, int S>
+__device__ __forceinline__ void fft_stages_c(C2<T> *z, int tt, const C2<T> *tw) {
+  if constexpr (S < sched_n(LL)) {
+    constexpr int R = sched_radix(LL, S), p = sched_pw(LL, S), tws = LL / (p * R);
+    fft_stage<T, R, WAVE>(z, LL / R, LL / 8, tt, p, tws, tw);   // every index expression folds
+    fft_stages_c<T, WAVE, LL, S + 1>(z, tt, tw);
+  }
+}
+
 template <typename T, bool WAVE, int LL>
 __device__ __forceinline__ void fft_pairs(C2<T> *z, const DstPlan &P, int t, bool live, const C2<T> *tw) {
   const int L = plan_L<LL>(P), tp = plan_tp<LL>(P);
   const int tt = live ? t : L;  // empty butterfly range
+  if constexpr (LL > 0) {
+    fft_stages_c<T, WAVE, LL, 0>(z, tt, tw);
+    return;
+  }
   for (int s = 0; s < P.nstage; ++s) {
     const int R = P.radix[s], p = P.pw[s], tws = P.tws[s];
     if (R == 8) fft_stage<T, 8, WAVE>(z, L >> 3, tp, tt, p, tws, tw);
