@@ -919,8 +919,6 @@ extern "C" int phx_system_destroy(phx_system *s) {
                   s->c0, s->stencil, s->seg, s->slice_seg, s->sell_rows, s->cscale, s->pvec};
   for (void *p : ptrs) (void)phx_free(p);
   phx_box_precond_destroy(s->precond);
-  if (s->scal_h) (void)hipHostFree(s->scal_h);
-  for (auto &pe : s->prof_ev) for (auto &e : pe) (void)hipEventDestroy(e);
   delete s;
   return PHX_OK;
 }

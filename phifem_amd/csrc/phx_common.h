@@ -120,6 +120,11 @@ struct phx_mesh {
   int spmv_value_index = 1;        // PHX_OPT_SPMV_VALUE_INDEX
   int precond = 1;                 // PHX_OPT_PRECOND: 0 Jacobi, 1 / 2 box sine transforms in f64 / f32 where applicable
   int has_exterior_override = -1;  // -1: decide from the local tags; 0/1: imposed (multi-GPU)
+  // Per-solve host resources live HERE, not in the systems a mesh sees come and go (one per bench step): creating
+  // 4096 profiling events and a pinned buffer per system cost 1.2 ms of idle GPU per step.
+  std::vector<hipEvent_t> prof_ev[2];  // event pairs of the sampled launches: [0] SpMV, [1] sine-transform y pass
+  int prof_used[2] = {0, 0}, prof_seen[2] = {0, 0};
+  double *scal_h = nullptr;            // 16 pinned doubles: the Krylov scalars the host looks at
   int export_csr = 0;              // PHX_OPT_EXPORT_CSR: assembly also builds the CSR copy phx_system_export reads
   int structured = 1;              // PHX_OPT_STRUCTURED: stencil-coded interior rows on Kuhn boxes (P1 weak Dirichlet)
   int allow_empty = 0;             // PHX_OPT_ALLOW_EMPTY: assembly returns an EMPTY system when no cell is tagged 1 / 2
@@ -155,7 +160,7 @@ struct phx_system {
   // solver workspace
   double *work = nullptr;        // 8 vectors of n
   double *scal = nullptr;        // device scalars
-  double *scal_h = nullptr;      // pinned
+  double *scal_h = nullptr;      // pinned; BORROWED from the mesh (phx_mesh_pinned_scalars)
   // externally attached Krylov buffers (multi-GPU driver) and ownership mask (solver order)
   double *kr_work = nullptr, *kr_scal = nullptr;
   const uint8_t *own = nullptr;
@@ -184,8 +189,6 @@ struct phx_system {
   int64_t n_sell_rows = 0;
   double *cscale = nullptr;        // [n] x = cscale * y when the iteration ends (1 for unscaled columns, else 1 / diag)
   double *pvec = nullptr;          // [2 n] phat / shat of the library-owned workspace when no box preconditioner holds them
-  std::vector<hipEvent_t> prof_ev[2];  // event pairs of the sampled launches: [0] SpMV, [1] sine-transform y pass
-  int prof_used[2] = {0, 0}, prof_seen[2] = {0, 0};
 };
 
 // helpers implemented in phx_mesh.hip
@@ -193,6 +196,7 @@ int phx_mesh_alloc_common(phx_mesh *m);
 int phx_begin_timing(phx_mesh *m);
 int phx_end_timing(phx_mesh *m, int slot);
 int phx_mesh_build_edges(phx_mesh *m);
+int phx_mesh_pinned_scalars(phx_mesh *m, double **out);
 
 int phx_system_build_empty(phx_system *s);  // phx_solve.hip
 // row slots of the assembly as the SELL builder of structured systems reads them (phx_assemble.hip: Slots)

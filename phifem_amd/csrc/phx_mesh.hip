@@ -832,6 +832,8 @@ extern "C" int phx_mesh_destroy(phx_mesh *m) {
   for (void *p : ptrs) (void)phx_free(p);
   free(m->c_map_h); free(m->v_map_h);
   (void)phx_free(m->v2lat); (void)phx_free(m->lat2v);
+  if (m->scal_h) (void)hipHostFree(m->scal_h);
+  for (auto &pe : m->prof_ev) for (auto &e : pe) (void)hipEventDestroy(e);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
@@ -842,6 +844,12 @@ extern "C" int phx_mesh_destroy(phx_mesh *m) {
 extern "C" int phx_mesh_counts(const phx_mesh *m, int64_t *counts) {
   counts[0] = m->gdim; counts[1] = m->cell_type; counts[2] = m->nv;
   counts[3] = m->nc; counts[4] = m->nf; counts[5] = m->nbf;
+  return PHX_OK;
+}
+
+int phx_mesh_pinned_scalars(phx_mesh *m, double **out) {
+  if (!m->scal_h) PHX_HIP(hipHostMalloc(&m->scal_h, sizeof(double) * 16));
+  *out = m->scal_h;
   return PHX_OK;
 }
 

@@ -278,7 +278,7 @@ int phx_system_build_sell(phx_system *s) {
   // solver workspace: 9 vectors + scalars
   PHX_HIP(phx_malloc(&s->work, sizeof(double) * (size_t)n * 9));
   PHX_HIP(phx_malloc(&s->scal, sizeof(double) * PHX_SCAL_DOUBLES));
-  PHX_HIP(hipHostMalloc(&s->scal_h, sizeof(double) * 16));
+  PHX_CHECK(phx_mesh_pinned_scalars(s->mesh, &s->scal_h));
   return PHX_OK;
 }
 
@@ -699,7 +699,7 @@ int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t 
   // solver workspace: 9 vectors + scalars
   PHX_HIP(phx_malloc(&s->work, sizeof(double) * (size_t)n * 9));
   PHX_HIP(phx_malloc(&s->scal, sizeof(double) * PHX_SCAL_DOUBLES));
-  PHX_HIP(hipHostMalloc(&s->scal_h, sizeof(double) * 16));
+  PHX_CHECK(phx_mesh_pinned_scalars(s->mesh, &s->scal_h));
   return PHX_OK;
 }
 
@@ -710,7 +710,7 @@ int phx_system_build_empty(phx_system *s) {
   PHX_HIP(phx_malloc(&s->work, sizeof(double) * 16));
   PHX_HIP(phx_malloc(&s->scal, sizeof(double) * PHX_SCAL_DOUBLES));
   PHX_HIP(hipMemsetAsync(s->scal, 0, sizeof(double) * PHX_SCAL_DOUBLES, s->mesh->stream));
-  PHX_HIP(hipHostMalloc(&s->scal_h, sizeof(double) * 16));
+  PHX_CHECK(phx_mesh_pinned_scalars(s->mesh, &s->scal_h));
   PHX_HIP(hipStreamSynchronize(s->mesh->stream));
   return PHX_OK;
 }
@@ -1180,28 +1180,28 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
 // 1 brackets every launch, k every k-th (an event pair costs ~2.5 us of stream time, 4 % of a solve when
 // every launch carries one).
 static inline bool prof_sampled(const phx_system *s, int c) {
-  return s->mesh->profile_spmv > 0 && s->prof_used[c] < (int)s->prof_ev[c].size() / 2 &&
-         s->prof_seen[c] % s->mesh->profile_spmv == 0;
+  return s->mesh->profile_spmv > 0 && s->mesh->prof_used[c] < (int)s->mesh->prof_ev[c].size() / 2 &&
+         s->mesh->prof_seen[c] % s->mesh->profile_spmv == 0;
 }
 static int prof_begin(phx_system *s, int c = 0) {
-  if (prof_sampled(s, c)) PHX_HIP(hipEventRecord(s->prof_ev[c][2 * s->prof_used[c]], s->mesh->stream));
+  if (prof_sampled(s, c)) PHX_HIP(hipEventRecord(s->mesh->prof_ev[c][2 * s->mesh->prof_used[c]], s->mesh->stream));
   return PHX_OK;
 }
 static int prof_end(phx_system *s, int c = 0) {
   if (prof_sampled(s, c)) {
-    PHX_HIP(hipEventRecord(s->prof_ev[c][2 * s->prof_used[c] + 1], s->mesh->stream));
-    s->prof_used[c]++;
+    PHX_HIP(hipEventRecord(s->mesh->prof_ev[c][2 * s->mesh->prof_used[c] + 1], s->mesh->stream));
+    s->mesh->prof_used[c]++;
   }
-  s->prof_seen[c]++;
+  s->mesh->prof_seen[c]++;
   return PHX_OK;
 }
 static int prof_reset(phx_system *s) {
   for (int c = 0; c < 2; ++c) {
-    s->prof_used[c] = 0;
-    s->prof_seen[c] = 0;
-    if (s->mesh->profile_spmv && s->prof_ev[c].empty()) {
-      s->prof_ev[c].resize(2 * 1024);
-      for (auto &e : s->prof_ev[c]) PHX_HIP(hipEventCreate(&e));
+    s->mesh->prof_used[c] = 0;
+    s->mesh->prof_seen[c] = 0;
+    if (s->mesh->profile_spmv && s->mesh->prof_ev[c].empty()) {
+      s->mesh->prof_ev[c].resize(2 * 1024);
+      for (auto &e : s->mesh->prof_ev[c]) PHX_HIP(hipEventCreate(&e));
     }
   }
   return PHX_OK;
@@ -1209,16 +1209,16 @@ static int prof_reset(phx_system *s) {
 static int prof_collect(phx_system *s, double *avg_s, int *count, int c = 0) {
   *avg_s = 0.0;
   *count = 0;
-  if (!s->mesh->profile_spmv || s->prof_used[c] == 0) return PHX_OK;
-  PHX_HIP(hipEventSynchronize(s->prof_ev[c][2 * s->prof_used[c] - 1]));
+  if (!s->mesh->profile_spmv || s->mesh->prof_used[c] == 0) return PHX_OK;
+  PHX_HIP(hipEventSynchronize(s->mesh->prof_ev[c][2 * s->mesh->prof_used[c] - 1]));
   double tot = 0.0;
-  for (int i = 0; i < s->prof_used[c]; ++i) {
+  for (int i = 0; i < s->mesh->prof_used[c]; ++i) {
     float ms = 0.f;
-    PHX_HIP(hipEventElapsedTime(&ms, s->prof_ev[c][2 * i], s->prof_ev[c][2 * i + 1]));
+    PHX_HIP(hipEventElapsedTime(&ms, s->mesh->prof_ev[c][2 * i], s->mesh->prof_ev[c][2 * i + 1]));
     tot += ms;
   }
-  *avg_s = tot * 1e-3 / s->prof_used[c];
-  *count = s->prof_used[c];
+  *avg_s = tot * 1e-3 / s->mesh->prof_used[c];
+  *count = s->mesh->prof_used[c];
   if (c == 0) {
     s->mesh->timings[4] = *avg_s;
     s->mesh->timings[5] = (double)*count;
@@ -1449,15 +1449,17 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
   PHX_CHECK(prof_reset(s));
   PHX_CHECK(phx_begin_timing(m));
   PHX_CHECK(kr_phase(s, 0, 0, 0));
-  // the host looks at the residual every 8th iteration (one ~50 us round trip), every 2nd when the
-  // iterations are few and expensive
-  const int check_every = s->precond_state == 1 ? 2 : 8;
+  // The host looks at the residual every 8th iteration with Jacobi (cheap iterations).  With the box preconditioner
+  // (few, expensive iterations) a check drains the pipeline for ~30 us, so the next one is scheduled from the
+  // observed convergence rate: a quarter of the predicted remaining iterations ahead, at least 2 -- near the end every
+  // 2nd iteration, so no iteration is wasted on a late check (28 -> ~10 drains over 56 iterations).
+  const bool pc = s->precond_state == 1;
   PHX_CHECK(kr_phase(s, 1, 0, 0));
   PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
   PHX_HIP(hipStreamSynchronize(st));
   const double bb = s->scal_h[S_BB];
-  int64_t it = 0, spmvs = 0;
-  double relres = bb == 0.0 ? 0.0 : 1.0;
+  int64_t it = 0, spmvs = 0, next_check = pc ? 2 : 8, last_check = 0;
+  double relres = bb == 0.0 ? 0.0 : 1.0, last_relres = 1.0;
   int rc = PHX_OK;
   while (bb != 0.0 && it < max_iter) {
     const int par = (int)(it & 1);
@@ -1465,7 +1467,7 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
     for (int ph : seq) PHX_CHECK(kr_phase(s, ph, 0, par));
     spmvs += 2;
     ++it;
-    if ((it % check_every == 0) || it == max_iter) {
+    if (it >= next_check || it == max_iter) {
       // fold (r,r) and (rhat,r) of this iteration for the host, without clearing the slots
       k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_RHO, 2, 0);
       PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
@@ -1479,6 +1481,17 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
         break;
       }
       if (relres <= rtol) break;
+      int64_t step = pc ? 2 : 8;
+      if (pc && relres < last_relres && relres > 0.0) {
+        // iterations still needed at the rate seen since the last check
+        const double rate = log(last_relres / relres) / (double)(it - last_check);
+        const double remaining = log(relres / rtol) / rate;
+        step = std::max<int64_t>(2, std::min<int64_t>(6, (int64_t)(0.25 * remaining)));
+        step &= ~(int64_t)1;   // checks stay on even iterations
+      }
+      last_check = it;
+      last_relres = relres;
+      next_check = it + step;
     }
     PHX_CHECK(kr_phase(s, 6, 0, par));
   }
