@@ -230,7 +230,10 @@ int phx_assemble_poisson_sd(phx_mesh *m, double stab_coef, int degree, const dou
 /* Neumann / Robin phi-FEM Poisson (-lap u + u = f, du/dn + kappa u = g on the boundary), mixed (u, y, p) in
  * P1 x P1^d x DG0 with a P2 level-set, on simplices: forms demo/robin/square/main.py:112-168 + assemble_matrix /
  * assemble_vector :145-147,167-168; kappa = 0 with facet_tag = 3 is the formulation of
- * demo/neumann/square/main.py:113-158 (whose quadrilateral cells are not covered).
+ * demo/neumann/square/main.py:113-158.  QUADRILATERAL meshes (the cell type of that demo, :49-50; axis-parallel
+ * rectangles in tensor-product vertex order, else PHX_ERR_NOT_IMPLEMENTED) are assembled as Q1 x Q1^2 x DG0 with a Q2
+ * level-set: phi_h[nv + nf + nc] = vertex values, edge-midpoint values by facet id, cell-centre values; the cut-cell
+ * integrals then use a tensor Gauss rule of quadrature_degree / 2 + 1 points per direction.
  * params = {pen_coef, stab_coef, robin_coef}; facet_tag: the interior facets carrying the gradient-jump term
  * (2 in the Robin demo :140, 3 in the Neumann demo :134); quadrature_degree: degree of the cut-cell rule
  * (|grad phi_h| is not polynomial; 10 = UFL's estimate for the Robin integrand).  phi_h: [nv + ne] (P2: vertex

@@ -1329,4 +1329,5 @@ extern "C" int phx_system_export(phx_system *s, int64_t *rowptr, int32_t *col, d
 #include "phx_assemble_sd.inc.hip"
 #include "phx_assemble_el.inc.hip"
 #include "phx_assemble_flux.inc.hip"
+#include "phx_assemble_flux_quad.inc.hip"
 #include "phx_errors.inc.hip"

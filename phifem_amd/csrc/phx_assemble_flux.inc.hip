@@ -211,6 +211,10 @@ __global__ void __launch_bounds__(256) k_fx_facets(int64_t nlist, const int32_t 
   slot_add(A.slots, A.dofmap[dofs[a]], dofs[b], A.sigma * 0.5 * hsum * area * J[a] * J[b]);
 }
 
+static int assemble_flux_quad_with_capacity(phx_mesh *m, const double *params, int facet_tag, int nq,
+                                            const double *dphi, const double *df, const double *dg, int W,
+                                            phx_system **out);
+
 static int assemble_flux_with_capacity(phx_mesh *m, const double *params, int facet_tag, int qdeg,
                                        const double *dphi, const double *df, const double *dg, int W,
                                        phx_system **out) {
@@ -295,12 +299,30 @@ extern "C" int phx_assemble_poisson_flux(phx_mesh *m, const double *params, int 
                                          const double *phi_h, const double *f_h, const double *g_h, int loc,
                                          phx_system **out) {
   PHX_HIP(hipSetDevice(m->device));
-  PHX_REQUIRE(m->cell_type == PHX_TRIANGLE || m->cell_type == PHX_TETRAHEDRON,
-              PHX_ERR_NOT_IMPLEMENTED, "assembly supports simplices (triangle, tetrahedron) only");
   PHX_REQUIRE(m->have_cell_tags && m->have_facet_tags, PHX_ERR_VALUE,
               "cell and facet tags must be computed before assembly");
   PHX_REQUIRE(facet_tag >= 1 && facet_tag <= 6, PHX_ERR_VALUE, "facet_tag must be one of the facet tags 1..6");
   PHX_REQUIRE(quadrature_degree >= 2 && quadrature_degree <= 15, PHX_ERR_VALUE, "quadrature_degree must be in 2..15");
+  if (m->cell_type == PHX_QUADRILATERAL) {
+    // Q1 x Q1^2 x DG0 with a Q2 level-set [nv + nf + nc] (phx_assemble_flux_quad.inc.hip); a Gauss rule of
+    // quadrature_degree / 2 + 1 points per direction integrates that degree exactly
+    const double *qphi, *qf, *qg;
+    double *q1, *q2, *q3;
+    PHX_CHECK(to_device(m, phi_h, loc, m->nv + m->nf + m->nc, &qphi, &q1));
+    PHX_CHECK(to_device(m, f_h, loc, m->nv, &qf, &q2));
+    PHX_CHECK(to_device(m, g_h, loc, m->nv, &qg, &q3));
+    PHX_CHECK(phx_begin_timing(m));
+    const int nq = std::min(8, quadrature_degree / 2 + 1);
+    int rcq = assemble_flux_quad_with_capacity(m, params, facet_tag, nq, qphi, qf, qg, 64, out);
+    if (rcq == PHX_ERR_CAPACITY) rcq = assemble_flux_quad_with_capacity(m, params, facet_tag, nq, qphi, qf, qg, 128, out);
+    if (rcq == PHX_OK) rcq = phx_end_timing(m, 2);
+    if (q1) (void)phx_free(q1);
+    if (q2) (void)phx_free(q2);
+    if (q3) (void)phx_free(q3);
+    return rcq;
+  }
+  PHX_REQUIRE(m->cell_type == PHX_TRIANGLE || m->cell_type == PHX_TETRAHEDRON,
+              PHX_ERR_NOT_IMPLEMENTED, "unknown cell type");
   PHX_CHECK(phx_mesh_build_edges(m));
   const double *dphi, *df, *dg;
   double *o1, *o2, *o3;

@@ -112,6 +112,18 @@ class Mesh:
         x, e = self.x, self.edges
         return np.concatenate([x, 0.5 * (x[e[:, 0]] + x[e[:, 1]])], axis=0)
 
+    def q2_dof_points(self):
+        """Coordinates of the Q2 nodes of a quadrilateral mesh: the vertices, the edge midpoints in FACET order,
+        the cell centres (the nodal layout `NeumannRobinSolver` and `NodalFunction(degree=2)` use on quadrilaterals)."""
+        if self.cell_type != "quadrilateral":
+            raise ValueError("q2_dof_points is for quadrilateral meshes")
+        x, cells, c2f = self.x, self.cells, self.c2f
+        fverts = np.empty((self.nf, 2), dtype=np.int64)
+        lfv = np.array([[0, 1], [0, 2], [1, 3], [2, 3]])       # local facet -> local vertices (tensor-product order)
+        for lf in range(4):
+            fverts[c2f[:, lf]] = cells[:, lfv[lf]]
+        return np.concatenate([x, 0.5 * (x[fverts[:, 0]] + x[fverts[:, 1]]), x[cells].mean(axis=1)], axis=0)
+
     def cell_tag_values(self):
         return self._get(L.ARR_CELL_TAGS, (self.nc,), np.int32)
 

@@ -161,11 +161,46 @@ def _p2_tab(cell_type, lam):
     return N
 
 
+def _l3(t):
+    return np.stack([2 * (t - 0.5) * (t - 1), 4 * t * (1 - t), 2 * t * (t - 0.5)], axis=1)
+
+
+_Q2_IDX = [(0, 0), (2, 0), (0, 2), (2, 2), (1, 0), (0, 1), (2, 1), (1, 2), (1, 1)]
+
+
+def _q2_tab(pts):
+    """Q2 basis at reference points of the unit square: 4 vertices, 4 edge midpoints (local facet order), centre."""
+    Lx, Ly = _l3(pts[:, 0]), _l3(pts[:, 1])
+    return np.stack([Lx[:, a] * Ly[:, b] for a, b in _Q2_IDX], axis=1)
+
+
+def _evaluate_q2(mesh, nodal, degree):
+    """phi_h in Q2 on quadrilaterals (nodal layout: vertices, edge midpoints by facet id, cell centres) at the cell
+    detection points and at the facet detection points of the background-boundary facets."""
+    if nodal.shape[0] != mesh.nv + mesh.nf + mesh.nc:
+        raise ValueError("a Q2 level-set has one value per vertex, per facet and per cell")
+    cells, c2f = mesh.cells, mesh.c2f
+    cell_dofs = np.concatenate([cells, mesh.nv + c2f, (mesh.nv + mesh.nf + np.arange(mesh.nc))[:, None]], axis=1)
+    vc = nodal[cell_dofs] @ _q2_tab(_ref_points("quadrilateral", degree, 0)).T
+    bf = mesh.boundary_facets
+    s = _ref_points("quadrilateral", degree, 1)[:, 0]          # parameter along the facet, first -> second vertex
+    vf = np.empty((bf.shape[0], s.shape[0]))
+    for lf, (ax, val) in enumerate([(1, 0.0), (0, 0.0), (0, 1.0), (1, 1.0)]):
+        sel = np.flatnonzero(bf[:, 1] == lf)
+        if sel.size == 0:
+            continue
+        pts = np.stack([np.full_like(s, val) if ax == 0 else s, np.full_like(s, val) if ax == 1 else s], axis=1)
+        vf[sel] = nodal[cell_dofs[bf[sel, 0]]] @ _q2_tab(pts).T
+    return np.ascontiguousarray(np.concatenate([vc.reshape(-1), vf.reshape(-1)]))
+
+
 def _evaluate_p2(mesh, nodal, degree):
     """phi_h in P2 (vertex + edge values) at the cell detection points and at the facet detection
     points of the background-boundary facets (layout of PHX_PHI_POINTS)."""
+    if mesh.cell_type == "quadrilateral":
+        return _evaluate_q2(mesh, nodal, degree)
     if mesh.cell_type not in _EDGE_VERTS:
-        raise NotImplementedError("P2 level-sets are implemented on simplices")
+        raise NotImplementedError("P2 level-sets are implemented on simplices and quadrilaterals")
     cells, c2e = mesh.cells, mesh.c2e
     if nodal.shape[0] != mesh.nv + mesh.ne:
         raise ValueError("a P2 level-set has one value per vertex and per edge")

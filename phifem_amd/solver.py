@@ -271,11 +271,14 @@ class NeumannRobinSolver(PhiFEMSolver):
         self.stats = {}
 
     def assemble(self, phi_h, f_h, g_h):
-        """phi_h: P2 nodal values (vertices, then edges: `mesh.p2_dof_points()`); f_h, g_h (u_N / u_R,
-        main.py:103-110): P1 nodal values."""
+        """phi_h: degree-2 nodal values -- simplices: vertices, then edges (`mesh.p2_dof_points()`);
+        quadrilaterals (the cell type of demo/neumann/square/main.py:49-50, Q1 x Q1^2 x DG0 with a Q2 level-set):
+        vertices, then edge midpoints by facet id, then cell centres (`mesh.q2_dof_points()`).
+        f_h, g_h (u_N / u_R, main.py:103-110): degree-1 nodal values."""
         self._free()
         m = self.mesh
-        phi_h = self._arr(phi_h, m.nv + m.ne)
+        nphi = m.nv + m.nf + m.nc if m.cell_type == "quadrilateral" else m.nv + m.ne
+        phi_h = self._arr(phi_h, nphi)
         f_h, g_h = self._arr(f_h, m.nv), self._arr(g_h, m.nv)
         locs = {L.ptr(a)[1] for a in (phi_h, f_h, g_h)}
         if len(locs) != 1:
