@@ -61,6 +61,8 @@ def main():
           f"relative H1 error {h1:.3e}")
     np.savez(os.path.join(out_dir, "solution.npz"), x=mesh.x, cells=mesh.cells, u=u_h, y=y_h, p=p_h,
              cell_tags=mesh.cell_tag_values(), h1_local=e["h10_local"] + e["l2_local"], h1_cells=omega_h)
+    # solution.xdmf: of.write_mesh(mesh); of.write_function(u) of the reference (heavy data as raw binary, no HDF5)
+    P.io.write_solution(os.path.join(out_dir, "solution.xdmf"), mesh, u=u_h, y=y_h, p=p_h, cell_tags=mesh.cell_tag_values())
 
 
 if __name__ == "__main__":

@@ -58,6 +58,8 @@ def main():
           f"residual {solver.stats['relres']:.1e}, max u_h = {u_h.max():.6f}")
     np.savez(os.path.join(out_dir, "solution.npz"), x=mesh.x, cells=mesh.cells, u=u_h, w=w_h,
              cell_tags=mesh.cell_tag_values())
+    # solution.xdmf: of.write_mesh(mesh); of.write_function(u) of the reference (heavy data as raw binary, no HDF5)
+    P.io.write_solution(os.path.join(out_dir, "solution.xdmf"), mesh, u=u_h, cell_tags=mesh.cell_tag_values())
 
 
 if __name__ == "__main__":

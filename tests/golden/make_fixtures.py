@@ -43,6 +43,11 @@ H5DUMP = "/opt/conda/bin/h5dump"
 
 
 def h5_dataset(path, name, dtype):
+    # NOTE (round 2): h5dump's text output prints doubles with 6 significant digits, so the committed coordinates are
+    # the file's values rounded at 1e-7 relative (1/3 -> 0.333333; the square meshes differ from the file by <= 1 ulp).
+    # With the exact values (h5dump -b, as phifem_amd/io.py reads them) 8 more golden cases -- ellipse_in_square,
+    # detection degree 3, discretize -- join the floating-point-degenerate ones (decided by the last bit of the
+    # coordinates); the fixture is kept as generated in round 1, see DESIGN.md section 5.
     out = subprocess.run([H5DUMP, "-d", name, "-y", "-w", "0", path],
                          check=True, capture_output=True, text=True).stdout
     m = re.search(r"DATASPACE\s+SIMPLE\s*\{\s*\(\s*(\d+)\s*,\s*(\d+)\s*\)", out)
