@@ -27,7 +27,7 @@ def scipy_box_solve(f, L, h):
 
 
 @pytest.mark.parametrize("L", [(64, 64, 64), (128, 64, 192), (192, 128, 64), (256, 128, 64), (64, 384, 128),
-                               (512, 64, 64), (64, 64, 768), (1024, 64, 64),
+                               (512, 64, 64), (64, 64, 768), (1024, 64, 64), (768, 64, 40), (64, 768, 20), (384, 192, 30),
                                # z is solved as a tridiagonal system: any column length, no transform
                                (64, 64, 180), (128, 64, 38), (64, 128, 2), (64, 64, 3), (64, 64, 1025)])
 @pytest.mark.parametrize("f32", [0, 1])
