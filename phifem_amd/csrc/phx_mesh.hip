@@ -311,6 +311,10 @@ static int mesh_init_device(phx_mesh *m, int device) {
   PHX_REQUIRE(device >= 0 && device < ndev, PHX_ERR_VALUE, "device %d out of range (%d)", device,
               ndev);
   m->device = device;
+  if (const char *e = getenv("PHX_PRECOND")) {   // default of PHX_OPT_PRECOND for this process (0 / 1 / 2)
+    const int v = atoi(e);
+    if (v >= 0 && v <= 2) m->precond = v;
+  }
   PHX_HIP(hipSetDevice(device));
   PHX_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
   PHX_HIP(hipEventCreate(&m->ev0));

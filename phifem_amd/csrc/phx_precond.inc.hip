@@ -1013,8 +1013,12 @@ __global__ void k_dscale_weighted(int64_t n, const int32_t *__restrict__ perm, c
   iscale[i] = D > 0.0 ? sqrt(kd / D) : 0.0;
 }
 
-// Builds the preconditioner of system `s` (state 1) or marks it not applicable (state -1).
-#define PHX_PRECOND_MARGIN 4
+// z margin on a side where the active vertices reach the face of the mesh box (an OPEN end: phi-FEM imposes nothing
+// on the box boundary, a natural condition): the Dirichlet face of the lattice moves this many planes away so that
+// the lattice operator does not clamp what the real operator leaves free.  1024 x 1024 x 128 slab through the
+// sphere: 54 iterations with ~32 planes, 96 with the closed-side margin of 4.  z planes are cheap (tridiagonal
+// solve, any length).
+#define PHX_PRECOND_MARGIN_OPEN 32
 // lattice bounding box of this rank's (owned) active u DoFs in LOCAL lattice coordinates; hbb[3] < 0: none
 static int box_local_bbox(phx_system *s, bool p2, int hbb[6]) {
   phx_mesh *m = s->mesh;
@@ -1117,7 +1121,17 @@ static int box_precond_setup(phx_system *s) {
     const int extent = hbb[3 + a] - hbb[a] + 1;
     // z (tridiagonal solve, no transform): exactly extent + margins planes; a 2-D lattice keeps its one real plane
     const bool free_len = a == 2 && ztri;
-    if (free_len) L[a] = m->gdim == 3 ? extent + 2 * PHX_PRECOND_MARGIN + 1 : 2;
+    if (free_len && m->gdim == 3) {
+      const int top = (m->is_box || m->on_box_lattice) ? (int)m->box_n[2] : -1;   // last vertex plane of the mesh box
+      int mlo = hbb[2] == 0 ? PHX_PRECOND_MARGIN_OPEN : PHX_PRECOND_MARGIN;
+      int mhi = hbb[5] == top ? PHX_PRECOND_MARGIN_OPEN : PHX_PRECOND_MARGIN;
+      if (extent + mlo + mhi + 1 > 1025) mlo = mhi = PHX_PRECOND_MARGIN;
+      L[a] = extent + mlo + mhi + 1;
+      if (L[a] > 1025) return PHX_OK;
+      lo[a] = hbb[a] - 1 - mlo;
+      continue;
+    }
+    if (free_len) L[a] = 2;
     else L[a] = dst_pick_length(extent + 2 * PHX_PRECOND_MARGIN + 1);
     if (L[a] < 0 || L[a] > 1025) return PHX_OK;  // larger than the longest transform / column: stay with Jacobi
     lo[a] = hbb[a] - 1 - (L[a] - 1 - extent) / 2;
@@ -1174,8 +1188,11 @@ extern "C" int phx_precond_setup_global(phx_system *s, const int64_t *bbox6, int
     if (L[a] < 0) return PHX_OK;
     lo_g[a] = (int)bbox6[a] - 1 - (L[a] - 1 - extent) / 2;
   }
-  const int zext = (int)(bbox6[5] - bbox6[2] + 1), N = zext + 2 * PHX_PRECOND_MARGIN;
-  lo_g[2] = (int)bbox6[2] - 1 - PHX_PRECOND_MARGIN;
+  // open ends of the global box (see PHX_PRECOND_MARGIN_OPEN); zb[nranks] - 1 is its last vertex plane
+  const int mlo = bbox6[2] == 0 ? PHX_PRECOND_MARGIN_OPEN : PHX_PRECOND_MARGIN;
+  const int mhi = bbox6[5] == zb[nranks] - 1 ? PHX_PRECOND_MARGIN_OPEN : PHX_PRECOND_MARGIN;
+  const int zext = (int)(bbox6[5] - bbox6[2] + 1), N = zext + mlo + mhi;
+  lo_g[2] = (int)bbox6[2] - 1 - mlo;
   int planes[16], k0r = 1, first_local = 0;
   for (int r = 0; r < nranks; ++r) {
     const int64_t kf = r == 0 ? lo_g[2] + 1 : std::max<int64_t>(zb[r], lo_g[2] + 1);

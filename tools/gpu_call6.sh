@@ -1,12 +1,7 @@
 #!/bin/bash
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-for p in 1 2; do
-  export PHX_SPMV_PART=$p
-  timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU --kernel-include-regex 'k_spmv' -d $O/r2_pmc6a_$p -o a --output-format csv -- python3 $R/tools/spmv_only.py 256 10 > $O/r2_pmc6a_$p.log 2>&1; echo "a$p rc=$?"
-  timeout -k 10 200 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --kernel-include-regex 'k_spmv' -d $O/r2_pmc6b_$p -o b --output-format csv -- python3 $R/tools/spmv_only.py 256 10 > $O/r2_pmc6b_$p.log 2>&1; echo "b$p rc=$?"
-  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'k_spmv' -d $O/r2_pmc6c_$p -o c --output-format csv -- python3 $R/tools/spmv_only.py 256 10 > $O/r2_pmc6c_$p.log 2>&1; echo "c$p rc=$?"
-  timeout -k 10 200 rocprofv3 --pmc TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum --kernel-include-regex 'k_spmv' -d $O/r2_pmc6d_$p -o d --output-format csv -- python3 $R/tools/spmv_only.py 256 10 > $O/r2_pmc6d_$p.log 2>&1; echo "d$p rc=$?"
-  for q in a b c d; do echo "== part $p pass $q"; python3 $R/tools/pmc_summary.py $O/r2_pmc6${q}_$p k_spmv; done
-done
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
+timeout -k 10 300 python bench.py --config5 --steps 2 --warmup 1 --no-cpu-baseline > $O/r2_c5.json 2> $O/r2_c5.err; echo "config5 rc=$?"; tail -1 $O/r2_c5.json | cut -c1-600
+timeout -k 10 200 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/r2_def.json 2> $O/r2_def.err; echo "default rc=$?"; tail -1 $O/r2_def.json | cut -c1-400
+timeout -k 10 1500 python -m pytest tests -m gpu -x -q > $O/r2_full.log 2>&1; echo "pytest rc=$?"; tail -5 $O/r2_full.log
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/r2_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/r2_smoke.log

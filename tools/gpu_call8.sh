@@ -1,4 +1,6 @@
 #!/bin/bash
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
-timeout -k 10 1100 python -m pytest tests/test_hip_multirank.py tests/test_hip_assembly.py -x -q -s > $O/r2_t8.log 2>&1; echo "pytest rc=$?"; grep -E "iterations, single|passed|failed|Error|error" $O/r2_t8.log | tail -20; tail -5 $O/r2_t8.log
+for v in 0 1 2 3 4 5 7; do
+  PHX_SELL_EXP=$v timeout -k 10 200 python tools/spmv_only.py 256 50 2>&1 | grep xcd_group | sed "s/^/var $v: /"
+done

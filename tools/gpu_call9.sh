@@ -1,13 +1,15 @@
 #!/bin/bash
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
-export PHIFEM_DIST_BACKEND=gloo
-timeout -k 10 300 python tools/capsule_single.py 64 5 2>&1 | grep "single mesh"
-for ex in 1 0; do
-  PHIFEM_PRECOND_EXACT=$ex timeout -k 10 500 python bench.py --gpus 5 --cubes 64 --steps 1 --warmup 1 --no-cpu-baseline > $O/r2_n5_$ex.json 2> $O/r2_n5_$ex.err; echo "rc=$?"
-  python - <<PY
+timeout -k 10 300 python tools/experiments/f32_restart.py 1 2>&1 | grep "pc=" 
+for d in 0 1e-3 1e-4 1e-5; do
+  PHX_RESTART_DROP=$d timeout -k 10 300 python tools/experiments/f32_restart.py 2 2>&1 | grep "pc="
+done
+for cfg in "1 0" "2 0" "2 1e-3" "2 1e-4" "2 1e-5"; do set -- $cfg
+  PHX_PRECOND=$1 PHX_RESTART_DROP=$2 timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/r2_b9.json 2> $O/r2_b9.err; echo "bench rc=$? precond=$1 drop=$2"
+  python - <<'PY'
 import json
-d=json.loads([l for l in open('gpurun_out/r2_n5_$ex.json') if l.startswith('{')][-1])
-c=d['config']; print('exact=$ex', 'N', d['n_gpus'], 'ranks_seen', c['ranks_seen'], 'dofs', c['active_dofs'], 'iterations', c['iterations'], 'relres', c['relres'], 'loop', c['dist_loop'], 'ms', round(d['ms_per_step'],1))
+d=json.loads(open('gpurun_out/r2_b9.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['config']['iterations'], d['config']['relres'], d['config']['stage_ms'])
 PY
 done
