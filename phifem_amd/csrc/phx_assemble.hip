@@ -571,6 +571,117 @@ __global__ void __launch_bounds__(256) k_assemble_cut(int64_t nlist, const int32
   // main.py:123-128,150: div(grad(.)) of a P1 function is identically zero.
 }
 
+// --- cut-cell penalisation as ROW GATHERS on a Kuhn box (the terms of k_assemble_cut, main.py:115-122,144-149):
+// one thread per vertex of a cut cell walks the 24 (6) simplices of its star in closed form (as
+// k_assemble_rows_box does), keeps the rows u_v and p_v of every cut one in registers -- 3 x 27 accumulators: (u,u),
+// (u,p) = (p,u), (p,p) per lattice neighbour -- and adds them to the two rows once, without atomics (the kernel
+// is the only writer of its rows while it runs).  The scatter form issued 64 hashed atomics per cut cell
+// (7e7 at 256^3, 2.1 ms); this one evaluates every cut cell once per vertex (4x the arithmetic, which is cheap).
+template <int D>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))   // 81 accumulators: registers over occupancy
+k_assemble_cut_rows_box(int64_t np, const int64_t *__restrict__ full_p, BoxDims bd, AsmArgs A) {
+  constexpr int N = D + 1, NPERM = D == 3 ? 6 : 2, NCODE = D == 3 ? 27 : 9;
+  constexpr int P[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+  constexpr int P2[2][3] = {{0, 1, 0}, {1, 0, 0}};
+  constexpr int POW3[3] = {1, 3, 9};
+  constexpr double c2 = D == 3 ? 1.0 / 20.0 : 1.0 / 12.0;
+  constexpr double c3 = D == 3 ? 1.0 / 120.0 : 1.0 / 60.0;
+  constexpr double c4 = D == 3 ? 1.0 / 840.0 : 1.0 / 360.0;
+  // p lives on the vertices of the cut cells and its DoFs are numbered contiguously behind the u DoFs: thread k
+  // takes the vertex of the k-th p DoF, so every lane of a wavefront has work (a launch over ALL vertices left
+  // 3-6 live lanes per wave and a chain of 24 dependent tag loads: 3 ms)
+  const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (k >= np) return;
+  const int64_t vtx = full_p[k] - A.nv;
+  const int32_t rowp = A.dp[vtx], rowu = A.du[vtx];
+  const int64_t n0 = bd.n[0] + 1, n1 = bd.n[1] + 1;
+  const int64_t idx[3] = {vtx % n0, D == 3 ? (vtx / n0) % n1 : vtx / n0, D == 3 ? vtx / (n0 * n1) : 0};
+  const int64_t vstride[3] = {1, n0, n0 * n1};
+  const int64_t cstride[3] = {1, bd.n[0], bd.n[0] * bd.n[1]};
+  double auu[NCODE], aup[NCODE], app[NCODE];
+  uint32_t seen = 0u;
+#pragma unroll
+  for (int c = 0; c < NCODE; ++c) { auu[c] = aup[c] = app[c] = 0.0; }
+  double ru = 0.0, rp = 0.0;
+  // tags of the whole star first: 24 independent loads in flight instead of 24 load -> branch round trips
+  int8_t stag[NPERM][N];
+#pragma unroll
+  for (int t = 0; t < NPERM; ++t) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+      int dd[3] = {0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < m; ++q) dd[D == 3 ? P[t][q] : P2[t][q]] -= 1;
+      bool in = true;
+      int64_t cube = 0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const int64_t o = idx[a] + dd[a];
+        in = in && o >= 0 && o < bd.n[a];
+        cube += o * cstride[a];
+      }
+      stag[t][m] = in ? (int8_t)(A.ctags[cube * NPERM + t] & PHX_TAG_MASK) : (int8_t)0;
+    }
+  }
+  // every Kuhn simplex of the box has the volume h_x h_y (h_z) / D! and contains the main diagonal of its cube
+  // (ufl.CellDiameter, main.py:108): the three coefficients are constants of the mesh
+  double vol = bd.h[0] * bd.h[1] * (D == 3 ? bd.h[2] * (1.0 / 6.0) : 0.5), hd2 = 0.0;
+  for (int a = 0; a < D; ++a) hd2 += bd.h[a] * bd.h[a];
+  const double h1 = 1.0 / sqrt(hd2), gam = A.gamma * vol;
+  const double kuu = gam * h1 * h1 * c2, kup = -gam * h1 * h1 * h1 * c3, kpp = gam * h1 * h1 * h1 * h1 * c4;
+#pragma unroll
+  for (int t = 0; t < NPERM; ++t) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+      int dd[3] = {0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < m; ++q) dd[D == 3 ? P[t][q] : P2[t][q]] -= 1;
+      if (stag[t][m] != 2) continue;
+      int code[N];
+      double ph[N], ud[N], sp = 0.0, sp2 = 0.0, sud = 0.0;
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        code[q] = 0;
+        int64_t w = vtx;
+#pragma unroll
+        for (int a = 0; a < D; ++a) { code[q] += (dd[a] + 1) * POW3[a]; w += dd[a] * vstride[a]; }
+        ph[q] = A.phi[w]; ud[q] = A.ud[w];
+        sp += ph[q]; sp2 += ph[q] * ph[q]; sud += ud[q];
+        if (q < D) dd[D == 3 ? P[t][q] : P2[t][q]] += 1;
+      }
+      double bq = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double d2 = j == m ? 2.0 : 1.0;
+        auu[code[j]] += kuu * d2;
+        aup[code[j]] += kup * d2 * (sp + ph[m] + ph[j]);
+        // sum_kl alpha! phi_k phi_l = c! [T^2 + sum_k (c_k + 1) phi_k^2], c = e_i + e_j, T = sum_k (c_k + 1) phi_k
+        const double T = sp + ph[m] + ph[j];
+        const double m4 = d2 * (T * T + sp2 + ph[m] * ph[m] + ph[j] * ph[j]);
+        app[code[j]] += kpp * m4;
+        seen |= 1u << code[j];
+        bq += ud[j] * d2 * (sp + ph[m] + ph[j]);
+      }
+      ru += kuu * (sud + ud[m]);
+      rp += kup * bq;
+    }
+  }
+  const int32_t nvi = A.nv;
+#pragma unroll
+  for (int code = 0; code < NCODE; ++code) {
+    if (!((seen >> code) & 1u)) continue;
+    int64_t w = vtx;
+    w += (code % 3 - 1) * vstride[0] + ((code / 3) % 3 - 1) * vstride[1];
+    if (D == 3) w += (code / 9 - 1) * vstride[2];
+    slot_add_owned(A.slots, rowu, (int32_t)w, auu[code]);
+    slot_add_owned(A.slots, rowu, nvi + (int32_t)w, aup[code]);
+    slot_add_owned(A.slots, rowp, (int32_t)w, aup[code]);
+    slot_add_owned(A.slots, rowp, nvi + (int32_t)w, app[code]);
+  }
+  A.rhs[rowu] += ru;
+  A.rhs[rowp] += rp;
+}
+
 // --- one-sided boundary term, main.py:114:  -int_F (grad u . n) v  over (cell, local facet) ---
 // With n = -g_lf/|g_lf|, |F| = D |K| |g_lf| and int_F N_i = |F|/D (i on F) the entry is
 // |K| (g_j . g_lf) for every row i != lf and every column j.  16 lanes per entity.
@@ -1194,7 +1305,15 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
       else k_assemble_rows<3><<<g, b, 0, m->stream>>>(m->nv, m->v2c_ptr, m->v2c_idx, A);
     }
   }
-  if (n_cut > 0) {
+  static const bool cut_scatter = getenv("PHX_CUT_SCATTER") && atoi(getenv("PHX_CUT_SCATTER")) != 0;   // A/B aid
+  if (n_cut > 0 && m->is_box && !cut_scatter) {
+    // Kuhn box: the cut-cell terms as row gathers (no atomics)
+    const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}, {m->box_h[0], m->box_h[1], m->box_h[2]}};
+    const int64_t npd = s->n - s->nu;
+    const dim3 g((unsigned)phx_div_up(std::max<int64_t>(npd, 1), 256));
+    if (D == 2) k_assemble_cut_rows_box<2><<<g, block, 0, m->stream>>>(npd, s->full_of_active + s->nu, bd, A);
+    else k_assemble_cut_rows_box<3><<<g, block, 0, m->stream>>>(npd, s->full_of_active + s->nu, bd, A);
+  } else if (n_cut > 0) {
     // 64 lanes per cut cell.  Measured at 256^3 (1.1e6 cut cells): 64 lanes per cell 2.1 ms, 8 lanes (one
     // tensor row each) 2.6 ms, one lane per cell 2.7 ms -- the dependent hash probes of a lane serialise;
     // the ghost-penalty facets behave the other way round (one lane per facet: 2.8 -> 1.5 ms).
