@@ -620,8 +620,6 @@ struct phx_box_precond {
   double *dscale = nullptr;  // [n] diag of A in solver order (weighted systems: sqrt(diag A * diag K_box))
   double *iscale = nullptr;  // [n] weighted systems only: sqrt(diag K_box / diag A), applied to the input
   const uint8_t *own_ptr = nullptr;  // ownership mask the maps were built for
-  int32_t *rest = nullptr;   // solver positions of the rows outside the u block (identity part of P)
-  int64_t nrest = 0;
   double *lam[3] = {nullptr, nullptr, nullptr};
   int lo[3] = {0, 0, 0};     // lattice index of the lower Dirichlet face
   // slab-exact mode (multi-GPU): this rank holds `g.m[2]` planes of a GLOBAL column of zN planes starting at the
@@ -642,7 +640,6 @@ static void box_precond_free(phx_box_precond *bp) {
   (void)phx_free(bp->G); (void)phx_free(bp->gmap); (void)phx_free(bp->dscale); (void)phx_free(bp->iscale); (void)phx_free(bp->line_any);
   if (!bp->carry_borrowed) { (void)phx_free(bp->carry_send); (void)phx_free(bp->carry_recv); }
   (void)phx_free(bp->tri_in);
-  (void)phx_free(bp->rest);
   for (int a = 0; a < 3; ++a) (void)phx_free(bp->lam[a]);
   delete bp;
 }
@@ -988,14 +985,6 @@ __global__ void k_line_any(BoxGrid g, const int32_t *__restrict__ gmap, uint8_t 
   if (lane == 0) line_any[l] = b != 0ull;
 }
 
-struct SelNotU { const int32_t *perm; int32_t nu; __host__ __device__ bool operator()(const int32_t &i) const { return perm[i] >= nu; } };
-
-__global__ void k_copy_list(int64_t n, const int32_t *__restrict__ list, const double *__restrict__ vin,
-                            double *__restrict__ vout) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) { const int32_t q = list[i]; vout[q] = vin[q]; }
-}
-
 __global__ void k_dscale(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ diag,
                          double *__restrict__ dscale) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1086,10 +1075,8 @@ static int box_precond_build(phx_system *s, bool p2, const int L[3], const int l
       k_dscale<<<dim3((unsigned)phx_div_up(s->n, 256)), dim3(256), 0, st>>>(s->n, s->perm, s->diag, bp->dscale);
     }
     if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
-    // rows outside the u block (active rows are numbered u first): P is the identity there.  The other
-    // entries of phat / shat (u rows this rank does not own) are never written and stay zero.
-    rc = phx_select_indices(st, s->n, SelNotU{s->perm, (int32_t)s->nu}, &bp->rest, &bp->nrest);
-    if (rc != PHX_OK) { box_precond_free(bp); return rc; }
+    // rows outside the u block: P is the identity there, written by the producers of p and s (RestOut,
+    // phx_solve.hip).  The other entries of phat / shat (u rows this rank does not own) are never written and stay zero.
   }
   if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
   bp->own_ptr = s->own;
@@ -1248,11 +1235,8 @@ static int box_precond_apply(phx_system *s, const double *vin, double *vout, int
     phx_set_error("the slab-exact preconditioner is applied in two halves around an all-gather");
     return PHX_ERR_VALUE;
   }
-  if (part != 2) {
-    if (bp->nrest > 0)
-      k_copy_list<<<dim3((unsigned)phx_div_up(bp->nrest, 256)), dim3(256), 0, st>>>(bp->nrest, bp->rest, vin, vout);
-    PHX_CHECK(box_pass_x<1>(bp, st, vin, nullptr));
-  }
+  // the identity part (rows outside the u block) is written by the kernels that produce p and s (RestOut, phx_solve.hip)
+  if (part != 2) PHX_CHECK(box_pass_x<1>(bp, st, vin, nullptr));
   if (part == 0) PHX_CHECK(box_solve_middle(bp, st, s));
   else if (part == 1) PHX_CHECK(bp->f32 ? box_middle_A_t<float>(bp, st, s) : box_middle_A_t<double>(bp, st, s));
   else PHX_CHECK(bp->f32 ? box_middle_B_t<float>(bp, st, s) : box_middle_B_t<double>(bp, st, s));

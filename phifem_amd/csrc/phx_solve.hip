@@ -1030,17 +1030,31 @@ __global__ void k_reduce_slots(double *S, int par, int q0, int nq, int clear) {
 #define GRID_STRIDE(i, n) \
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
+// The box preconditioner is the identity on the rows outside the u block (p rows): the kernels that produce p and s
+// write those entries of phat / shat themselves (`RestOut`), so an application needs no copy pass over them (a list
+// copy of 5 us + a launch, twice per iteration).  perm == nullptr: the u rows come first in solver order (structured
+// systems), otherwise row i belongs to the u block iff perm[i] < nu.
+struct RestOut {
+  double *hat;           // phat or shat; nullptr: nothing to do (no box preconditioner, or hat aliases the vector)
+  const int32_t *perm;
+  int64_t nu;
+  __device__ __forceinline__ void put(int64_t i, double v) const {
+    if (hat && (perm ? perm[i] >= nu : i >= nu)) hat[i] = v;
+  }
+};
+
 // r = rhat = p = own ? b : 0; y = 0; R_RHO += (b,b)
 __global__ void __launch_bounds__(256)
 k_kr_begin(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ rhs,
            const uint8_t *__restrict__ own, double *__restrict__ b, double *__restrict__ r,
            double *__restrict__ rhat, double *__restrict__ p, double *__restrict__ y,
-           double *__restrict__ S) {
+           double *__restrict__ S, RestOut ro) {
   double acc = 0.0;
   GRID_STRIDE(i, n) {
     const bool mine = !own || own[i];
     const double bi = mine ? rhs[perm[i]] : 0.0;
     b[i] = bi; r[i] = bi; rhat[i] = bi; p[i] = bi; y[i] = 0.0;
+    ro.put(i, bi);
     acc += bi * bi;
   }
   block_atomic_sum(acc, slot_base(S, 0, R_RHO));
@@ -1065,12 +1079,14 @@ __global__ void k_kr_begin2(double *S, int mode) {
 // s = r - alpha v, alpha = rho/(rhat,v)
 __global__ void __launch_bounds__(256)
 k_update_s(int64_t n, int par, const uint8_t *__restrict__ own, const double *__restrict__ r,
-           const double *__restrict__ v, double *__restrict__ sv, double *__restrict__ S) {
+           const double *__restrict__ v, double *__restrict__ sv, double *__restrict__ S, RestOut ro) {
   const double rho = S[S_RHO_NEXT];
   const double alpha = rho / dotv(S, par, R_RV);
   GRID_STRIDE(i, n) {
     const bool mine = !own || own[i];
-    sv[i] = mine ? r[i] - alpha * v[i] : 0.0;
+    const double si = mine ? r[i] - alpha * v[i] : 0.0;
+    sv[i] = si;
+    ro.put(i, si);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { S[S_ALPHA] = alpha; S[S_RHO] = rho; }
 }
@@ -1120,7 +1136,7 @@ __device__ __forceinline__ bool kr_restart(const double *S, double rho_new, doub
 __global__ void __launch_bounds__(256)
 k_update_p(int64_t n, int par, const uint8_t *__restrict__ own, const double *__restrict__ r,
            const double *__restrict__ v, double *__restrict__ p, double *__restrict__ rhat,
-           double *__restrict__ S, double drop2) {
+           double *__restrict__ S, double drop2, RestOut ro) {
   const double rho_new = dotv(S, par, R_RHO), rr = dotv(S, par, R_RR);
   const bool restart = kr_restart(S, rho_new, rr, drop2, par);
   if (blockIdx.x == 0) {
@@ -1134,14 +1150,16 @@ k_update_p(int64_t n, int par, const uint8_t *__restrict__ own, const double *__
     for (int k = threadIdx.x; k < 8 * NSLOT; k += blockDim.x) nxt[k * SLOT_STRIDE] = 0.0;
   }
   if (restart) {
-    GRID_STRIDE(i, n) { const double ri = r[i]; p[i] = ri; rhat[i] = ri; }
+    GRID_STRIDE(i, n) { const double ri = r[i]; p[i] = ri; rhat[i] = ri; ro.put(i, ri); }
     return;
   }
   const double beta = (rho_new / S[S_RHO]) * (S[S_ALPHA] / S[S_OMEGA]);
   const double omega = S[S_OMEGA];
   GRID_STRIDE(i, n) {
     const bool mine = !own || own[i];
-    p[i] = mine ? r[i] + beta * (p[i] - omega * v[i]) : 0.0;
+    const double pi = mine ? r[i] + beta * (p[i] - omega * v[i]) : 0.0;
+    p[i] = pi;
+    ro.put(i, pi);
   }
 }
 
@@ -1318,10 +1336,14 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
   const KrVecs V = kr_vecs(s);
   double *S = kr_scal(s);
   const dim3 block(256);
+  // identity part of the box preconditioner, written by the producers of p and s (RestOut)
+  const bool rest_out = s->precond_state == 1 && V.phat != V.p;
+  const int32_t *rperm = s->structured ? nullptr : s->perm;
+  const RestOut rop{rest_out ? V.phat : nullptr, rperm, s->nu}, ros{rest_out ? V.shat : nullptr, rperm, s->nu};
   switch (phase) {
     case 0:
       PHX_HIP(hipMemsetAsync(S, 0, sizeof(double) * PHX_SCAL_DOUBLES, st));
-      k_kr_begin<<<vec_grid(n), block, 0, st>>>(n, s->perm, s->rhs, s->own, V.b, V.r, V.rhat, V.p, V.y, S);
+      k_kr_begin<<<vec_grid(n), block, 0, st>>>(n, s->perm, s->rhs, s->own, V.b, V.r, V.rhat, V.p, V.y, S, rop);
       k_reduce_slots<<<1, 64, 0, st>>>(S, 0, R_RHO, 1, 1);
       if (mode) k_set_scalar<<<1, 1, 0, st>>>(S + R_OFF + R_RR, s->precond_veto ? 1.0 : 0.0);
       break;
@@ -1335,7 +1357,7 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_RV, 1, 1);
       break;
     case 3:
-      k_update_s<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.r, V.v, V.sv, S);
+      k_update_s<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.r, V.v, V.sv, S, ros);
       break;
     case 4:
       PHX_CHECK(prof_begin(s));
@@ -1348,7 +1370,7 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_RHO, 2, 1);
       break;
     case 6:
-      k_update_p<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.r, V.v, V.p, V.rhat, S, kr_drop2(s));
+      k_update_p<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.r, V.v, V.p, V.rhat, S, kr_drop2(s), rop);
       break;
     case 7:  // phat = P p   (before the halo exchange of phat and phase 2)
       if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.p, V.phat, s->precond->dist ? 1 : 0));

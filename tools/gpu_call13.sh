@@ -1,4 +1,12 @@
 #!/bin/bash
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
-timeout -k 10 1150 python -m pytest tests -m gpu -x -q > $O/r2_gpu_tests_full.log 2>&1; echo "pytest rc=$?"; tail -6 $O/r2_gpu_tests_full.log
+timeout -k 10 900 python -m pytest tests/test_hip_tagging.py tests/test_hip_assembly.py tests/test_hip_fullsize.py -x -q -m gpu > $O/r2_t13.log 2>&1; echo "pytest rc=$?"; tail -5 $O/r2_t13.log
+for v in 0 1; do
+  PHX_TAG_F2C_LOAD=$v timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/r2_b13.json 2> $O/r2_b13.err; echo "bench rc=$? f2c_load=$v"
+  python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r2_b13.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['config']['iterations'], d['config']['relres'], d['config']['stage_ms'])
+PY
+done

@@ -1,6 +1,10 @@
 #!/bin/bash
 set -o pipefail
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace -d /tmp/tr -o t --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/r2_tr14.log 2>&1; echo "rc=$?"
-python3 $R/tools/gaps.py /tmp/tr/t_kernel_trace.csv 8 > $O/r2_gaps14.txt; head -70 $O/r2_gaps14.txt; tail -3 $O/r2_gaps14.txt
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
+timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/r2_b14.json 2> $O/r2_b14.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r2_b14.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['config']['iterations'], d['config']['relres'], d['config']['stage_ms'])
+PY
+timeout -k 10 1500 python -m pytest tests -m gpu -x -q > $O/r2_full14.log 2>&1; echo "pytest rc=$?"; tail -5 $O/r2_full14.log
