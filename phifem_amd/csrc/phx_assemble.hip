@@ -203,13 +203,20 @@ __device__ __forceinline__ double mult4(int i, int j, int k, int l) {
 // facets) with one lane per entry of the element tensor, so a wavefront issues 64 independent
 // slot updates instead of one lane walking a whole element matrix.
 struct SelOmega { const int8_t *t; __host__ __device__ bool operator()(const int32_t &c) const { const int v = t[c] & PHX_TAG_MASK; return v == 1 || v == 2; } };
-struct SelCut { const int8_t *t; __host__ __device__ bool operator()(const int32_t &c) const { return (t[c] & PHX_TAG_MASK) == 2; } };
+struct SelCut {
+  const int8_t *t;
+  __host__ __device__ bool operator()(const int32_t &c) const { return (t[c] & PHX_TAG_MASK) == 2; }
+  __host__ __device__ const int8_t *bytes() const { return t; }           // byte fast path of phx_select.h
+  __host__ __device__ bool test(int tag, int32_t) const { return (tag & PHX_TAG_MASK) == 2; }
+};
 struct SelGhostFacet {
   const int8_t *ft; const int32_t *f2c;
   __host__ __device__ bool operator()(const int32_t &f) const {
     const int t = ft[f];
     return (t == 2 || t == 3) && f2c[2 * (int64_t)f + 1] >= 0;  // dS: interior facets only
   }
+  __host__ __device__ const int8_t *bytes() const { return ft; }
+  __host__ __device__ bool test(int t, int32_t f) const { return (t == 2 || t == 3) && f2c[2 * (int64_t)f + 1] >= 0; }
 };
 
 // --- vertex -> cell adjacency (once per mesh) ---------------------------------------------------
@@ -771,12 +778,12 @@ __global__ void k_assemble_ds(int64_t nent, const int64_t *__restrict__ ent_pack
 // One lane per facet: the geometry of the two cells is evaluated once per facet, then the lane walks the
 // (D+2)^2 entries.  Measured at 256^3 (2e6 facets): 32 lanes per facet (one entry each, every load issued
 // once per TWO facets of a wavefront) 2.8 ms, 8 lanes per facet (one tensor row each) 1.8 ms, this 1.5 ms.
+// macro-element of interior facet f: its D + 2 distinct vertices vd (the D + 1 of the first cell, then the vertex of
+// the second cell opposite f), their jump coefficients Jd (a shared vertex carries the sum of its two one-sided
+// normal derivatives) and the weight sigma avg(h) |F|: entry (a, b) of the facet tensor is w Jd[a] Jd[b]
 template <int D>
-__global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
-  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e >= nlist) return;
-  constexpr int N = D + 1, M = D + 2;
-  const int64_t f = list[e];
+__device__ __forceinline__ void facet_macro(const AsmArgs &A, int64_t f, int32_t *vd, double *Jd, double *w_out) {
+  constexpr int N = D + 1;
   int32_t vp[N], vm[N];
   double Jp[N], Jm[N], hsum = 0.0, area = 0.0;
   int lfm = 0;
@@ -813,8 +820,6 @@ __global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const in
       J[j] = -sj / gn;
     }
   }
-  int32_t vd[M];
-  double Jd[M];
 #pragma unroll
   for (int j = 0; j < N; ++j) { vd[j] = vp[j]; Jd[j] = Jp[j]; }
   vd[N] = 0;
@@ -826,7 +831,17 @@ __global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const in
     for (int q = 0; q < N; ++q)
       if (vp[q] == vm[j]) Jd[q] += Jm[j];
   }
-  const double w = A.sigma * 0.5 * hsum * area;
+  *w_out = A.sigma * 0.5 * hsum * area;
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= nlist) return;
+  constexpr int M = D + 2;
+  int32_t vd[M];
+  double Jd[M], w;
+  facet_macro<D>(A, list[e], vd, Jd, &w);
   int32_t rows[M];
 #pragma unroll
   for (int a = 0; a < M; ++a) rows[a] = A.du[vd[a]];

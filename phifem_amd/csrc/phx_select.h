@@ -6,11 +6,18 @@
 // of a generic look-back select (measured on 2e8 facets: 2.0 ms -> see DESIGN.md).
 #pragma once
 #include <hipcub/hipcub.hpp>
+#include <utility>
 
 #include "phx_common.h"
 
 #define PHX_SEL_ROUNDS 32
 #define PHX_SEL_CHUNK (64 * PHX_SEL_ROUNDS)
+
+// Predicates over ONE tag byte per item may say so: `const int8_t *bytes() const` (the byte array, 4-byte aligned as
+// every device allocation is) and `bool test(int tag, int32_t i) const`.  A lane then takes four consecutive items
+// from one 32-bit load (a quarter of the load instructions: the byte streams ran at 0.8 TB/s, instruction bound).
+template <typename Pred, typename = void> struct sel_has_bytes { static constexpr bool value = false; };
+template <typename Pred> struct sel_has_bytes<Pred, decltype((void)std::declval<const Pred &>().bytes())> { static constexpr bool value = true; };
 
 template <typename Pred, bool FILL>
 __global__ void __launch_bounds__(256)
@@ -22,12 +29,40 @@ k_select_chunks(int64_t n, Pred pred, int32_t *__restrict__ chunk_counts,
   if (base >= n) return;
   int64_t pos = FILL ? chunk_offsets[chunk] : 0;
   const unsigned long long below = (1ull << lane) - 1ull;
-  for (int r = 0; r < PHX_SEL_ROUNDS; ++r) {
-    const int64_t i = base + r * 64 + lane;
-    const bool keep = i < n && pred((int32_t)i);
-    const unsigned long long mask = __ballot(keep);
-    if (FILL && keep) list[pos + __popcll(mask & below)] = (int32_t)i;
-    pos += __popcll(mask);
+  if constexpr (sel_has_bytes<Pred>::value) {
+    // items base + 256 r + 4 lane + j, j = 0..3: ascending order = lane-major, j-minor
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(pred.bytes());
+    for (int r = 0; r < PHX_SEL_ROUNDS / 4; ++r) {
+      const int64_t i0 = base + r * 256 + lane * 4;
+      uint32_t w = 0u;
+      if (i0 + 3 < n) w = words[i0 >> 2];          // base and 256 r are multiples of 4
+      else for (int j = 0; j < 4; ++j) if (i0 + j < n) w |= (uint32_t)(uint8_t)pred.bytes()[i0 + j] << (8 * j);
+      bool keep[4];
+      unsigned long long mask[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        keep[j] = i0 + j < n && pred.test((int)(int8_t)((w >> (8 * j)) & 255u), (int32_t)(i0 + j));
+        mask[j] = __ballot(keep[j]);
+      }
+      int before = 0, all = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { before += __popcll(mask[j] & below); all += __popcll(mask[j]); }
+      if (FILL) {
+        int k = before;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (keep[j]) { list[pos + k] = (int32_t)(i0 + j); ++k; }
+      }
+      pos += all;
+    }
+  } else {
+    for (int r = 0; r < PHX_SEL_ROUNDS; ++r) {
+      const int64_t i = base + r * 64 + lane;
+      const bool keep = i < n && pred((int32_t)i);
+      const unsigned long long mask = __ballot(keep);
+      if (FILL && keep) list[pos + __popcll(mask & below)] = (int32_t)i;
+      pos += __popcll(mask);
+    }
   }
   if (!FILL && lane == 0) chunk_counts[chunk] = (int32_t)pos;
 }

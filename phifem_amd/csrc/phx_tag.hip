@@ -259,6 +259,8 @@ k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restri
 struct SelTag34 {
   const int8_t *ft;
   __host__ __device__ bool operator()(const int32_t &f) const { return ft[f] == 3 || ft[f] == 4; }
+  __host__ __device__ const int8_t *bytes() const { return ft; }
+  __host__ __device__ bool test(int t, int32_t) const { return t == 3 || t == 4; }
 };
 
 template <bool FILL>
