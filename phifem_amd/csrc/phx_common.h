@@ -58,6 +58,15 @@ static inline int64_t phx_div_up(int64_t a, int64_t b) { return (a + b - 1) / b;
 // `ds` detection says the level-set changes sign over the cell's background-boundary facets.
 #define PHX_TAG_MASK 0x7f
 #define PHX_BCUT_BIT 0x80
+// Kernels that look at ONE tag byte per entity and act on few of them take four entities per thread from one 32-bit
+// load (device allocations are 256-byte aligned): `i0` = first of the four, bytes past n read as 0x7f (no tag).
+__device__ __forceinline__ uint32_t phx_tag_word(const int8_t *tags, int64_t i0, int64_t n) {
+  if (i0 + 3 < n) return *reinterpret_cast<const uint32_t *>(tags + i0);
+  uint32_t w = 0x7f7f7f7fu;
+  for (int j = 0; j < 4; ++j)
+    if (i0 + j < n) w = (w & ~(255u << (8 * j))) | ((uint32_t)(uint8_t)tags[i0 + j] << (8 * j));
+  return w;
+}
 
 struct phx_cell_info {
   int tdim, nvpc, nfpc, nvpf;

@@ -104,20 +104,32 @@ template <int NVPC>
 __global__ void k_mark_inside_vertices(int64_t nc, const int32_t *__restrict__ cells,
                                        const int8_t *__restrict__ tags,
                                        uint8_t *__restrict__ touched) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= nc || (tags[c] & PHX_TAG_MASK) != 1) return;
-  for (int i = 0; i < NVPC; ++i) touched[cells[c * NVPC + i]] = 1;
+  const int64_t c0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;   // four cells per thread (phx_tag_word)
+  if (c0 >= nc) return;
+  const uint32_t w = phx_tag_word(tags, c0, nc);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (((w >> (8 * j)) & PHX_TAG_MASK) != 1u) continue;
+    const int64_t c = c0 + j;
+    for (int i = 0; i < NVPC; ++i) touched[cells[c * NVPC + i]] = 1;
+  }
 }
 
 template <int NVPC>
 __global__ void k_demote_isolated_cut(int64_t nc, const int32_t *__restrict__ cells,
                                       int8_t *__restrict__ tags,
                                       const uint8_t *__restrict__ touched) {
-  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (c >= nc || (tags[c] & PHX_TAG_MASK) != 2) return;
-  bool keep = false;
-  for (int i = 0; i < NVPC; ++i) keep = keep || touched[cells[c * NVPC + i]];
-  if (!keep) tags[c] = 3;
+  const int64_t c0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
+  if (c0 >= nc) return;
+  const uint32_t w = phx_tag_word(tags, c0, nc);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (((w >> (8 * j)) & PHX_TAG_MASK) != 2u) continue;
+    const int64_t c = c0 + j;
+    bool keep = false;
+    for (int i = 0; i < NVPC; ++i) keep = keep || touched[cells[c * NVPC + i]];
+    if (!keep) tags[c] = 3;
+  }
 }
 
 // Tag histogram: four tag bytes per lane and load, counted with ballots (the counters are
@@ -388,7 +400,7 @@ extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int l
     uint8_t *touched = nullptr;
     PHX_HIP(phx_malloc(&touched, (size_t)m->nv));
     PHX_HIP(hipMemsetAsync(touched, 0, (size_t)m->nv, m->stream));
-    const dim3 grid((unsigned)phx_div_up(m->nc, 256)), block(256);
+    const dim3 grid((unsigned)phx_div_up(phx_div_up(m->nc, 4), 256)), block(256);   // four cells per thread
     if (m->ci.nvpc == 3) {
       k_mark_inside_vertices<3><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
       k_demote_isolated_cut<3><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
@@ -428,8 +440,13 @@ static int launch_bcut(phx_mesh *m, const DetTab &tab, const FacetVerts &fvs, co
 }
 
 __global__ void k_clear_bcut(int64_t n, int8_t *tags) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < n) tags[i] = (int8_t)(tags[i] & PHX_TAG_MASK);
+  const int64_t i0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;   // four tags per thread
+  if (i0 + 3 < n) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(tags + i0);
+    *w &= 0x01010101u * (uint32_t)PHX_TAG_MASK;
+  } else {
+    for (int64_t i = i0; i < n; ++i) tags[i] = (int8_t)(tags[i] & PHX_TAG_MASK);
+  }
 }
 
 static int run_facet_rule(phx_mesh *m) {
@@ -478,7 +495,7 @@ extern "C" int phx_tag_facets(phx_mesh *m, int phi_kind, const double *phi, int 
   }
   PHX_CHECK(stage_phi(m, phi_kind, src, loc, count, &dphi, &owned, &quad));
   PHX_CHECK(phx_begin_timing(m));
-  k_clear_bcut<<<dim3((unsigned)phx_div_up(m->nc, 256)), dim3(256), 0, m->stream>>>(m->nc, m->cell_tags);
+  k_clear_bcut<<<dim3((unsigned)phx_div_up(phx_div_up(m->nc, 4), 256)), dim3(256), 0, m->stream>>>(m->nc, m->cell_tags);
   if (phi_kind == PHX_PHI_NODAL_P1) PHX_CHECK(launch_bcut<PHX_PHI_NODAL_P1>(m, tab, fvs, dphi, quad));
   else if (phi_kind == PHX_PHI_POINTS) PHX_CHECK(launch_bcut<PHX_PHI_POINTS>(m, tab, fvs, dphi, quad));
   else PHX_CHECK(launch_bcut<PHX_PHI_QUADRIC>(m, tab, fvs, dphi, quad));
