@@ -229,9 +229,154 @@ def patch_variants(n):
         print(f"  Kbox, post block-Jacobi c={c} then shifted c/2: it={it}")
 
 
+def x0_variants(n):
+    """does x0 = M^-1 b (one extra application + SpMV) save iterations?"""
+    x, topo, cv, A, b, act = assemble_local(n, 1, 0, n, sphere=True)
+    nv = topo.nv
+    idx = np.flatnonzero(act)
+    Aa = A[idx][:, idx].tocsr(); ba = b[idx]
+    nu = int((idx < nv).sum())
+    K, pos = lattice(n, x, idx[:nu])
+    Klu = spla.splu(K)
+    dpp = Aa.diagonal()[nu:]
+    def M(r):
+        g = np.zeros(K.shape[0]); g[pos] = r[:nu]
+        return np.concatenate([Klu.solve(g)[pos], r[nu:] / dpp])
+    xs, it0 = bicgstab(Aa, ba, M)
+    x0 = M(ba)
+    r0 = ba - Aa @ x0
+    # same absolute target: rtol relative to |b|
+    xs1, it1 = bicgstab(Aa, r0, M, rtol=1e-8 * np.linalg.norm(ba) / np.linalg.norm(r0))
+    print(f"n={n}: x0 = 0: {it0} iterations; x0 = M^-1 b: |r0|/|b| = {np.linalg.norm(r0) / np.linalg.norm(ba):.3f}, {it1} iterations (+ ~0.4 for the start)")
+
+
+def fgmres(A, b, M, rtol=1e-8, maxit=300):
+    """flexible GMRES without restart (experiment sizes): returns x, iterations"""
+    n = b.size
+    bn = np.linalg.norm(b)
+    V = [b / bn]; Z = []; H = np.zeros((maxit + 1, maxit))
+    g = np.zeros(maxit + 1); g[0] = bn
+    for k in range(maxit):
+        z = M(V[k]); Z.append(z)
+        w = A @ z
+        for i in range(k + 1):
+            H[i, k] = V[i] @ w; w = w - H[i, k] * V[i]
+        H[k + 1, k] = np.linalg.norm(w); V.append(w / H[k + 1, k])
+        y, res, _, _ = np.linalg.lstsq(H[:k + 2, :k + 1], g[:k + 2], rcond=None)
+        r = np.linalg.norm(H[:k + 2, :k + 1] @ y - g[:k + 2])
+        if r <= rtol * bn:
+            x = sum(yi * zi for yi, zi in zip(y, Z))
+            return x, k + 1
+    x = sum(yi * zi for yi, zi in zip(y, Z))
+    return x, maxit
+
+
+def inner_variants(n):
+    """Kbox followed by a few inner Krylov steps on the band block (flexible outer GMRES)."""
+    x, topo, cv, A, b, act = assemble_local(n, 1, 0, n, sphere=True)
+    nv = topo.nv
+    idx = np.flatnonzero(act)
+    Aa = A[idx][:, idx].tocsr(); ba = b[idx]
+    nu = int((idx < nv).sum())
+    Auu = Aa[:nu][:, :nu].tocsr()
+    K, pos = lattice(n, x, idx[:nu])
+    Klu = spla.splu(K)
+    Kaa = K.tocsr()[pos][:, pos]
+    rowdiff = np.asarray(abs(Auu - Kaa).max(axis=1).todense()).ravel()
+    band = np.flatnonzero(rowdiff > 1e-9 * abs(Auu).max())
+    Abb = Auu[band][:, band].tocsr(); Aband = Auu[band]
+    db = Abb.diagonal()
+    dpp = Aa.diagonal()[nu:]
+    Abblu = spla.splu(Abb.tocsc())
+    print(f"n={n} nu={nu} band={band.size}")
+    def Ku(r):
+        g = np.zeros(K.shape[0]); g[pos] = r
+        return Klu.solve(g)[pos]
+    def mk(post):
+        def M(r):
+            z = Ku(r[:nu])
+            if post is not None:
+                rb = r[:nu][band] - Aband @ z
+                z[band] += post(rb)
+            return np.concatenate([z, r[nu:] / dpp])
+        return M
+    def inner(k):
+        def f(rb):
+            zb, info = spla.gmres(Abb, rb, M=sp.diags(1.0 / db), restart=k, maxiter=1, rtol=1e-14)
+            return zb
+        return f
+    for name, M in [("Kbox", mk(None)), ("Kbox + exact band", mk(Abblu.solve))] + [(f"Kbox + {k} inner GMRES(Jacobi) steps on the band", mk(inner(k))) for k in (3, 5, 10, 20)]:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            xs, it = fgmres(Aa, ba, M)
+        print(f"  FGMRES, {name:50s} it={it:4d} res={np.linalg.norm(Aa @ xs - ba) / np.linalg.norm(ba):.1e}", flush=True)
+
+
+def poly_variants(n):
+    """Kbox followed by a FIXED polynomial in the Jacobi-scaled band block (the GMRES polynomial of one start vector):
+    a linear preconditioner, so the outer BiCGStab stays valid."""
+    x, topo, cv, A, b, act = assemble_local(n, 1, 0, n, sphere=True)
+    nv = topo.nv
+    idx = np.flatnonzero(act)
+    Aa = A[idx][:, idx].tocsr(); ba = b[idx]
+    nu = int((idx < nv).sum())
+    Auu = Aa[:nu][:, :nu].tocsr()
+    K, pos = lattice(n, x, idx[:nu])
+    Klu = spla.splu(K)
+    Kaa = K.tocsr()[pos][:, pos]
+    rowdiff = np.asarray(abs(Auu - Kaa).max(axis=1).todense()).ravel()
+    band = np.flatnonzero(rowdiff > 1e-9 * abs(Auu).max())
+    Abb = Auu[band][:, band].tocsr(); Aband = Auu[band]
+    db = Abb.diagonal()
+    B = Abb @ sp.diags(1.0 / db)          # right-scaled band block: z_b = D^-1 q(B) r_b
+    dpp = Aa.diagonal()[nu:]
+    print(f"n={n} nu={nu} band={band.size}")
+    def Ku(r):
+        g = np.zeros(K.shape[0]); g[pos] = r
+        return Klu.solve(g)[pos]
+    rng = np.random.default_rng(5)
+    def gmres_poly(k, v0):
+        # power basis with per-step normalisation; c minimises |v0 - B Kc|
+        cols = [v0 / np.linalg.norm(v0)]; scal = [1.0 / np.linalg.norm(v0)]
+        for j in range(1, k):
+            w = B @ cols[-1]; s = 1.0 / np.linalg.norm(w)
+            cols.append(w * s); scal.append(scal[-1] * s)
+        Km = np.stack(cols, 1)
+        c, *_ = np.linalg.lstsq(B @ Km, v0, rcond=None)
+        coef = c * np.array(scal)          # q(B) v = sum_j coef_j B^j v  (for ANY v)
+        return coef
+    def apply_poly(coef, r):
+        # Horner: q(B) r = coef_0 r + B (coef_1 r + B (...))
+        acc = coef[-1] * r
+        for cj in coef[-2::-1]:
+            acc = cj * r + B @ acc
+        return acc / db
+    def mk(post):
+        def M(r):
+            z = Ku(r[:nu])
+            if post is not None:
+                rb = r[:nu][band] - Aband @ z
+                z[band] += post(rb)
+            return np.concatenate([z, r[nu:] / dpp])
+        return M
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xs, it = bicgstab(Aa, ba, mk(None))
+    print(f"  BiCGStab, Kbox: {it}")
+    rb0 = ba[:nu][band] - Aband @ Ku(ba[:nu])
+    for k in (3, 5, 8, 12):
+        for label, v0 in (("random start", rng.standard_normal(band.size)), ("first band residual", rb0)):
+            coef = gmres_poly(k, v0)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                xs, it = bicgstab(Aa, ba, mk(lambda rb: apply_poly(coef, rb)), maxit=400)
+                xf, itf = fgmres(Aa, ba, mk(lambda rb: apply_poly(coef, rb)))
+            print(f"  Kbox + degree-{k - 1} GMRES polynomial ({label}): BiCGStab {it}  (FGMRES {itf})  res={np.linalg.norm(Aa @ xs - ba) / np.linalg.norm(ba):.1e}", flush=True)
+
+
 def _main():
     for n in [int(a) for a in sys.argv[2:]] or [24, 32]:
-        {"band": band_variants, "patch": patch_variants}.get(sys.argv[1], main)(n)
+        {"band": band_variants, "patch": patch_variants, "x0": x0_variants, "inner": inner_variants, "poly": poly_variants}.get(sys.argv[1], main)(n)
 
 
 if __name__ == "__main__":
