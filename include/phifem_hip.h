@@ -87,6 +87,20 @@ int phx_pool_release(void);
  * (tdim-1 coords each).  Count-then-fill: call with out == NULL to get *npts. */
 int phx_detection_points(int cell_type, int degree, int which, double *out, int64_t *npts);
 
+/* Level-sets that are neither P1-nodal nor a quadric reach phx_tag_cells / phx_tag_facets as PHX_PHI_POINTS: one
+ * value per detection point, the cells first ([nc][points per cell]), then the background-boundary facets in
+ * ascending facet id ([nbf][points per facet]); *count = the number of values (doubles) of that layout.
+ * phx_levelset_eval_points: a DEGREE-2 nodal level-set (mesh_scripts.py:95-134 with a P2 `discrete_levelset`, the
+ * Robin / Neumann demos' phi_h) evaluated on the device -- nodal[nv + ne] (vertices, then edges) on simplices,
+ * nodal[nv + nf + nc] (vertices, facets, cells) on quadrilaterals, at `loc`; out_device[count].
+ * phx_detection_points_physical: the physical detection points x_q themselves, out_device[count][gdim], so that a
+ * caller's expression (the "UFL expression" mode of tests/test_compute_meshtags.py:159-161) can be evaluated on
+ * device arrays without a host round trip. */
+int phx_levelset_points_count(phx_mesh *m, int detection_degree, int64_t *count);
+int phx_levelset_eval_points(phx_mesh *m, int detection_degree, const double *nodal, int loc,
+                             double *out_device);
+int phx_detection_points_physical(phx_mesh *m, int detection_degree, double *out_device);
+
 /* [host] Facet numbering and connectivities of an unstructured mesh: stands in for dolfinx
  * create_connectivity (mesh_scripts.py:151-153,419-422) and locate_entities_boundary (:430).
  * c2f[nc*nfpc], f2c[(max)nc*nfpc*2] are caller buffers; *nf receives the facet count. */

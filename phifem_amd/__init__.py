@@ -14,6 +14,6 @@ declared in `include/phifem_hip.h`.  There is no CPU fallback.
 from . import _lib  # noqa: F401  (fails loudly when the HIP library is missing)
 from .mesh import Mesh, MeshTags, create_box, create_rectangle  # noqa: F401
 from . import io  # noqa: F401
-from .mesh_scripts import compute_tags_measures  # noqa: F401
+from .mesh_scripts import DeviceExpression, NodalFunction, Quadric, compute_tags_measures  # noqa: F401
 from .solver import (InterfaceElasticitySolver, NeumannRobinSolver, PhiFEMSolver,  # noqa: F401
                      StrongDirichletSolver)

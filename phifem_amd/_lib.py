@@ -46,6 +46,9 @@ SIGNATURES = {
     "phx_device_count": ([_pi], _i),
     "phx_pool_release": ([], _i),
     "phx_detection_points": ([_i, _i, _i, _vp, _pi64], _i),
+    "phx_levelset_points_count": ([_vp, _i, _pi64], _i),
+    "phx_levelset_eval_points": ([_vp, _i, _vp, _i, _vp], _i),
+    "phx_detection_points_physical": ([_vp, _i, _vp], _i),
     "phx_topology_build_host": ([_i, _i64, _i64, _vp, _vp, _vp, _pi64], _i),
     "phx_mesh_create": ([_i, _i, _i64, _vp, _i64, _vp, _i, C.POINTER(_vp)], _i),
     "phx_mesh_create_box": ([_i, _vp, _vp, _vp, _vp, _vp, _i, C.POINTER(_vp)], _i),

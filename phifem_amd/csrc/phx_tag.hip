@@ -666,3 +666,5 @@ extern "C" int phx_integration_entities(phx_mesh *m, int which, int32_t *out, in
   for (int64_t i = 0; i < n; ++i) { out[2 * i] = r[i].cell; out[2 * i + 1] = r[i].lf; }
   return PHX_OK;
 }
+
+#include "phx_levelset.inc.hip"

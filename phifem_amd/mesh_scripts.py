@@ -26,12 +26,26 @@ class NodalFunction:
 
     def __init__(self, values, degree=1):
         """degree 1: one value per vertex.  degree 2: vertex values then edge-midpoint values
-        (`mesh.p2_dof_points()`); evaluated at the detection points by P2 tabulation on the host
-        and classified on the device (PHX_PHI_POINTS)."""
+        (`mesh.p2_dof_points()`; quadrilaterals: `mesh.q2_dof_points()`), numpy or a torch tensor on the
+        mesh's GPU; evaluated at the detection points by the library on the device
+        (`phx_levelset_eval_points`) and classified there (PHX_PHI_POINTS)."""
         if degree not in (1, 2):
             raise NotImplementedError("level-set functions of degree 1 and 2 are implemented")
         self.values = values
         self.degree = degree
+
+
+class DeviceExpression:
+    """A level-set EXPRESSION evaluated on the device: `f(x)` receives a torch tensor of shape (gdim, npoints) on
+    the mesh's GPU -- the physical detection points, produced by the library (`phx_detection_points_physical`) --
+    and returns a float64 tensor of npoints values.  The device-side counterpart of passing a plain callable
+    (which is evaluated by numpy on the host, like the reference's UFL-expression mode,
+    tests/test_compute_meshtags.py:159-161)."""
+
+    def __init__(self, f):
+        if not callable(f):
+            raise TypeError("DeviceExpression wraps a callable x -> phi on torch tensors")
+        self.f = f
 
 
 class Quadric:
@@ -75,9 +89,9 @@ class BoundaryMeasure:
 def _levelset_args(mesh, levelset, degree):
     """-> (phi_kind, pointer, loc, keepalive)."""
     if isinstance(levelset, NodalFunction) and levelset.degree == 2:
-        vals = _evaluate_p2(mesh, np.asarray(levelset.values, dtype=np.float64), degree)
-        p, loc = L.ptr(vals)
-        return L.PHI_POINTS, p, loc, vals
+        return _device_points(mesh, degree, nodal=levelset.values)
+    if isinstance(levelset, DeviceExpression):
+        return _device_points(mesh, degree, expr=levelset.f)
     if isinstance(levelset, NodalFunction):
         v = levelset.values
         if hasattr(v, "data_ptr"):
@@ -103,6 +117,45 @@ def _levelset_args(mesh, levelset, degree):
         p, loc = L.ptr(vals)
         return L.PHI_POINTS, p, loc, vals
     raise TypeError("discrete_levelset must be a NodalFunction, a Quadric or a callable x -> phi")
+
+
+def _device_points(mesh, degree, nodal=None, expr=None):
+    """PHX_PHI_POINTS values produced on the device: a degree-2 nodal level-set tabulated by the library, or a
+    caller's torch expression at the physical detection points."""
+    import torch
+    dev = torch.device("cuda", mesh.device)
+    cnt = C.c_int64(0)
+    L.check(L.lib.phx_levelset_points_count(mesh._h, degree, C.byref(cnt)))
+    out = torch.empty(cnt.value, dtype=torch.float64, device=dev)
+    if nodal is not None:
+        if mesh.cell_type == "quadrilateral":
+            want, what = mesh.nv + mesh.nf + mesh.nc, "a Q2 level-set has one value per vertex, per facet and per cell"
+        elif mesh.cell_type in _EDGE_VERTS:
+            want, what = mesh.nv + mesh.ne, "a P2 level-set has one value per vertex and per edge"
+        else:
+            raise NotImplementedError("P2 level-sets are implemented on simplices and quadrilaterals")
+        v = nodal
+        if hasattr(v, "data_ptr"):
+            if v.dtype != torch.float64 or not v.is_contiguous():
+                raise ValueError("a nodal level-set tensor must be contiguous float64")
+            if v.is_cuda and v.device.index != mesh.device:
+                raise ValueError(f"nodal level-set lives on cuda:{v.device.index}, the mesh on cuda:{mesh.device}")
+            n = v.numel()
+        else:
+            v = np.ascontiguousarray(v, dtype=np.float64)
+            n = v.shape[0]
+        if n != want:
+            raise ValueError(what)
+        p, loc = L.ptr(v)
+        L.check(L.lib.phx_levelset_eval_points(mesh._h, degree, p, loc, C.c_void_p(out.data_ptr())))
+        return L.PHI_POINTS, C.c_void_p(out.data_ptr()), L.DEVICE, (out, v)
+    xq = torch.empty((cnt.value, mesh.gdim), dtype=torch.float64, device=dev)
+    L.check(L.lib.phx_detection_points_physical(mesh._h, degree, C.c_void_p(xq.data_ptr())))
+    vals = expr(xq.t())
+    if not hasattr(vals, "data_ptr") or not vals.is_cuda or vals.numel() != cnt.value:
+        raise ValueError("a DeviceExpression must return one value per point as a tensor on the mesh's GPU")
+    out.copy_(vals.reshape(-1).to(torch.float64))
+    return L.PHI_POINTS, C.c_void_p(out.data_ptr()), L.DEVICE, out
 
 
 def _ref_points(cell_type, degree, which):

