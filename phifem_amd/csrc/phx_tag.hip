@@ -223,14 +223,8 @@ __global__ void k_boundary_cell_cut(int64_t nbf, DetTab tab, FacetVerts fvs, int
 }
 
 // --- a4: facet tags; per-facet predicates equivalent to the set algebra of :454-496 ----------
-__global__ void __launch_bounds__(256)
-k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restrict__ ctags,
-             int no_ext, const uint8_t *__restrict__ exempt, int8_t *__restrict__ ftags,
-             unsigned long long *__restrict__ bad) {
-  const int64_t f = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (f >= nf) return;
-  if (exempt && exempt[f]) { ftags[f] = 0; return; }  // cut through the global mesh: no tag
-  const int2 cc = *reinterpret_cast<const int2 *>(f2c + 2 * f);
+// the tag of one facet from the tags of its two cells; returns how many of the reference's facet sets hold it
+__device__ __forceinline__ int facet_rule(int2 cc, const int8_t *__restrict__ ctags, int no_ext, int8_t *tag) {
   const int b0 = (int)(uint8_t)ctags[cc.x];
   const int t0 = b0 & PHX_TAG_MASK;
   const int t1 = cc.y >= 0 ? (ctags[cc.y] & PHX_TAG_MASK) : 0;
@@ -255,9 +249,38 @@ k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restri
   if (cut) t = 2;
   if (BF) t = 4;
   if (DI) t = 6;
-  ftags[f] = t;
-  const int count = (int)ext + (int)inte + (int)IB + (int)cut + (int)BF + (int)DI;
-  if (count != 1) atomicAdd(bad, 1ull);
+  *tag = t;
+  return (int)ext + (int)inte + (int)IB + (int)cut + (int)BF + (int)DI;
+}
+
+// four facets per thread: two 16-byte loads of f2c, one 4-byte store of the tags (a byte per lane and store left the
+// kernel at 1.9 TB/s of its 11 B per facet)
+__global__ void __launch_bounds__(256)
+k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restrict__ ctags,
+             int no_ext, const uint8_t *__restrict__ exempt, int8_t *__restrict__ ftags,
+             unsigned long long *__restrict__ bad) {
+  const int64_t f0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
+  if (f0 >= nf) return;
+  int nbad = 0;
+  if (f0 + 3 < nf) {
+    const int4 a = *reinterpret_cast<const int4 *>(f2c + 2 * f0), b = *reinterpret_cast<const int4 *>(f2c + 2 * f0 + 4);
+    const int2 cc[4] = {make_int2(a.x, a.y), make_int2(a.z, a.w), make_int2(b.x, b.y), make_int2(b.z, b.w)};
+    uint32_t w = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int8_t t = 0;
+      if (!(exempt && exempt[f0 + j])) nbad += facet_rule(cc[j], ctags, no_ext, &t) != 1;   // exempt: cut through the global mesh, no tag
+      w |= (uint32_t)(uint8_t)t << (8 * j);
+    }
+    *reinterpret_cast<uint32_t *>(ftags + f0) = w;
+  } else {
+    for (int64_t f = f0; f < nf; ++f) {
+      int8_t t = 0;
+      if (!(exempt && exempt[f])) nbad += facet_rule(*reinterpret_cast<const int2 *>(f2c + 2 * f), ctags, no_ext, &t) != 1;
+      ftags[f] = t;
+    }
+  }
+  if (nbad) atomicAdd(bad, (unsigned long long)nbad);
 }
 
 // --- a6: (facet, cell) incidences of a one-sided measure -------------------------------------
@@ -453,7 +476,7 @@ static int run_facet_rule(phx_mesh *m) {
   unsigned long long *dbad = nullptr;
   PHX_HIP(phx_malloc(&dbad, sizeof(unsigned long long)));
   PHX_HIP(hipMemsetAsync(dbad, 0, sizeof(unsigned long long), m->stream));
-  k_tag_facets<<<dim3((unsigned)phx_div_up(m->nf, 256)), dim3(256), 0, m->stream>>>(
+  k_tag_facets<<<dim3((unsigned)phx_div_up(phx_div_up(m->nf, 4), 256)), dim3(256), 0, m->stream>>>(
       m->nf, m->f2c, m->cell_tags,
       m->has_exterior_override >= 0 ? (m->has_exterior_override ? 0 : 1) : (m->tag_hist[3] == 0 ? 1 : 0),
       m->facet_exempt, m->facet_tags, dbad);
