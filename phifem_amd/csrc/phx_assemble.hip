@@ -419,18 +419,40 @@ __global__ void k_box_stencil(BoxDims bd, double *__restrict__ stencil) {
   stencil[3] = D == 3 ? acc[SELF + 9] : 0.0;
 }
 
+// the stored rows as a list (rank = exclusive scan of the flags)
+__global__ void k_flagged_list(int64_t n, const uint8_t *__restrict__ flags, const int32_t *__restrict__ rank,
+                               int32_t *__restrict__ list) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r < n && flags[r]) list[rank[r]] = (int32_t)r;
+}
+
+// mode 0: one thread per vertex, every active u row.  Structured systems split the work: mode 1 -- one thread per
+// vertex, the C0 rows only (right-hand side, a few loads each); mode 2 -- one thread per entry of the list of STORED
+// rows (`rows`, active indices; p rows skipped), the full closed-form row: the 2e5 stored u rows sit 3-6 to a
+// wavefront of consecutive vertices, and a launch over all vertices ran the whole 24-simplex code for those few
+// lanes (0.96 ms at 256^3; list-driven the waves are dense).
 template <int D>
 __global__ void __launch_bounds__(256)
-k_assemble_rows_box(int64_t nv, BoxDims bd, AsmArgs A) {
+k_assemble_rows_box(int64_t nthreads, BoxDims bd, AsmArgs A, int mode, const int32_t *__restrict__ rows,
+                    const int64_t *__restrict__ full, int64_t nu) {
   constexpr int N = D + 1, NPERM = D == 3 ? 6 : 2, NCODE = D == 3 ? 27 : 9;
   constexpr int P[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};  // c_perm3 / c_perm2
   constexpr int P2[2][3] = {{0, 1, 0}, {1, 0, 0}};
   constexpr int POW3[3] = {1, 3, 9};
   constexpr double c2 = D == 3 ? 1.0 / 20.0 : 1.0 / 12.0;
-  const int64_t vtx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (vtx >= nv) return;
-  const int32_t row = A.du[vtx];
-  if (row < 0) return;
+  const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (tid >= nthreads) return;
+  int64_t vtx = tid;
+  int32_t row;
+  if (mode == 2) {
+    row = rows[tid];
+    if (row >= nu) return;
+    vtx = full[row];
+  } else {
+    row = A.du[vtx];
+    if (row < 0) return;
+    if (mode == 1 && !A.c0[row]) return;
+  }
   const int64_t n0 = bd.n[0] + 1, n1 = bd.n[1] + 1;
   int64_t idx[3] = {vtx % n0, D == 3 ? (vtx / n0) % n1 : vtx / n0, D == 3 ? vtx / (n0 * n1) : 0};
   const int64_t vstride[3] = {1, n0, n0 * n1};
@@ -1291,6 +1313,8 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   A.phi = dphi; A.f = df; A.ud = dud; A.gamma = pen_coef; A.sigma = stab_coef;
   A.rhs = s->rhs; A.nv = (int32_t)m->nv;
   uint8_t *touched = nullptr;
+  int32_t *stored_rows = nullptr;   // structured systems without a CSR copy: active indices of the rows that are stored
+  int64_t n_stored_rows = 0;
   const bool structured = m->is_box && !m->is_submesh && m->structured != 0;
   int64_t slot_rows = s->n;
   if (m->is_box && !m->is_submesh) {
@@ -1355,6 +1379,11 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
       while ((1 << lg) < W) ++lg;
       k_slot_offsets<<<dim3((unsigned)phx_div_up(s->n, 256)), block, 0, m->stream>>>(s->n, W, lg, s->c0, rank, off, wl);
       sl.off = off; sl.wlog = wl;
+      if (nstored > 0) {   // the stored rows as a list: work list of the row kernel (mode 2)
+        PHX_HIP(phx_malloc(&stored_rows, sizeof(int32_t) * (size_t)nstored));
+        k_flagged_list<<<dim3((unsigned)phx_div_up(s->n, 256)), block, 0, m->stream>>>(s->n, notc0, rank, stored_rows);
+        n_stored_rows = nstored;
+      }
       PHX_HIP(hipStreamSynchronize(m->stream));
       PHX_HIP(phx_free(rank)); PHX_HIP(phx_free(notc0));
     }
@@ -1374,8 +1403,14 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
     if (m->is_box) {
       const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}, {m->box_h[0], m->box_h[1], m->box_h[2]}};
       const dim3 g((unsigned)phx_div_up(m->nv, 256));
-      if (D == 2) k_assemble_rows_box<2><<<g, block, 0, m->stream>>>(m->nv, bd, A);
-      else k_assemble_rows_box<3><<<g, block, 0, m->stream>>>(m->nv, bd, A);
+      const int mode = stored_rows ? 1 : 0;
+      if (D == 2) k_assemble_rows_box<2><<<g, block, 0, m->stream>>>(m->nv, bd, A, mode, nullptr, nullptr, s->nu);
+      else k_assemble_rows_box<3><<<g, block, 0, m->stream>>>(m->nv, bd, A, mode, nullptr, nullptr, s->nu);
+      if (stored_rows && n_stored_rows > 0) {
+        const dim3 g2((unsigned)phx_div_up(n_stored_rows, 256));
+        if (D == 2) k_assemble_rows_box<2><<<g2, block, 0, m->stream>>>(n_stored_rows, bd, A, 2, stored_rows, s->full_of_active, s->nu);
+        else k_assemble_rows_box<3><<<g2, block, 0, m->stream>>>(n_stored_rows, bd, A, 2, stored_rows, s->full_of_active, s->nu);
+      }
     } else {
       const dim3 g((unsigned)phx_div_up(m->nv, ROW_THREADS)), b(ROW_THREADS);
       if (D == 2) k_assemble_rows<2><<<g, b, 0, m->stream>>>(m->nv, m->v2c_ptr, m->v2c_idx, A);
@@ -1425,6 +1460,7 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_fac));
   if (touched) PHX_HIP(phx_free(touched));
+  if (stored_rows) PHX_HIP(phx_free(stored_rows));
   {
     const int rc = structured ? finish_structured(s, sl, (int32_t)m->nv, m->export_csr != 0)
                               : phx_finish_system(s, sl, (int32_t)m->nv);
