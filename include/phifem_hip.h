@@ -289,7 +289,10 @@ enum phx_method { PHX_BICGSTAB_JACOBI = 0 };
  *            average SpMV seconds and launches timed (PHX_OPT_PROFILE_SPMV),
  *            converged (1: relative residual <= rtol; 0: max_iter reached -- the reference solves directly,
  *            its callers assume an accurate x: treat 0 as a failure), breakdown restarts}.
- * Returns PHX_OK also when max_iter was reached: check stats[6]. */
+ * Returns PHX_OK also when max_iter was reached: check stats[6].
+ * The residual that is reported (and tested against rtol) is the TRUE one: when the recurrences announce
+ * convergence, b - A x is evaluated once and, if it does not meet rtol (drift after thousands of iterations on
+ * ill-conditioned systems), the iteration restarts from it. */
 int phx_solve(phx_system *s, int method, double rtol, int64_t max_iter, double *x, int loc,
               double *stats);
 

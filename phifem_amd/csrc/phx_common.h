@@ -205,6 +205,8 @@ int phx_mesh_alloc_common(phx_mesh *m);
 int phx_begin_timing(phx_mesh *m);
 int phx_end_timing(phx_mesh *m, int slot);
 int phx_mesh_build_edges(phx_mesh *m);
+int phx_mesh_create_from(int gdim, int cell_type, int64_t nv, const double *coords, int64_t nc,
+                         const int32_t *cells, int loc, int device, phx_mesh **out);
 int phx_mesh_pinned_scalars(phx_mesh *m, double **out);
 
 int phx_system_build_empty(phx_system *s);  // phx_solve.hip

@@ -423,46 +423,77 @@ static bool detect_lattice(int gdim, int nvpc, int64_t nv, const double *coords,
   return true;
 }
 
-extern "C" int phx_mesh_create(int gdim, int cell_type, int64_t nv, const double *coords,
-                               int64_t nc, const int32_t *cells, int device, phx_mesh **out) {
+#include "phx_topology.inc.hip"
+
+// coords / cells at `loc` (host arrays from a caller, or device arrays of a parent mesh: phx_submesh.hip).  The facet
+// numbering and both connectivities are built on the device (phx_topology.inc.hip); PHX_TOPOLOGY_HOST=1 takes the
+// host sort of phx_topology_build_host instead (same numbering; A/B aid, host inputs only).
+int phx_mesh_create_from(int gdim, int cell_type, int64_t nv, const double *coords, int64_t nc,
+                         const int32_t *cells, int loc, int device, phx_mesh **out) {
   phx_cell_info ci;
   PHX_CHECK(phx_get_cell_info(cell_type, &ci));
   PHX_REQUIRE(gdim == ci.tdim, PHX_ERR_VALUE, "gdim %d does not match the cell type", gdim);
+  PHX_REQUIRE(nc > 0 && nv > 0, PHX_ERR_VALUE, "empty mesh");
   PHX_REQUIRE(nc * (int64_t)ci.nfpc < INT32_MAX, PHX_ERR_VALUE, "mesh too large for 32-bit local ids");
-  std::vector<int32_t> c2f((size_t)nc * ci.nfpc), f2c((size_t)nc * ci.nfpc * 2);
-  int64_t nf = 0;
-  PHX_CHECK(phx_topology_build_host(cell_type, nv, nc, cells, c2f.data(), f2c.data(), &nf));
+  static const bool host_topo = getenv("PHX_TOPOLOGY_HOST") && atoi(getenv("PHX_TOPOLOGY_HOST")) != 0;
   phx_mesh *m = new phx_mesh();
   int rc = mesh_init_device(m, device);
   if (rc != PHX_OK) { delete m; return rc; }
   m->gdim = gdim; m->cell_type = cell_type; m->ci = ci;
-  m->nv = nv; m->nc = nc; m->nf = nf;
-  PHX_HIP(phx_malloc(&m->x, sizeof(double) * (size_t)nv * gdim));
-  PHX_HIP(phx_malloc(&m->cells, sizeof(int32_t) * (size_t)nc * ci.nvpc));
-  PHX_HIP(phx_malloc(&m->c2f, sizeof(int32_t) * (size_t)nc * ci.nfpc));
-  PHX_HIP(phx_malloc(&m->f2c, sizeof(int32_t) * (size_t)nf * 2));
-  PHX_HIP(hipMemcpy(m->x, coords, sizeof(double) * (size_t)nv * gdim, hipMemcpyHostToDevice));
-  PHX_HIP(hipMemcpy(m->cells, cells, sizeof(int32_t) * (size_t)nc * ci.nvpc, hipMemcpyHostToDevice));
-  PHX_HIP(hipMemcpy(m->c2f, c2f.data(), sizeof(int32_t) * (size_t)nc * ci.nfpc, hipMemcpyHostToDevice));
-  PHX_HIP(hipMemcpy(m->f2c, f2c.data(), sizeof(int32_t) * (size_t)nf * 2, hipMemcpyHostToDevice));
-  PHX_CHECK(build_boundary_list(m));
-  PHX_CHECK(phx_mesh_alloc_common(m));
-  if (cell_type == PHX_TRIANGLE || cell_type == PHX_TETRAHEDRON) {
+  m->nv = nv; m->nc = nc;
+  const hipMemcpyKind kind = loc == PHX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  auto fail = [&](int code) { phx_mesh_destroy(m); return code; };
+  if (phx_malloc(&m->x, sizeof(double) * (size_t)nv * gdim) != hipSuccess ||
+      phx_malloc(&m->cells, sizeof(int32_t) * (size_t)nc * ci.nvpc) != hipSuccess ||
+      hipMemcpy(m->x, coords, sizeof(double) * (size_t)nv * gdim, kind) != hipSuccess ||
+      hipMemcpy(m->cells, cells, sizeof(int32_t) * (size_t)nc * ci.nvpc, kind) != hipSuccess) {
+    phx_set_error("mesh upload failed");
+    return fail(PHX_ERR_HIP);
+  }
+  if (host_topo && loc != PHX_DEVICE) {
+    std::vector<int32_t> c2f((size_t)nc * ci.nfpc), f2c((size_t)nc * ci.nfpc * 2);
+    int64_t nf = 0;
+    rc = phx_topology_build_host(cell_type, nv, nc, cells, c2f.data(), f2c.data(), &nf);
+    if (rc != PHX_OK) return fail(rc);
+    m->nf = nf;
+    if (phx_malloc(&m->c2f, sizeof(int32_t) * (size_t)nc * ci.nfpc) != hipSuccess ||
+        phx_malloc(&m->f2c, sizeof(int32_t) * (size_t)nf * 2) != hipSuccess ||
+        hipMemcpy(m->c2f, c2f.data(), sizeof(int32_t) * (size_t)nc * ci.nfpc, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->f2c, f2c.data(), sizeof(int32_t) * (size_t)nf * 2, hipMemcpyHostToDevice) != hipSuccess) {
+      phx_set_error("mesh upload failed");
+      return fail(PHX_ERR_HIP);
+    }
+  } else {
+    rc = phx_topology_build_device(m);
+    if (rc != PHX_OK) return fail(rc);
+  }
+  rc = build_boundary_list(m);
+  if (rc == PHX_OK) rc = phx_mesh_alloc_common(m);
+  if (rc != PHX_OK) return fail(rc);
+  if (loc != PHX_DEVICE && (cell_type == PHX_TRIANGLE || cell_type == PHX_TETRAHEDRON)) {
     std::vector<int32_t> v2lat, lat2v;
     int64_t ln[3];
     double lh[3];
     if (detect_lattice(gdim, ci.nvpc, nv, coords, nc, cells, ln, lh, v2lat, lat2v)) {
       m->on_box_lattice = true;
       for (int a = 0; a < 3; ++a) { m->box_n[a] = ln[a]; m->box_h[a] = lh[a]; }
-      PHX_HIP(phx_malloc(&m->v2lat, sizeof(int32_t) * (size_t)nv));
-      PHX_HIP(phx_malloc(&m->lat2v, sizeof(int32_t) * (size_t)nv));
-      PHX_HIP(hipMemcpy(m->v2lat, v2lat.data(), sizeof(int32_t) * (size_t)nv, hipMemcpyHostToDevice));
-      PHX_HIP(hipMemcpy(m->lat2v, lat2v.data(), sizeof(int32_t) * (size_t)nv, hipMemcpyHostToDevice));
+      if (phx_malloc(&m->v2lat, sizeof(int32_t) * (size_t)nv) != hipSuccess ||
+          phx_malloc(&m->lat2v, sizeof(int32_t) * (size_t)nv) != hipSuccess ||
+          hipMemcpy(m->v2lat, v2lat.data(), sizeof(int32_t) * (size_t)nv, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(m->lat2v, lat2v.data(), sizeof(int32_t) * (size_t)nv, hipMemcpyHostToDevice) != hipSuccess) {
+        phx_set_error("mesh upload failed");
+        return fail(PHX_ERR_HIP);
+      }
     }
   }
-  PHX_HIP(hipStreamSynchronize(m->stream));
+  if (hipStreamSynchronize(m->stream) != hipSuccess) return fail(PHX_ERR_HIP);
   *out = m;
   return PHX_OK;
+}
+
+extern "C" int phx_mesh_create(int gdim, int cell_type, int64_t nv, const double *coords,
+                               int64_t nc, const int32_t *cells, int device, phx_mesh **out) {
+  return phx_mesh_create_from(gdim, cell_type, nv, coords, nc, cells, PHX_HOST, device, out);
 }
 
 // ------------------------------------------------------------------------------------------
