@@ -8,7 +8,7 @@
 // Only ACTIVE DoFs get rows (u on vertices of cells tagged 1/2, p on vertices of cut cells): the
 // reference's matrix has empty rows elsewhere and relies on MUMPS null-pivot detection
 // (main.py:169-173); restricting to the active set is the same solution (hard part 2).
-#include <hipcub/hipcub.hpp>
+#include "phx_prim.h"
 #include <string.h>
 
 #include <algorithm>
@@ -1086,10 +1086,10 @@ k_row_fill_list(int64_t nlist, const int32_t *__restrict__ list, const int64_t *
 template <typename T>
 static int exclusive_sum(phx_mesh *m, const T *in, T *out, int64_t n) {
   size_t bytes = 0;
-  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, m->stream));
+  PHX_HIP(phx_exclusive_sum(nullptr, bytes, in, out, (size_t)(n), m->stream));
   void *tmp = nullptr;
   PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, m->stream));
+  PHX_HIP(phx_exclusive_sum(tmp, bytes, in, out, (size_t)(n), m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(tmp));
   return PHX_OK;
@@ -1100,12 +1100,12 @@ struct U8ToI32 {
 };
 
 static int scan_flags(phx_mesh *m, const uint8_t *flags, int32_t *out, int64_t n, int32_t *total) {
-  hipcub::TransformInputIterator<int32_t, U8ToI32, const uint8_t *> it(flags, U8ToI32());
+  auto it = rocprim::make_transform_iterator(flags, U8ToI32());
   size_t bytes = 0;
-  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, (int)n, m->stream));
+  PHX_HIP(phx_exclusive_sum(nullptr, bytes, it, out, (size_t)(n), m->stream));
   void *tmp = nullptr;
   PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, out, (int)n, m->stream));
+  PHX_HIP(phx_exclusive_sum(tmp, bytes, it, out, (size_t)(n), m->stream));
   int32_t last = 0;
   uint8_t lastf = 0;
   PHX_HIP(hipMemcpyAsync(&last, out + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));

@@ -2,7 +2,7 @@
 // Kuhn boxes, detection-point tables.  Replaces the dolfinx mesh/topology services the reference
 // calls at src/phifem/mesh_scripts.py:151-153,308-315,419-422,430 and
 // demo/weak-dirichlet/flower/main.py:45-46.  gfx950 only.
-#include <hipcub/hipcub.hpp>
+#include "phx_prim.h"
 #include <stdarg.h>
 #include <string.h>
 

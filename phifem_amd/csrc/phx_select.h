@@ -5,7 +5,7 @@
 // and the per-chunk counts are scanned in between -- two streaming passes over the tag bytes instead
 // of a generic look-back select (measured on 2e8 facets: 2.0 ms -> see DESIGN.md).
 #pragma once
-#include <hipcub/hipcub.hpp>
+#include "phx_prim.h"
 #include <utility>
 
 #include "phx_common.h"
@@ -80,10 +80,10 @@ static int phx_select_indices(hipStream_t stream, int64_t n, Pred pred, int32_t 
   const dim3 block(256), grid((unsigned)phx_div_up(nchunks, 4));
   if (n > 0) k_select_chunks<Pred, false><<<grid, block, 0, stream>>>(n, pred, cnt, nullptr, nullptr);
   size_t bytes = 0;
-  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt, off, (int)(nchunks + 1), stream));
+  PHX_HIP(phx_exclusive_sum(nullptr, bytes, cnt, off, (size_t)(nchunks + 1), stream));
   void *tmp = nullptr;
   PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, cnt, off, (int)(nchunks + 1), stream));
+  PHX_HIP(phx_exclusive_sum(tmp, bytes, cnt, off, (size_t)(nchunks + 1), stream));
   int32_t total = 0;
   PHX_HIP(hipMemcpyAsync(&total, off + nchunks, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   PHX_HIP(hipStreamSynchronize(stream));

@@ -9,7 +9,7 @@
 // by length with a STABLE sort (removes the padding, keeps equal-length rows in natural order), and
 // the whole system is renumbered into that order so y is written coalesced.  Explicitly stored zeros
 // of the assembled CSR are not carried into the SELL copy.
-#include <hipcub/hipcub.hpp>
+#include "phx_prim.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -225,10 +225,10 @@ int phx_system_build_sell(phx_system *s) {
   int end_bit = 10;
   for (int64_t w = (n - 1) / g_sell_window; w > 0; w >>= 1) ++end_bit;
   size_t bytes = 0;
-  PHX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys2, rows, s->perm, (int)n, 0, end_bit, m->stream));
+  PHX_HIP(phx_sort_pairs(nullptr, bytes, keys, keys2, rows, s->perm, (size_t)n, 0, end_bit, m->stream));
   void *tmp = nullptr;
   PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-  PHX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys, keys2, rows, s->perm, (int)n, 0, end_bit, m->stream));
+  PHX_HIP(phx_sort_pairs(tmp, bytes, keys, keys2, rows, s->perm, (size_t)n, 0, end_bit, m->stream));
   k_invert_perm<<<grid, block, 0, m->stream>>>(n, s->perm, s->iperm);
   s->nslices = phx_div_up(n, SELL_C);
   int64_t *widths = nullptr;
@@ -238,10 +238,10 @@ int phx_system_build_sell(phx_system *s) {
       s->nslices, n, keys2, widths);
   {
     size_t b2 = 0;
-    PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, widths, s->slice_ptr, (int)(s->nslices + 1), m->stream));
+    PHX_HIP(phx_exclusive_sum(nullptr, b2, widths, s->slice_ptr, (size_t)(s->nslices + 1), m->stream));
     void *t2 = nullptr;
     PHX_HIP(phx_malloc(&t2, b2 ? b2 : 16));
-    PHX_HIP(hipcub::DeviceScan::ExclusiveSum(t2, b2, widths, s->slice_ptr, (int)(s->nslices + 1), m->stream));
+    PHX_HIP(phx_exclusive_sum(t2, b2, widths, s->slice_ptr, (size_t)(s->nslices + 1), m->stream));
     PHX_HIP(hipStreamSynchronize(m->stream));
     PHX_HIP(phx_free(t2));
   }
@@ -558,12 +558,12 @@ __global__ void k_map_i32(int64_t n, const int32_t *__restrict__ map, int32_t *_
 
 struct U8AsI32 { __host__ __device__ int32_t operator()(const uint8_t &a) const { return (int32_t)a; } };
 static int scan_u8(hipStream_t st, const uint8_t *flags, int32_t *out, int64_t n, int32_t *total) {
-  hipcub::TransformInputIterator<int32_t, U8AsI32, const uint8_t *> it(flags, U8AsI32());
+  auto it = rocprim::make_transform_iterator(flags, U8AsI32());
   size_t bytes = 0;
-  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, (int)n, st));
+  PHX_HIP(phx_exclusive_sum(nullptr, bytes, it, out, (size_t)(n), st));
   void *tmp = nullptr;
   PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, it, out, (int)n, st));
+  PHX_HIP(phx_exclusive_sum(tmp, bytes, it, out, (size_t)(n), st));
   int32_t last = 0;
   uint8_t lastf = 0;
   PHX_HIP(hipMemcpyAsync(&last, out + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -643,20 +643,20 @@ int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t 
     k_stored_keys<<<gs, block, 0, st>>>(ns, list, len, keys, s->full_of_active, m->nv, n0, n01, tile, tn[0], tn[1]);
     k_fill_i32<<<dim3((unsigned)phx_div_up(s->nslices * SELL_S, 256)), block, 0, st>>>(s->nslices * SELL_S, rows_active, -1, 0);
     size_t bytes = 0;
-    PHX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys, keys2, list, rows_active, (int)ns, 0, key_bits, st));
+    PHX_HIP(phx_sort_pairs(nullptr, bytes, keys, keys2, list, rows_active, (size_t)ns, 0, key_bits, st));
     void *tmp = nullptr;
     PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-    PHX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, keys, keys2, list, rows_active, (int)ns, 0, key_bits, st));
+    PHX_HIP(phx_sort_pairs(tmp, bytes, keys, keys2, list, rows_active, (size_t)ns, 0, key_bits, st));
     PHX_HIP(hipMemcpyAsync(s->sell_rows, rows_active, sizeof(int32_t) * (size_t)(s->nslices * SELL_S), hipMemcpyDeviceToDevice, st));
     k_map_i32<<<dim3((unsigned)phx_div_up(s->nslices * SELL_S, 256)), block, 0, st>>>(s->nslices * SELL_S, s->iperm, s->sell_rows);
     int64_t *widths = nullptr;
     PHX_HIP(phx_malloc(&widths, sizeof(int64_t) * (size_t)(s->nslices + 1)));
     k_slice_widths16<<<dim3((unsigned)phx_div_up(s->nslices + 1, 256)), block, 0, st>>>(s->nslices, ns, keys2, widths);
     size_t b2 = 0;
-    PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, widths, s->slice_ptr, (int)(s->nslices + 1), st));
+    PHX_HIP(phx_exclusive_sum(nullptr, b2, widths, s->slice_ptr, (size_t)(s->nslices + 1), st));
     void *t2 = nullptr;
     PHX_HIP(phx_malloc(&t2, b2 ? b2 : 16));
-    PHX_HIP(hipcub::DeviceScan::ExclusiveSum(t2, b2, widths, s->slice_ptr, (int)(s->nslices + 1), st));
+    PHX_HIP(phx_exclusive_sum(t2, b2, widths, s->slice_ptr, (size_t)(s->nslices + 1), st));
     PHX_HIP(hipMemcpyAsync(&s->sell_nnz, s->slice_ptr + s->nslices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PHX_HIP(hipStreamSynchronize(st));
     PHX_HIP(phx_free(tmp)); PHX_HIP(phx_free(t2)); PHX_HIP(phx_free(widths)); PHX_HIP(phx_free(keys)); PHX_HIP(phx_free(keys2));

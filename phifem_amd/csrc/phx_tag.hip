@@ -6,7 +6,7 @@
 // loads, one byte written per entity).  This file is compiled with -ffp-contract=off: the tags
 // hang on exact float compares (mesh_scripts.py:343-347), so every sum is evaluated in the order
 // the oracle spells out and without fused multiply-add.
-#include <hipcub/hipcub.hpp>
+#include "phx_prim.h"
 #include <string.h>
 
 #include <algorithm>
@@ -286,7 +286,7 @@ k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restri
 // --- a6: (facet, cell) incidences of a one-sided measure -------------------------------------
 // key = 2*facet + position of the cell in the reversed link list (mesh_scripts.py:210-213), so a
 // host-side sort by key reproduces the reference's first-seen order.
-// Facets tagged 3 or 4 are compacted first (hipcub select); a count / scan / fill over that short
+// Facets tagged 3 or 4 are compacted first (ordered select); a count / scan / fill over that short
 // list then places the entries without any contended counter (a single global append counter
 // serialises: the matches are ~1 per wavefront, 4 ms at 2*10^8 facets).
 //   which 0 -> ds(100): facets tagged 4 seen from cells {1,2}   (mesh_scripts.py:619-622)
@@ -635,10 +635,10 @@ int phx_collect_entities(phx_mesh *m) {
   for (int w = 0; w < 2; ++w) {
     size_t bytes = 0;
     int32_t *ci = w == 0 ? cnt0 : cnt1, *oi = w == 0 ? off0 : off1;
-    PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, ci, oi, (int)(nmax + 1), st));
+    PHX_HIP(phx_exclusive_sum(nullptr, bytes, ci, oi, (size_t)(nmax + 1), st));
     void *tmp = nullptr;
     PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-    PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, ci, oi, (int)(nmax + 1), st));
+    PHX_HIP(phx_exclusive_sum(tmp, bytes, ci, oi, (size_t)(nmax + 1), st));
     int32_t tot = 0;
     PHX_HIP(hipMemcpyAsync(&tot, oi + nmax, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     PHX_HIP(hipStreamSynchronize(st));

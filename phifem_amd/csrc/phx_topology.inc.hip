@@ -95,28 +95,28 @@ static int phx_topology_build_device(phx_mesh *m) {
   k_facet_keys<<<grid, block, 0, st>>>(m->nc, T, m->cells, m->nv, hi, lo, idx, bad);
   size_t b1 = 0, b2 = 0, b3 = 0;
   // least significant first: v2 (3-D only), then (v0, v1); radix sorts are stable, so equal tuples stay in record order
-  PHX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, lo, lo2, idx, idx2, (int)n, 0, 32, st));
-  PHX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, b2, hi, hi2, idx, idx2, (int)n, 0, 64, st));
-  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, b3, hipcub::TransformInputIterator<int32_t, TopoU8ToI32, const uint8_t *>(head, TopoU8ToI32()), rank, (int)n, st));
+  PHX_HIP(phx_sort_pairs(nullptr, b1, lo, lo2, idx, idx2, (size_t)n, 0, 32, st));
+  PHX_HIP(phx_sort_pairs(nullptr, b2, hi, hi2, idx, idx2, (size_t)n, 0, 64, st));
+  PHX_HIP(phx_exclusive_sum(nullptr, b3, rocprim::make_transform_iterator(head, TopoU8ToI32()), rank, (size_t)(n), st));
   void *tmp = nullptr;
   PHX_HIP(phx_malloc(&tmp, std::max(std::max(b1, b2), std::max(b3, (size_t)16))));
   int32_t *order = idx;     // permutation after the sorts
   if (ci.nvpf == 3) {
-    PHX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, b1, lo, lo2, idx, idx2, (int)n, 0, 32, st));
+    PHX_HIP(phx_sort_pairs(tmp, b1, lo, lo2, idx, idx2, (size_t)n, 0, 32, st));
     // bring the major keys into the order of the first pass, sort by them
     k_gather_u64<<<grid, block, 0, st>>>(n, idx2, hi, hi2);
-    PHX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, b2, hi2, hi, idx2, idx, (int)n, 0, 64, st));
+    PHX_HIP(phx_sort_pairs(tmp, b2, hi2, hi, idx2, idx, (size_t)n, 0, 64, st));
     order = idx;            // sorted major keys in `hi`
     k_gather_u32<<<grid, block, 0, st>>>(n, order, lo, lo2);   // lo (unsorted, by record) -> lo2 in final order
   } else {
-    PHX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, b2, hi, hi2, idx, idx2, (int)n, 0, 64, st));
+    PHX_HIP(phx_sort_pairs(tmp, b2, hi, hi2, idx, idx2, (size_t)n, 0, 64, st));
     order = idx2;
     // sorted major keys are in hi2: move to hi for the code below
     PHX_HIP(hipMemcpyAsync(hi, hi2, sizeof(unsigned long long) * (size_t)n, hipMemcpyDeviceToDevice, st));
     PHX_HIP(hipMemsetAsync(lo2, 0, sizeof(uint32_t) * (size_t)n, st));
   }
   k_facet_heads<<<grid, block, 0, st>>>(n, hi, lo2, head);
-  PHX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp, b3, hipcub::TransformInputIterator<int32_t, TopoU8ToI32, const uint8_t *>(head, TopoU8ToI32()), rank, (int)n, st));
+  PHX_HIP(phx_exclusive_sum(tmp, b3, rocprim::make_transform_iterator(head, TopoU8ToI32()), rank, (size_t)(n), st));
   int32_t last_rank = 0;
   uint8_t last_head = 0;
   PHX_HIP(hipMemcpyAsync(&last_rank, rank + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
