@@ -380,3 +380,33 @@ def test_device_expression_equals_host_callable(P, d, n, deg):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             P.compute_tags_measures(m, DeviceExpression(lambda x: np.zeros(3)), deg, box_mode=True)
+
+
+def test_device_topology_rejects_bad_meshes_and_matches_the_host_helper(P):
+    """The facet numbering of a caller-supplied mesh is built on the device (phx_topology.inc.hip): same c2f / f2c as
+    the exported host helper phx_topology_build_host on a shuffled unstructured mesh, and the same errors -- a vertex
+    index out of range, a facet shared by three cells."""
+    import ctypes as C
+    L = P._lib
+    ctype, x, cells = load_mesh("coarse_square")
+    rng = np.random.default_rng(3)
+    cells = cells[rng.permutation(cells.shape[0])].astype(np.int32)
+    m = P.Mesh.from_arrays(ctype, x, cells)
+    nfpc = m.c2f.shape[1]
+    c2f = np.empty((cells.shape[0], nfpc), dtype=np.int32)
+    f2c = np.empty((cells.shape[0] * nfpc, 2), dtype=np.int32)
+    nf = C.c_int64(0)
+    L.check(L.lib.phx_topology_build_host(L.CELL_TYPES[ctype], x.shape[0], cells.shape[0],
+                                          cells.ctypes.data_as(C.c_void_p), c2f.ctypes.data_as(C.c_void_p),
+                                          f2c.ctypes.data_as(C.c_void_p), C.byref(nf)))
+    assert m.nf == nf.value
+    assert np.array_equal(m.c2f, c2f) and np.array_equal(m.f2c, f2c[:nf.value])
+    bad = cells.copy()
+    bad[0, 0] = x.shape[0] + 5
+    with pytest.raises(ValueError):
+        P.Mesh.from_arrays(ctype, x, bad)
+    # three triangles on one edge: non-manifold
+    xt = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0], [0.5, -1.0]])
+    tri = np.array([[0, 1, 2], [0, 1, 3], [0, 1, 4]], dtype=np.int32)
+    with pytest.raises(ValueError):
+        P.Mesh.from_arrays("triangle", xt, tri)
