@@ -1538,9 +1538,11 @@ extern "C" int phx_system_get_perm(phx_system *s, int32_t *perm, int32_t *dof_u,
                                    int loc) {
   PHX_HIP(hipSetDevice(s->mesh->device));
   const hipMemcpyKind k = loc == PHX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-  if (perm) PHX_HIP(hipMemcpy(perm, s->perm, sizeof(int32_t) * (size_t)s->n, k));
-  if (dof_u) PHX_HIP(hipMemcpy(dof_u, s->dof_of_vertex_u, sizeof(int32_t) * (size_t)s->nent, k));
-  if (dof_p) PHX_HIP(hipMemcpy(dof_p, s->dof_of_vertex_p, sizeof(int32_t) * (size_t)s->nent, k));
+  hipStream_t st = s->mesh->stream;   // device-to-device copies do not wait on the host side: stream + explicit wait
+  if (perm) PHX_HIP(hipMemcpyAsync(perm, s->perm, sizeof(int32_t) * (size_t)s->n, k, st));
+  if (dof_u) PHX_HIP(hipMemcpyAsync(dof_u, s->dof_of_vertex_u, sizeof(int32_t) * (size_t)s->nent, k, st));
+  if (dof_p) PHX_HIP(hipMemcpyAsync(dof_p, s->dof_of_vertex_p, sizeof(int32_t) * (size_t)s->nent, k, st));
+  PHX_HIP(hipStreamSynchronize(st));
   return PHX_OK;
 }
 

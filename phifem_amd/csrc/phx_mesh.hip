@@ -361,8 +361,11 @@ static int build_boundary_list(phx_mesh *m) {
         nbf, sel, m->f2c, m->c2f, m->ci.nfpc, m->bfacets);
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_malloc(&m->bfacet_ids, sizeof(int32_t) * (size_t)(nbf > 0 ? nbf : 1)));
-  if (nbf > 0)
-    PHX_HIP(hipMemcpy(m->bfacet_ids, sel, sizeof(int32_t) * (size_t)nbf, hipMemcpyDeviceToDevice));
+  if (nbf > 0) {
+    // device-to-device hipMemcpy does not wait on the host side: keep it on the mesh's stream and wait before `sel` goes
+    PHX_HIP(hipMemcpyAsync(m->bfacet_ids, sel, sizeof(int32_t) * (size_t)nbf, hipMemcpyDeviceToDevice, m->stream));
+    PHX_HIP(hipStreamSynchronize(m->stream));
+  }
   PHX_HIP(phx_free(sel));
   return PHX_OK;
 }
@@ -443,10 +446,13 @@ int phx_mesh_create_from(int gdim, int cell_type, int64_t nv, const double *coor
   m->nv = nv; m->nc = nc;
   const hipMemcpyKind kind = loc == PHX_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   auto fail = [&](int code) { phx_mesh_destroy(m); return code; };
+  // (a device-to-device hipMemcpy returns before the copy has run and the mesh's stream does not wait for the null
+  // stream: device sources are copied ON the mesh's stream, ahead of the kernels that read them)
   if (phx_malloc(&m->x, sizeof(double) * (size_t)nv * gdim) != hipSuccess ||
       phx_malloc(&m->cells, sizeof(int32_t) * (size_t)nc * ci.nvpc) != hipSuccess ||
-      hipMemcpy(m->x, coords, sizeof(double) * (size_t)nv * gdim, kind) != hipSuccess ||
-      hipMemcpy(m->cells, cells, sizeof(int32_t) * (size_t)nc * ci.nvpc, kind) != hipSuccess) {
+      hipMemcpyAsync(m->x, coords, sizeof(double) * (size_t)nv * gdim, kind, m->stream) != hipSuccess ||
+      hipMemcpyAsync(m->cells, cells, sizeof(int32_t) * (size_t)nc * ci.nvpc, kind, m->stream) != hipSuccess ||
+      hipStreamSynchronize(m->stream) != hipSuccess) {
     phx_set_error("mesh upload failed");
     return fail(PHX_ERR_HIP);
   }

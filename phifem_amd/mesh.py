@@ -1,6 +1,8 @@
 """Mesh handle resident in HBM + MeshTags view (host side of the C ABI)."""
 import ctypes as C
 
+import weakref
+
 import numpy as np
 
 from . import _lib as L
@@ -22,12 +24,44 @@ class MeshTags:
         return self.indices[self.values == v]
 
 
+class LazyMeshTags(MeshTags):
+    """MeshTags whose host arrays are fetched from the device on first use.  The tags of a 256^3 box are 3e8 bytes
+    on the device; `compute_tags_measures` must return MeshTags objects (src/phifem/mesh_scripts.py:647-653), but a
+    caller that goes on to assemble and solve never looks at them.  The mesh flushes every outstanding object
+    before its tags change again (`Mesh._flush_lazy_tags`), so what is read is always the state at creation."""
+
+    def __init__(self, dim, mesh, facets):
+        self.dim = int(dim)
+        self._mesh, self._facets = mesh, facets
+        self._idx = self._val = None
+        mesh._lazy_tags.add(self)
+
+    def _load(self):
+        if self._idx is None:
+            m = self._mesh
+            vals = m.facet_tag_values() if self._facets else m.cell_tag_values()
+            idx = np.flatnonzero(vals > 0).astype(np.int32)
+            self._idx, self._val = idx, np.ascontiguousarray(vals[idx], dtype=np.int32)
+            self._mesh = None
+
+    @property
+    def indices(self):
+        self._load()
+        return self._idx
+
+    @property
+    def values(self):
+        self._load()
+        return self._val
+
+
 class Mesh:
     """Owns a `phx_mesh*`.  Arrays stay on the GPU; accessors copy on demand."""
 
     def __init__(self, handle, parent=None, device=None):
         self._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
         self.parent = parent
+        self._lazy_tags = weakref.WeakSet()
         self.device = int(device) if device is not None else (parent.device if parent is not None else 0)
         cnt = (C.c_int64 * 6)()
         L.check(L.lib.phx_mesh_counts(self._h, cnt))
@@ -63,6 +97,11 @@ class Mesh:
             pass
 
     # --- accessors ----------------------------------------------------------------------
+    def _flush_lazy_tags(self):
+        """Materialise the MeshTags handed out so far (called before the tags of this mesh change)."""
+        for t in list(self._lazy_tags):
+            t._load()
+
     def _get(self, which, shape, dtype):
         out = np.empty(shape, dtype=dtype)
         L.check(L.lib.phx_mesh_get_array(self._h, which, out.ctypes.data_as(C.c_void_p), L.HOST))

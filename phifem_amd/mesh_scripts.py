@@ -10,7 +10,7 @@ import warnings
 import numpy as np
 
 from . import _lib as L
-from .mesh import Mesh, MeshTags
+from .mesh import LazyMeshTags, Mesh, MeshTags
 
 # mesh_scripts.py:22-25
 debug_mode = os.environ.get("MODE", "") == "debug"
@@ -329,9 +329,7 @@ def _tag_facets(mesh, staged, detection_degree):
 
 
 def _meshtags(mesh, facets):
-    vals = mesh.facet_tag_values() if facets else mesh.cell_tag_values()
-    idx = np.flatnonzero(vals > 0).astype(np.int32)
-    return MeshTags(mesh.tdim - 1 if facets else mesh.tdim, idx, vals[idx])
+    return LazyMeshTags(mesh.tdim - 1 if facets else mesh.tdim, mesh, facets)
 
 
 def compute_tags_measures(mesh, discrete_levelset, detection_degree, box_mode=False,
@@ -351,6 +349,7 @@ def compute_tags_measures(mesh, discrete_levelset, detection_degree, box_mode=Fa
 
     Returns (cells_tags, facets_tags, submesh|None, boundaries_measure, submesh_maps|None).
     """
+    mesh._flush_lazy_tags()     # MeshTags of an earlier call keep the state they were created in
     staged = _tag_cells(mesh, discrete_levelset, detection_degree, single_layer_cut)
     if debug_mode:
         cv = mesh.cell_tag_values()
