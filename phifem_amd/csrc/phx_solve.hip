@@ -1538,8 +1538,8 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
   PHX_CHECK(kr_phase(s, 0, 0, 0));
   // The host looks at the residual every 8th iteration with Jacobi (cheap iterations).  With the box preconditioner
   // (few, expensive iterations) a check drains the pipeline for ~30 us, so the next one is scheduled from the
-  // observed convergence rate: a quarter of the predicted remaining iterations ahead, at least 2 -- near the end every
-  // 2nd iteration, so no iteration is wasted on a late check (28 -> ~10 drains over 56 iterations).
+  // observed convergence rate: half of the predicted remaining iterations ahead (at most 12, at least 2) -- near the
+  // end every 2nd iteration, so no iteration is wasted on a late check (28 -> ~9 drains over 56 iterations).
   const bool pc = s->precond_state == 1;
   PHX_CHECK(kr_phase(s, 1, 0, 0));
   PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
@@ -1579,7 +1579,7 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
           // iterations still needed at the rate seen since the last check
           const double rate = log(last_relres / relres) / (double)(it - last_check);
           const double remaining = log(relres / rtol) / rate;
-          step = std::max<int64_t>(2, std::min<int64_t>(6, (int64_t)(0.25 * remaining)));
+          step = std::max<int64_t>(2, std::min<int64_t>(12, (int64_t)(0.5 * remaining)));
           step &= ~(int64_t)1;   // checks stay on even iterations
         }
         last_check = it;
