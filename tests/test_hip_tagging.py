@@ -410,3 +410,21 @@ def test_device_topology_rejects_bad_meshes_and_matches_the_host_helper(P):
     tri = np.array([[0, 1, 2], [0, 1, 3], [0, 1, 4]], dtype=np.int32)
     with pytest.raises(ValueError):
         P.Mesh.from_arrays("triangle", xt, tri)
+
+
+def test_meshtags_keep_the_state_they_were_created_in(P):
+    """compute_tags_measures hands out MeshTags whose host arrays are fetched on first use; tagging the same mesh again
+    must not change what an earlier, still unread result shows."""
+    from phifem_amd.mesh_scripts import Quadric
+    m = P.create_box([-1.5] * 2, [1.5] * 2, [24, 24])
+    small, big = Quadric([0.0, 0.0], [1.0, 1.0], -0.25), Quadric([0.0, 0.0], [1.0, 1.0], -1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c_small, f_small = P.compute_tags_measures(m, small, 1, box_mode=True)[:2]      # not read yet
+        c_big, f_big = P.compute_tags_measures(m, big, 1, box_mode=True)[:2]
+        c_ref, f_ref = P.compute_tags_measures(m, small, 1, box_mode=True)[:2]
+    n_in_big = int((c_big.values == 1).sum())
+    assert np.array_equal(c_small.values, c_ref.values) and np.array_equal(c_small.indices, c_ref.indices)
+    assert np.array_equal(f_small.values, f_ref.values) and np.array_equal(f_small.indices, f_ref.indices)
+    assert int((c_small.values == 1).sum()) < n_in_big
+    assert c_small.find(2).size > 0 and c_small.dim == 2 and f_small.dim == 1
