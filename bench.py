@@ -74,7 +74,24 @@ def launch_ranks(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
+    import tempfile
+    mark = os.path.join(tempfile.gettempdir(), f"phifem_watchdog_{os.getpid()}")
+    if os.path.exists(mark):
+        os.remove(mark)
+    env["PHIFEM_WATCHDOG_FILE"] = mark
     proc = subprocess.run(cmd, env=env)
+    if proc.returncode != 0 and os.path.exists(mark) and env.get("PHIFEM_NATIVE_LOOP", "") != "0":
+        # a rank left through the watchdog (phifem_amd.dist_solver.Watchdog: a collective of the native RCCL loop
+        # never completed; it leaves this file behind).  This process has not touched a GPU: start FRESH ranks
+        # once with the Python-driven loop over torch.distributed.
+        print("bench.py: a rank left through the RCCL watchdog; retrying once with PHIFEM_NATIVE_LOOP=0",
+              file=sys.stderr, flush=True)
+        os.remove(mark)
+        env["PHIFEM_NATIVE_LOOP"] = "0"
+        cmd[cmd.index("--master-port") + 1] = str(free_port())
+        proc = subprocess.run(cmd, env=env)
+    if os.path.exists(mark):
+        os.remove(mark)
     return proc.returncode
 
 
@@ -255,14 +272,25 @@ def main(argv=None):
         value = n_active * args.steps / dt
         spmv_s = res["spmv_avg_s"]
         achieved = res["spmv_algorithmic_bytes"] / spmv_s / 1e9 if spmv_s > 0 else 0.0
+        # bytes the FORMAT has to move per launch: the stored matrix stream (columns, values, slice / run records)
+        # + x read once + y written once.  For a structured system most rows are applied from a 4-double stencil,
+        # so this is far below the CSR figure of SURVEY 8(d) and it is the one a bus fraction must be taken of.
+        required = res["spmv_stream_bytes"] + 16.0 * res["spmv_rows"]
+        ach_req = required / spmv_s / 1e9 if spmv_s > 0 else 0.0
         tr, src = pmc_traffic("k_spmv_sell", res["spmv_algorithmic_bytes"])
+        assert ach_req <= HBM_PEAK_GBS, "SpMV: more required bytes per second than the HBM peak -- the timed kernel is not doing the counted work"
         spmv_roof = {
             "bound": "hbm",
             "kernel": "k_spmv_sell (f64 SpMV of the assembled system in one launch: 7-point stencil blocks over the "
                       "translation-invariant interior rows of a structured P1 box system, SELL slices with f64 values / "
-                      "i32 columns for the stored rows; algorithmic bytes = 12 nnz + 20 n of the full CSR)",
+                      "i32 columns for the stored rows)",
+            # `achieved` / `frac`: SURVEY 8(d)'s algorithmic bytes of the CSR product, 12 nnz + 20 n -- a THROUGHPUT
+            # figure (CSR-equivalent GB/s); `achieved_required` / `frac_required`: bytes this format must move
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": tr, "traffic_source": src, "bytes_per_launch": res["spmv_algorithmic_bytes"],
+            "achieved_required": ach_req, "frac_required": ach_req / HBM_PEAK_GBS,
+            "required_bytes_per_launch": required,
+            "traffic": tr, "traffic_source": src, "traffic_over_required": (tr / required) if tr else None,
+            "bytes_per_launch": res["spmv_algorithmic_bytes"],
             "avg_launch_us": 1e6 * spmv_s, "launches_timed": res["spmv_count"],
             "launches_per_iteration": 2,
         }

@@ -43,7 +43,9 @@ enum phx_status {
   PHX_ERR_PARTITION = -4,      /* -> ValueError: facet tag sets overlap (dolfinx MeshTags
                                      rejects duplicated entities, mesh_scripts.py:554-556)    */
   PHX_ERR_CAPACITY = -5,       /* row-slot capacity exceeded during assembly; retry larger   */
-  PHX_ERR_BREAKDOWN = -6       /* Krylov breakdown (rho or omega vanished)                   */
+  PHX_ERR_BREAKDOWN = -6,      /* Krylov breakdown (rho or omega vanished)                   */
+  PHX_ERR_TIMEOUT = -7         /* multi-GPU: a collective did not complete within PHX_DIST_TIMEOUT_S (a rank
+                                  never arrived); the stream is wedged -- the process must exit        */
 };
 
 enum phx_loc { PHX_HOST = 0, PHX_DEVICE = 1 };
@@ -269,11 +271,12 @@ int phx_assemble_elasticity_if(phx_mesh *m, const double *params, const double *
                                const double *f_h, const double *u_D, const int32_t *bc_vertices,
                                int64_t nbc, int loc, phx_system **out);
 int phx_system_destroy(phx_system *s);
-/* info[13] = {n_active, n_active_u, nnz (structural, CSR), n_full (= 2*nv), sell_padded_nnz,
+/* info[14] = {n_active, n_active_u, nnz (structural, CSR), n_full (= 2*nv), sell_padded_nnz,
  *             slot_capacity, sell_nnz (explicit zeros dropped), n_slices, value-indexed slices,
  *             matrix bytes one SpMV of the solve streams (columns + value stream + slice table),
  *             value-indexed slices whose dictionary exceeds 64 entries (LDS look-up),
- *             rows applied from the stencil (structured systems, else 0), stencil runs} */
+ *             rows applied from the stencil (structured systems, else 0), stencil runs,
+ *             1 if the system holds its CSR copy (phx_system_export can return the matrix)} */
 int phx_system_info(const phx_system *s, int64_t *info);
 /* CSR of the active system in ORIGINAL active numbering (sorted columns) + the map active row ->
  * full DoF index; host buffers: rowptr[n_active+1], col[nnz], val[nnz], rhs[n_active],
@@ -336,7 +339,10 @@ int phx_precond_info(phx_system *s, double *out);
 /* phase 0 begin, 1 begin2, 2 v=A phat, 3 s-update, 4 t=A shat, 5 x/r-update, 6 p-update + roll,
  * 7 phat = P p, 8 shat = P s (no-ops without a preconditioner); with the slab-exact preconditioner
  * (phx_precond_setup_global) 7 / 8 run its first half and 9 / 10 the second, the driver all-gathering the
- * carry buffer in between */
+ * carry buffer in between.  Multi-GPU overlap: 20 | 21 (40 | 41) = phase 2 (4) in two launches -- the rows that
+ * read no halo entry, then (after the driver has unpacked the halo) the rows that do; they need the row flags
+ * phx_solve_distributed builds.  True-residual verification: 11 t = A y (after a halo exchange of y), 12 r = b - t and
+ * (r, r) -> scal[8 + 5] (all-reduced by the driver), 13 restart of the recurrences from r. */
 int phx_krylov_phase(phx_system *s, int phase);
 int phx_krylov_finish(phx_system *s, double *x, int loc);
 /* reset != 0: arm the SpMV event profile; else collect {average seconds, launches timed}. */
@@ -347,8 +353,12 @@ int phx_system_get_perm(phx_system *s, int32_t *perm, int32_t *dof_u, int32_t *d
 /* --- native multi-GPU solve: RCCL on the solver's stream (bound with dlopen at run time) -------
  * One communicator per process; the 128-byte id comes from rank 0 (phx_comm_unique_id) and is
  * broadcast by the host (torch.distributed).  phx_solve_distributed runs the same phase sequence
- * as phx_solve with a point-to-point halo of p and s (ncclSend/ncclRecv with <= 2 neighbours) and
- * three all-reduces of 1, 2, 2 doubles per iteration.  Buffers attached with phx_krylov_attach.
+ * as phx_solve with a point-to-point halo of p and s (ncclSend/ncclRecv with <= 2 neighbours, on the communicator's
+ * own stream, overlapped with the rows of the SpMV that read no halo entry; PHX_DIST_OVERLAP=0: in series) and
+ * three all-reduces of 1, 2, 2 doubles per iteration.  Convergence checks are scheduled as in phx_solve; relres /
+ * converged refer to the TRUE residual (one more halo exchange + SpMV + all-reduce, restart when it misses rtol).
+ * Every host wait is bounded by PHX_DIST_TIMEOUT_S (default 300 s) -> PHX_ERR_TIMEOUT.
+ * Buffers attached with phx_krylov_attach.
  *   peers[npeers]; counts[2*npeers] = {n_send, n_recv}; idx[2*npeers] = device int64 arrays
  *   {send positions, recv positions} in solver order. */
 typedef struct phx_comm phx_comm;

@@ -32,8 +32,8 @@ PHI_NODAL_P1, PHI_POINTS, PHI_QUADRIC = 0, 1, 2
 (ARR_COORDS, ARR_CELLS, ARR_C2F, ARR_F2C, ARR_CELL_TAGS, ARR_FACET_TAGS, ARR_BFACETS, ARR_C2E,
  ARR_EDGES) = range(9)
 
-OK, ERR_VALUE, ERR_NOT_IMPLEMENTED, ERR_HIP, ERR_PARTITION, ERR_CAPACITY, ERR_BREAKDOWN = (
-    0, -1, -2, -3, -4, -5, -6)
+OK, ERR_VALUE, ERR_NOT_IMPLEMENTED, ERR_HIP, ERR_PARTITION, ERR_CAPACITY, ERR_BREAKDOWN, ERR_TIMEOUT = (
+    0, -1, -2, -3, -4, -5, -6, -7)
 
 _vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
 _pi, _pi64, _pd = C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_double)
@@ -129,6 +129,8 @@ def check(rc):
         raise MemoryError(msg)
     if rc == ERR_BREAKDOWN:
         raise ArithmeticError(msg)
+    if rc == ERR_TIMEOUT:
+        raise TimeoutError(msg)
     raise RuntimeError(msg)
 
 
@@ -138,10 +140,19 @@ def device_count():
     return n.value
 
 
+def sync_torch_stream(device):
+    """The library's kernels run on the mesh's own NON-BLOCKING stream, which does not wait for torch's streams:
+    whatever torch still has queued for a tensor must have run before its raw pointer crosses the C ABI."""
+    import torch
+    torch.cuda.current_stream(device).synchronize()
+
+
 def ptr(a):
     """void* of a numpy array (host) or a torch tensor (host or device) + its location flag."""
     if a is None:
         return None, HOST
     if hasattr(a, "data_ptr"):  # torch tensor
+        if a.is_cuda:
+            sync_torch_stream(a.device)
         return C.c_void_p(a.data_ptr()), (DEVICE if a.is_cuda else HOST)
     return a.ctypes.data_as(C.c_void_p), HOST

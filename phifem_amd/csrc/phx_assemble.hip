@@ -1124,7 +1124,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
   void *ptrs[] = {s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active, s->rowptr, s->col,
                   s->val, s->rhs, s->diag, s->slice_ptr, s->sell_col, s->sell_val,
                   s->sell_val_raw, s->sell_kind, s->perm, s->iperm, s->work, s->scal, s->row_nz,
-                  s->c0, s->stencil, s->seg, s->slice_seg, s->sell_rows, s->cscale, s->pvec};
+                  s->c0, s->stencil, s->seg, s->slice_seg, s->sell_rows, s->cscale, s->pvec, s->bnd, s->bnd_rec};
   for (void *p : ptrs) (void)phx_free(p);
   phx_box_precond_destroy(s->precond);
   delete s;
@@ -1530,7 +1530,7 @@ extern "C" int phx_system_info(const phx_system *s, int64_t *info) {
   info[0] = s->n; info[1] = s->nu; info[2] = s->nnz; info[3] = s->nfull;
   info[4] = s->sell_nnz; info[5] = s->slot_cap; info[6] = s->sell_true_nnz; info[7] = s->nslices;
   info[8] = s->sell_indexed_slices; info[9] = s->sell_stream_bytes; info[10] = s->sell_indexed_large;
-  info[11] = s->nc0; info[12] = s->nseg;
+  info[11] = s->nc0; info[12] = s->nseg; info[13] = s->rowptr != nullptr;
   return PHX_OK;
 }
 

@@ -198,6 +198,11 @@ struct phx_system {
   int64_t n_sell_rows = 0;
   double *cscale = nullptr;        // [n] x = cscale * y when the iteration ends (1 for unscaled columns, else 1 / diag)
   double *pvec = nullptr;          // [2 n] phat / shat of the library-owned workspace when no box preconditioner holds them
+  // --- multi-GPU overlap (phx_dist.inc.hip): rows that reference halo entries.  The SpMV of an iteration runs in two
+  // launches: every other row while the halo is in flight, these rows (k_spmv_bnd over `bnd_rec`) after the unpack.
+  uint8_t *bnd = nullptr;          // [n] 1: row references an entry some neighbour sends
+  int32_t *bnd_rec = nullptr;      // [nbnd][6] {row, kind (0 stencil / 1 SELL-16 / 2 SELL-64), 4 kind-specific ints}
+  int64_t nbnd = 0;
 };
 
 // helpers implemented in phx_mesh.hip

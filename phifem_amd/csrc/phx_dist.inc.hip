@@ -4,6 +4,7 @@
 // library itself has no link-time dependency on it.  SURVEY 8(e): slabs talk point-to-point to at
 // most two neighbours over dedicated xGMI links; the scalar all-reduces carry 1, 2 and 2 doubles.
 #include <dlfcn.h>
+#include <time.h>
 
 typedef struct { char internal[128]; } phx_nccl_uid;
 typedef void *phx_nccl_comm;
@@ -61,6 +62,9 @@ static int nccl_bind() {
 struct phx_comm {
   phx_nccl_comm comm = nullptr;
   int nranks = 1, rank = 0, device = 0;
+  // halo exchanges run on their own stream so that the rows of the SpMV that read no halo entry overlap with them
+  hipStream_t cs = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_recvd = nullptr;
 };
 
 extern "C" int phx_comm_unique_id(void *out128) {
@@ -84,13 +88,25 @@ extern "C" int phx_comm_create(int nranks, int rank, const void *uid128, int dev
     delete c;
     return PHX_ERR_HIP;
   }
+  if (hipStreamCreateWithFlags(&c->cs, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_recvd, hipEventDisableTiming) != hipSuccess) {
+    phx_set_error("communication stream / events could not be created");
+    g_nccl.CommDestroy(c->comm);
+    delete c;
+    return PHX_ERR_HIP;
+  }
   *out = c;
   return PHX_OK;
 }
 
 extern "C" int phx_comm_destroy(phx_comm *c) {
   if (!c) return PHX_OK;
+  if (c->cs) { (void)hipStreamSynchronize(c->cs); }
   if (c->comm && g_nccl.ok) g_nccl.CommDestroy(c->comm);
+  if (c->ev_packed) (void)hipEventDestroy(c->ev_packed);
+  if (c->ev_recvd) (void)hipEventDestroy(c->ev_recvd);
+  if (c->cs) (void)hipStreamDestroy(c->cs);
   delete c;
   return PHX_OK;
 }
@@ -114,24 +130,43 @@ struct HaloSpec {
   double *sbuf[2], *rbuf[2];
 };
 
-static int halo_exchange(phx_system *s, phx_comm *c, const HaloSpec &H, double *vec) {
+// pack on the solver stream `st`, send / receive on `on` (st itself, or the communicator's stream behind an event)
+static int halo_begin(phx_system *s, phx_comm *c, const HaloSpec &H, const double *vec, bool overlap) {
   hipStream_t st = s->mesh->stream;
   for (int p = 0; p < H.npeers; ++p)
     if (H.nsend[p] > 0)
       k_halo_pack<<<dim3((unsigned)phx_div_up(H.nsend[p], 256)), dim3(256), 0, st>>>(
           H.nsend[p], H.send_idx[p], vec, H.sbuf[p]);
+  PHX_HIP(hipGetLastError());
+  hipStream_t on = st;
+  if (overlap) {
+    PHX_HIP(hipEventRecord(c->ev_packed, st));
+    PHX_HIP(hipStreamWaitEvent(c->cs, c->ev_packed, 0));
+    on = c->cs;
+  }
   PHX_NCCL(g_nccl.GroupStart());
   for (int p = 0; p < H.npeers; ++p) {
-    if (H.nsend[p] > 0) PHX_NCCL(g_nccl.Send(H.sbuf[p], (size_t)H.nsend[p], PHX_NCCL_FLOAT64, H.peer[p], c->comm, st));
-    if (H.nrecv[p] > 0) PHX_NCCL(g_nccl.Recv(H.rbuf[p], (size_t)H.nrecv[p], PHX_NCCL_FLOAT64, H.peer[p], c->comm, st));
+    if (H.nsend[p] > 0) PHX_NCCL(g_nccl.Send(H.sbuf[p], (size_t)H.nsend[p], PHX_NCCL_FLOAT64, H.peer[p], c->comm, on));
+    if (H.nrecv[p] > 0) PHX_NCCL(g_nccl.Recv(H.rbuf[p], (size_t)H.nrecv[p], PHX_NCCL_FLOAT64, H.peer[p], c->comm, on));
   }
   PHX_NCCL(g_nccl.GroupEnd());
+  if (overlap) PHX_HIP(hipEventRecord(c->ev_recvd, c->cs));
+  return PHX_OK;
+}
+// ... and the unpack on the solver stream, once the receives have landed
+static int halo_end(phx_system *s, phx_comm *c, const HaloSpec &H, double *vec, bool overlap) {
+  hipStream_t st = s->mesh->stream;
+  if (overlap) PHX_HIP(hipStreamWaitEvent(st, c->ev_recvd, 0));
   for (int p = 0; p < H.npeers; ++p)
     if (H.nrecv[p] > 0)
       k_halo_unpack<<<dim3((unsigned)phx_div_up(H.nrecv[p], 256)), dim3(256), 0, st>>>(
           H.nrecv[p], H.recv_idx[p], H.rbuf[p], vec);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
+}
+static int halo_exchange(phx_system *s, phx_comm *c, const HaloSpec &H, double *vec) {
+  PHX_CHECK(halo_begin(s, c, H, vec, false));
+  return halo_end(s, c, H, vec, false);
 }
 
 // slab-exact preconditioner: the zero-inflow carries of every rank's tridiagonal z recurrences (2 doubles per
@@ -155,10 +190,41 @@ static int allreduce_R(phx_system *s, phx_comm *c, int lo, int hi) {
   return PHX_OK;
 }
 
+// Watchdog of the host synchronisations inside the distributed loop: a collective whose partner never arrives would
+// otherwise block in hipStreamSynchronize for ever.  PHX_DIST_TIMEOUT_S (default 300; 0 = wait without limit).
+static double dist_timeout_s() {
+  static const double t = getenv("PHX_DIST_TIMEOUT_S") ? atof(getenv("PHX_DIST_TIMEOUT_S")) : 300.0;
+  return t;
+}
+static int stream_sync_watchdog(hipStream_t st, const char *what) {
+  const double limit = dist_timeout_s();
+  if (!(limit > 0.0)) { PHX_HIP(hipStreamSynchronize(st)); return PHX_OK; }
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (long spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess) return PHX_OK;
+    if (e != hipErrorNotReady) { phx_set_error("%s: %s", what, hipGetErrorString(e)); return PHX_ERR_HIP; }
+    if ((spins & 1023) == 1023) {
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      const double dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+      if (dt > limit) {
+        phx_set_error("%s: the stream did not drain within %g s -- a collective is waiting for a rank that never "
+                      "arrived (PHX_DIST_TIMEOUT_S)", what, limit);
+        return PHX_ERR_TIMEOUT;
+      }
+      if (dt > 0.01) { struct timespec nap = {0, 50000}; nanosleep(&nap, nullptr); }
+    }
+  }
+}
+
 // peers[npeers], counts[2*npeers] = {nsend, nrecv} per peer, idx[2*npeers] device pointers
 // {send_idx, recv_idx} (int64 solver positions), work/scal/own as phx_krylov_attach (already
-// attached).  stats[8] as phx_solve (stats[7]: 1 = every rank kept the box preconditioner).  Exchange `check` != 0 first verifies the halo wiring by
-// sending each peer the int64 tags in `tags_send[p]` and comparing with `tags_expect[p]`.
+// attached).  stats[8] as phx_solve: relres / converged refer to the TRUE residual b - A x (verified with one more
+// halo exchange + SpMV + all-reduce when the recurrences announce convergence, restart from it when it misses rtol);
+// stats[7]: 1 = every rank kept the box preconditioner.
+// PHX_DIST_OVERLAP=0: halo exchanges in series on the solver stream (default: overlapped with the rows of the SpMV
+// that read no halo entry, on the communicator's own stream).
 extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, const int *peers,
                                      const int64_t *counts, const int64_t *const *idx, double rtol,
                                      int64_t max_iter, double *x_out, int loc, double *stats) {
@@ -176,53 +242,108 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     PHX_HIP(phx_malloc(&H.sbuf[p], sizeof(double) * (size_t)(H.nsend[p] > 0 ? H.nsend[p] : 1)));
     PHX_HIP(phx_malloc(&H.rbuf[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)));
   }
+  static const bool overlap_env = !(getenv("PHX_DIST_OVERLAP") && atoi(getenv("PHX_DIST_OVERLAP")) == 0);
+  // a local matter: sends and receives pair up whatever stream each side issues them on
+  const bool overlap = overlap_env && c->nranks > 1 && npeers > 0 && c->cs != nullptr;
   double *S = kr_scal(s);
   int rc = PHX_OK;
   auto body = [&]() -> int {
+    if (overlap) {
+      const int64_t *rl[2] = {H.recv_idx[0], H.recv_idx[1]};
+      const int64_t rn[2] = {H.nrecv[0], H.nrecv[1]};
+      PHX_CHECK(phx_spmv_flag_rows(s, npeers, rl, rn));
+    }
     PHX_CHECK(prof_reset(s));
     PHX_CHECK(phx_begin_timing(m));
     PHX_CHECK(phx_krylov_phase(s, 0));
     PHX_CHECK(allreduce_R(s, c, R_RHO, R_RR + 1));  // (b, b) and the preconditioner vetoes
     PHX_CHECK(phx_krylov_phase(s, 1));
     PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
-    PHX_HIP(hipStreamSynchronize(st));
+    PHX_CHECK(stream_sync_watchdog(st, "start of the distributed solve"));
     // the preconditioner is a COLLECTIVE choice: one veto and every rank iterates with Jacobi, so that all
     // ranks exchange the same vectors and test convergence at the same iterations
     const bool pc_all = s->scal_h[R_OFF + R_RR] == 0.0;
     if (!pc_all) PHX_CHECK(phx_krylov_precond_disable(s));
     const KrVecs V = kr_vecs(s);  // after the vote: the preconditioner decides where phat / shat live
-    const int check_every = pc_all ? 2 : 8;
     const bool exact = s->precond_state == 1 && s->precond->dist;   // the same on every rank (set up from all-reduced numbers)
     const double bb = s->scal_h[S_BB];
-    int64_t it = 0;
-    double relres = bb == 0.0 ? 0.0 : 1.0;
-    while (bb != 0.0 && it < max_iter) {
-      PHX_CHECK(phx_krylov_phase(s, 7));
-      if (exact) { PHX_CHECK(allgather_carries(s, c)); PHX_CHECK(phx_krylov_phase(s, 9)); }
-      PHX_CHECK(halo_exchange(s, c, H, V.phat));
-      PHX_CHECK(phx_krylov_phase(s, 2));
-      PHX_CHECK(allreduce_R(s, c, R_RV, R_RV + 1));
-      PHX_CHECK(phx_krylov_phase(s, 3));
-      PHX_CHECK(phx_krylov_phase(s, 8));
-      if (exact) { PHX_CHECK(allgather_carries(s, c)); PHX_CHECK(phx_krylov_phase(s, 10)); }
-      PHX_CHECK(halo_exchange(s, c, H, V.shat));
-      PHX_CHECK(phx_krylov_phase(s, 4));
-      PHX_CHECK(allreduce_R(s, c, R_TS, R_TT + 1));
-      PHX_CHECK(phx_krylov_phase(s, 5));
-      PHX_CHECK(allreduce_R(s, c, R_RHO, R_RR + 1));
-      ++it;
-      if ((it % check_every == 0) || it == max_iter) {
-        PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
-        PHX_HIP(hipStreamSynchronize(st));
-        const double rr = s->scal_h[R_OFF + R_RR];
-        relres = sqrt(rr / bb);
-        if (!(rr == rr) || !(fabs(rr) <= 1.0e300)) {
-          phx_set_error("BiCGStab breakdown at iteration %lld (rr=%g)", (long long)it, rr);
-          return PHX_ERR_BREAKDOWN;
+    // convergence checks as in phx_solve: scheduled from the observed rate (every rank reads the same all-reduced
+    // numbers, so every rank schedules the same checks)
+    int64_t it = 0, spmvs = 0, next_check = pc_all ? 2 : 8, last_check = 0;
+    double relres = bb == 0.0 ? 0.0 : 1.0, last_relres = 1.0;
+    int verifications = 0;
+    for (;;) {
+      while (bb != 0.0 && it < max_iter) {
+        PHX_CHECK(phx_krylov_phase(s, 7));
+        if (exact) { PHX_CHECK(allgather_carries(s, c)); PHX_CHECK(phx_krylov_phase(s, 9)); }
+        if (overlap) {
+          PHX_CHECK(halo_begin(s, c, H, V.phat, true));
+          PHX_CHECK(phx_krylov_phase(s, 20));
+          PHX_CHECK(halo_end(s, c, H, V.phat, true));
+          PHX_CHECK(phx_krylov_phase(s, 21));
+        } else {
+          PHX_CHECK(halo_exchange(s, c, H, V.phat));
+          PHX_CHECK(phx_krylov_phase(s, 2));
         }
-        if (relres <= rtol) break;
+        PHX_CHECK(allreduce_R(s, c, R_RV, R_RV + 1));
+        PHX_CHECK(phx_krylov_phase(s, 3));
+        PHX_CHECK(phx_krylov_phase(s, 8));
+        if (exact) { PHX_CHECK(allgather_carries(s, c)); PHX_CHECK(phx_krylov_phase(s, 10)); }
+        if (overlap) {
+          PHX_CHECK(halo_begin(s, c, H, V.shat, true));
+          PHX_CHECK(phx_krylov_phase(s, 40));
+          PHX_CHECK(halo_end(s, c, H, V.shat, true));
+          PHX_CHECK(phx_krylov_phase(s, 41));
+        } else {
+          PHX_CHECK(halo_exchange(s, c, H, V.shat));
+          PHX_CHECK(phx_krylov_phase(s, 4));
+        }
+        PHX_CHECK(allreduce_R(s, c, R_TS, R_TT + 1));
+        PHX_CHECK(phx_krylov_phase(s, 5));
+        PHX_CHECK(allreduce_R(s, c, R_RHO, R_RR + 1));
+        spmvs += 2;
+        ++it;
+        if (it >= next_check || it == max_iter) {
+          PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+          PHX_CHECK(stream_sync_watchdog(st, "convergence check of the distributed solve"));
+          const double rr = s->scal_h[R_OFF + R_RR];
+          relres = sqrt(rr / bb);
+          if (!(rr == rr) || !(fabs(rr) <= 1.0e300)) {
+            phx_set_error("BiCGStab breakdown at iteration %lld (rr=%g)", (long long)it, rr);
+            return PHX_ERR_BREAKDOWN;
+          }
+          if (relres <= rtol) break;
+          int64_t step = pc_all ? 2 : 8;
+          if (pc_all && relres < last_relres && relres > 0.0) {
+            const double rate = log(last_relres / relres) / (double)(it - last_check);
+            const double remaining = log(relres / rtol) / rate;
+            step = std::max<int64_t>(2, std::min<int64_t>(12, (int64_t)(0.5 * remaining)));
+            step &= ~(int64_t)1;
+          }
+          last_check = it;
+          last_relres = relres;
+          next_check = it + step;
+        }
+        PHX_CHECK(phx_krylov_phase(s, 6));
       }
-      PHX_CHECK(phx_krylov_phase(s, 6));
+      if (bb == 0.0 || !(relres <= rtol)) break;
+      // the recurrences say converged: verify b - A y (one halo exchange, one SpMV, one all-reduce), restart from it
+      // should it miss the tolerance
+      PHX_CHECK(halo_exchange(s, c, H, V.y));
+      PHX_CHECK(phx_krylov_phase(s, 11));
+      PHX_CHECK(phx_krylov_phase(s, 12));
+      PHX_CHECK(allreduce_R(s, c, R_RR, R_RR + 1));
+      PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
+      PHX_CHECK(stream_sync_watchdog(st, "true-residual check of the distributed solve"));
+      spmvs += 1;
+      const double rr_true = s->scal_h[R_OFF + R_RR];
+      if (!(rr_true == rr_true)) { phx_set_error("non-finite true residual"); return PHX_ERR_BREAKDOWN; }
+      relres = sqrt(rr_true / bb);
+      if (relres <= rtol || ++verifications > 8 || it >= max_iter) break;
+      PHX_CHECK(phx_krylov_phase(s, 13));
+      last_relres = relres;
+      last_check = it;
+      next_check = it + 2;
     }
     PHX_CHECK(phx_krylov_finish(s, x_out, loc));
     PHX_CHECK(phx_end_timing(m, 3));
@@ -231,14 +352,17 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     PHX_CHECK(prof_collect(s, &pavg, &pcount));
     if (stats) {
       stats[0] = (double)it; stats[1] = relres; stats[2] = m->timings[3];
-      stats[3] = (double)(2 * it); stats[4] = pavg; stats[5] = (double)pcount;
+      stats[3] = (double)spmvs; stats[4] = pavg; stats[5] = (double)pcount;
       stats[6] = relres <= rtol ? 1.0 : 0.0; stats[7] = pc_all ? 1.0 : 0.0;
     }
     return PHX_OK;
   };
   rc = body();
-  (void)hipStreamSynchronize(st);
-  for (int p = 0; p < npeers; ++p) { (void)phx_free(H.sbuf[p]); (void)phx_free(H.rbuf[p]); }
+  if (rc != PHX_ERR_TIMEOUT) {   // a wedged stream would block here for ever
+    (void)hipStreamSynchronize(st);
+    if (c->cs) (void)hipStreamSynchronize(c->cs);
+    for (int p = 0; p < npeers; ++p) { (void)phx_free(H.sbuf[p]); (void)phx_free(H.rbuf[p]); }
+  }
   return rc;
 }
 

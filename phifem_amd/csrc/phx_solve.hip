@@ -759,7 +759,10 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
             const double *__restrict__ x, double *__restrict__ y,
             const uint8_t *__restrict__ own, const double *__restrict__ d0,
             double *__restrict__ out0, double *__restrict__ out1, int xcd_group,
-            const uint8_t *__restrict__ kind, const int32_t *__restrict__ rows, int64_t nb_sell, StencilArgs sa) {
+            const uint8_t *__restrict__ kind, const int32_t *__restrict__ rows, int64_t nb_sell, StencilArgs sa,
+            const uint8_t *__restrict__ bnd) {
+  // bnd (nullable, multi-GPU): rows flagged here reference halo entries that are still in flight; this launch
+  // leaves them (no store, no dot-product share) to k_spmv_bnd, which runs after the halo has been unpacked
   __shared__ double vi_dict[4][VI_MAX];
   const int lane = threadIdx.x & 63;
   // Optional XCD-aware block -> slice map (PHX_OPT_SPMV_XCD_GROUP): blocks b and b+8 share an XCD and
@@ -821,6 +824,7 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
           }
         }
         if (r >= sa.nu) live[u] = false;
+        if (bnd && live[u] && bnd[r]) live[u] = false;
       }
     }
     double xv[U][7];
@@ -876,7 +880,7 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
       acc += __shfl_xor(acc, 16);
       acc += __shfl_xor(acc, 32);
       const int32_t rr = rows[s * 16 + (lane & 15)];
-      if (lane < 16 && rr >= 0) {
+      if (lane < 16 && rr >= 0 && !(bnd && bnd[rr])) {
         if (own && !own[rr]) acc = 0.0;
         y[rr] = acc;
         PHX_DOT_ACC(acc, rr);
@@ -952,7 +956,7 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
     for (; k < width; ++k) acc = __builtin_fma(NT_LOAD(&v[k * SELL_C]), x[NT_LOAD(&c[k * SELL_C])], acc);
     // structured systems: the slices run over a list of stored rows (-1: padding of the last slice)
     row = s * SELL_C + lane;
-    if (row < n) {
+    if (row < n && !(bnd && bnd[row])) {
       if (own && !own[row]) acc = 0.0;  // ghost rows stay zero; the halo exchange refreshes them
       y[row] = acc;
       PHX_DOT_ACC(acc, row);
@@ -966,6 +970,134 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
     if (DOTS > 1) p1 = wave_sum(p1);
     const int w = threadIdx.x >> 6;
     if (lane == 0) { red[0][w] = p0; red[1][w] = p1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int slot = (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE;
+      unsafeAtomicAdd(out0 + slot, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+      if (DOTS > 1) unsafeAtomicAdd(out1 + slot, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU overlap: rows whose columns include a halo entry (`isg[pos]` = 1: some neighbour sends this
+// position).  k_spmv_flag walks the COLUMN structure of k_spmv_sell (stencil runs, SELL-16 row list, SELL-64
+// slices -- the value streams are not touched) and writes bnd[row]; with `rec` it also appends one record per
+// flagged row (order arbitrary: the dot products are summed through atomics anyway).  k_spmv_bnd applies the
+// recorded rows, one lane per row, after the halo has been unpacked.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_spmv_flag(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr, const int32_t *__restrict__ scol,
+            const uint8_t *__restrict__ isg, const uint8_t *__restrict__ own, const int32_t *__restrict__ rows,
+            int64_t nb_sell, StencilArgs sa, uint8_t *__restrict__ bnd, int32_t *__restrict__ rec,
+            unsigned long long *__restrict__ counter) {
+  const int lane = threadIdx.x & 63;
+  const int64_t s = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (blockIdx.x >= nb_sell) {
+    const int64_t w = (blockIdx.x - nb_sell) * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t r = w * 64 + lane;
+    if (w * 64 >= sa.nu || r >= sa.nu) return;
+    const int32_t *rc = sa.srec + 16 * w;
+    const int cnt = rc[0];
+    const bool inA = cnt >= 1 && r >= rc[2] && r < rc[3];
+    const bool inB = cnt >= 2 && r >= rc[8] && r < rc[9];
+    bool live = inA || inB;
+    int32_t o[4] = {inA ? rc[4] : rc[10], inA ? rc[5] : rc[11], inA ? rc[6] : rc[12], inA ? rc[7] : rc[13]};
+    if (!live && cnt >= 3) {
+      int k = rc[1] + 2;
+      while (k < sa.nseg && sa.seg[6 * (int64_t)k + 1] <= r) ++k;
+      if (k < sa.nseg && r >= sa.seg[6 * (int64_t)k]) {
+        const int32_t *sg = sa.seg + 6 * (int64_t)k;
+        live = true;
+        o[0] = sg[2]; o[1] = sg[3]; o[2] = sg[4]; o[3] = sg[5];
+      }
+    }
+    if (!live || (own && !own[r])) return;
+    int g = isg[r - 1] | isg[r + 1] | isg[r + o[0]] | isg[r + o[1]];
+    if (o[2] != 0) g |= isg[r + o[2]] | isg[r + o[3]];
+    if (!g) return;
+    bnd[r] = 1;
+    const unsigned long long at = atomicAdd(counter, 1ull);
+    if (rec) { int32_t *q = rec + 6 * at; q[0] = (int32_t)r; q[1] = 0; q[2] = o[0]; q[3] = o[1]; q[4] = o[2]; q[5] = o[3]; }
+  } else if (rows) {
+    if (s >= nslices) return;
+    const int64_t base = slice_ptr[s];
+    const int trips = (int)((slice_ptr[s + 1] - base) >> 6);
+    const int32_t *c = scol + base + lane;
+    int g = 0;
+    for (int j = 0; j < trips; ++j) g |= isg[c[j * 64]];
+    g |= __shfl_xor(g, 16);
+    g |= __shfl_xor(g, 32);
+    const int32_t rr = rows[s * 16 + (lane & 15)];
+    if (lane < 16 && rr >= 0 && g && !(own && !own[rr])) {
+      bnd[rr] = 1;
+      const unsigned long long at = atomicAdd(counter, 1ull);
+      if (rec) { int32_t *q = rec + 6 * at; q[0] = rr; q[1] = 1; q[2] = (int32_t)s; q[3] = lane; q[4] = 0; q[5] = 0; }
+    }
+  } else if (s < nslices) {
+    const int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const int32_t *c = scol + base + lane;
+    int g = 0;
+    for (int k = 0; k < width; ++k) g |= isg[c[k * SELL_C]];
+    const int64_t row = s * SELL_C + lane;
+    if (row < n && g && !(own && !own[row])) {
+      bnd[row] = 1;
+      const unsigned long long at = atomicAdd(counter, 1ull);
+      if (rec) { int32_t *q = rec + 6 * at; q[0] = (int32_t)row; q[1] = 2; q[2] = (int32_t)s; q[3] = lane; q[4] = 0; q[5] = 0; }
+    }
+  }
+}
+
+template <int DOTS>
+__global__ void __launch_bounds__(256)
+k_spmv_bnd(int64_t nrec, const int32_t *__restrict__ rec, const int64_t *__restrict__ slice_ptr,
+           const int32_t *__restrict__ scol, const double *__restrict__ sval, const uint8_t *__restrict__ kind,
+           const double *__restrict__ st, const double *__restrict__ x, double *__restrict__ y,
+           const double *__restrict__ d0, double *__restrict__ out0, double *__restrict__ out1) {
+  double p0 = 0.0, p1 = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nrec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t *q = rec + 6 * i;
+    const int64_t r = q[0];
+    double acc = 0.0;
+    if (q[1] == 0) {
+      acc = __builtin_fma(st[1], x[r - 1] + x[r + 1], st[0] * x[r]);
+      acc = __builtin_fma(st[2], x[r + q[2]] + x[r + q[3]], acc);
+      if (q[4] != 0) acc = __builtin_fma(st[3], x[r + q[4]] + x[r + q[5]], acc);
+    } else if (q[1] == 1) {
+      const int64_t base = slice_ptr[q[2]];
+      const int width = (int)((slice_ptr[q[2] + 1] - base) >> 4);
+      // the four lanes of a row hold entries k = 4 j + (lane >> 4) at base + 64 j + lane: entry k at base + 16 k + (lane & 15)
+      const int64_t b0 = base + (q[3] & 15);
+      for (int k = 0; k < width; ++k) acc = __builtin_fma(sval[b0 + 16 * (int64_t)k], x[scol[b0 + 16 * (int64_t)k]], acc);
+    } else {
+      const int64_t base = slice_ptr[q[2]];
+      const int width = (int)((slice_ptr[q[2] + 1] - base) >> 6);
+      const int lane = q[3];
+      const int nd = kind[q[2]];
+      const int32_t *c = scol + base + lane;
+      if (nd) {
+        const int chunks = (nd + SELL_C - 1) >> 6;
+        const uint32_t *cw = reinterpret_cast<const uint32_t *>(sval + base + chunks * SELL_C) + lane;
+        for (int k = 0; k < width; ++k) {
+          const uint32_t code = (cw[(k >> 2) * SELL_C] >> (8 * (k & 3))) & 255u;
+          acc = __builtin_fma(sval[base + code], x[c[k * SELL_C]], acc);
+        }
+      } else {
+        const double *v = sval + base + lane;
+        for (int k = 0; k < width; ++k) acc = __builtin_fma(v[k * SELL_C], x[c[k * SELL_C]], acc);
+      }
+    }
+    y[r] = acc;
+    if (DOTS > 0) { p0 = __builtin_fma(acc, d0[r], p0); if (DOTS > 1) p1 = __builtin_fma(acc, acc, p1); }
+  }
+  if (DOTS > 0) {
+    __shared__ double red[2][4];
+    p0 = wave_sum(p0);
+    if (DOTS > 1) p1 = wave_sum(p1);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = p0; red[1][w] = p1; }
     __syncthreads();
     if (threadIdx.x == 0) {
       const int slot = (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE;
@@ -1183,8 +1315,10 @@ __global__ void k_scatter_solution(int64_t n, const int32_t *__restrict__ perm,
 
 static inline dim3 vec_grid(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(phx_div_up(n, 256), 2048))); }
 
+// part 0: every row.  Multi-GPU overlap (s->bnd set by phx_spmv_flag_rows): part 1 = every row that references no halo
+// entry (runs while the halo is in flight), part 2 = the flagged rows (after the unpack); both add into the same slots.
 static int launch_spmv(phx_system *s, const double *vals, const double *x, double *y, int dots,
-                       const double *d0, double *o0, double *o1) {
+                       const double *d0, double *o0, double *o1, int part_of = 0) {
   hipStream_t st = s->mesh->stream;
   if (s->n == 0) return PHX_OK;  // empty system (a slab outside the domain): the dot-product slots stay zero
   const dim3 block(256);
@@ -1192,6 +1326,16 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   const int xg = s->mesh->spmv_xcd_group;
   const uint8_t *kinds = vals == s->sell_val ? s->sell_kind : s->sell_kind_raw;
   const int32_t *rows = s->structured ? s->sell_rows : nullptr;
+  if (part_of == 2) {
+    if (s->nbnd == 0) return PHX_OK;
+    const dim3 gb((unsigned)std::min<int64_t>(phx_div_up(s->nbnd, 256), 2048));
+    if (dots == 0) k_spmv_bnd<0><<<gb, block, 0, st>>>(s->nbnd, s->bnd_rec, s->slice_ptr, s->sell_col, vals, kinds, s->stencil, x, y, d0, o0, o1);
+    else if (dots == 1) k_spmv_bnd<1><<<gb, block, 0, st>>>(s->nbnd, s->bnd_rec, s->slice_ptr, s->sell_col, vals, kinds, s->stencil, x, y, d0, o0, o1);
+    else k_spmv_bnd<2><<<gb, block, 0, st>>>(s->nbnd, s->bnd_rec, s->slice_ptr, s->sell_col, vals, kinds, s->stencil, x, y, d0, o0, o1);
+    PHX_HIP(hipGetLastError());
+    return PHX_OK;
+  }
+  const uint8_t *bnd = part_of == 1 ? s->bnd : nullptr;
   // structured systems: the stencil blocks (rows of C0; u columns are unscaled in both value streams) ride behind
   // the SELL blocks of the same launch
   StencilArgs sa{0, nullptr, 0, nullptr, nullptr, 0};
@@ -1211,12 +1355,59 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   if (nb == 0) return PHX_OK;
   const dim3 g2((unsigned)nb);
   if (dots == 0)
-    k_spmv_sell<0><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa);
+    k_spmv_sell<0><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd);
   else if (dots == 1)
-    k_spmv_sell<1><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa);
+    k_spmv_sell<1><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd);
   else
-    k_spmv_sell<2><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa);
+    k_spmv_sell<2><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd);
   PHX_HIP(hipGetLastError());
+  return PHX_OK;
+}
+
+// Flags the rows that read one of the `nidx` solver positions in idx[] (the entries the neighbours send) and lists
+// them for k_spmv_bnd.  Two passes: count, then fill.
+__global__ void k_mark_positions(int64_t n, const int64_t *__restrict__ idx, uint8_t *__restrict__ isg) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) isg[idx[i]] = 1;
+}
+static int phx_spmv_flag_rows(phx_system *s, int nlists, const int64_t *const *idx, const int64_t *counts) {
+  hipStream_t st = s->mesh->stream;
+  PHX_HIP(phx_free(s->bnd)); PHX_HIP(phx_free(s->bnd_rec));
+  s->bnd = nullptr; s->bnd_rec = nullptr; s->nbnd = 0;
+  if (s->n == 0) return PHX_OK;
+  uint8_t *isg = nullptr;
+  unsigned long long *cnt = nullptr, hcnt = 0;
+  PHX_HIP(phx_malloc(&isg, (size_t)s->n));
+  PHX_HIP(phx_malloc(&s->bnd, (size_t)s->n));
+  PHX_HIP(phx_malloc(&cnt, sizeof(unsigned long long)));
+  PHX_HIP(hipMemsetAsync(isg, 0, (size_t)s->n, st));
+  for (int l = 0; l < nlists; ++l)
+    if (counts[l] > 0)
+      k_mark_positions<<<dim3((unsigned)phx_div_up(counts[l], 256)), dim3(256), 0, st>>>(counts[l], idx[l], isg);
+  const int32_t *rows = s->structured ? s->sell_rows : nullptr;
+  StencilArgs sa{0, nullptr, 0, nullptr, nullptr, 0};
+  const int64_t nb_sell = phx_div_up(s->nslices, 4);
+  int64_t nb = nb_sell;
+  if (s->structured && s->nseg > 0) {
+    sa = StencilArgs{s->nstencil_pos, s->seg, s->nseg, s->slice_seg, s->stencil, 0};
+    nb = nb_sell + phx_div_up(phx_div_up(s->nstencil_pos, 64), 4);
+  }
+  for (int pass = 0; pass < 2 && nb > 0; ++pass) {
+    PHX_HIP(hipMemsetAsync(s->bnd, 0, (size_t)s->n, st));
+    PHX_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st));
+    k_spmv_flag<<<dim3((unsigned)nb), dim3(256), 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, isg, s->own, rows,
+                                                          nb_sell, sa, s->bnd, pass ? s->bnd_rec : nullptr, cnt);
+    PHX_HIP(hipGetLastError());
+    if (pass == 0) {
+      PHX_HIP(hipMemcpyAsync(&hcnt, cnt, sizeof(hcnt), hipMemcpyDeviceToHost, st));
+      PHX_HIP(hipStreamSynchronize(st));
+      s->nbnd = (int64_t)hcnt;
+      if (s->nbnd == 0) break;
+      PHX_HIP(phx_malloc(&s->bnd_rec, sizeof(int32_t) * 6 * (size_t)s->nbnd));
+    }
+  }
+  PHX_HIP(hipStreamSynchronize(st));
+  PHX_HIP(phx_free(isg)); PHX_HIP(phx_free(cnt));
   return PHX_OK;
 }
 
@@ -1405,6 +1596,37 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
     case 8:  // shat = P s   (before the halo exchange of shat and phase 4)
       if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.sv, V.shat, s->precond->dist ? 1 : 0));
       else if (s->u_unscaled && n > 0) k_jacobi_u<<<vec_grid(n), block, 0, st>>>(n, s->nu, s->perm, s->diag, V.sv, V.shat);
+      break;
+    // --- multi-GPU overlap: phases 2 / 4 in two launches (rows that read no halo entry | the rows that do)
+    case 20:
+      PHX_CHECK(prof_begin(s));
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.phat, V.v, 1, V.rhat, slot_base(S, par, R_RV), nullptr, 1));
+      PHX_CHECK(prof_end(s));
+      break;
+    case 21:
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.phat, V.v, 1, V.rhat, slot_base(S, par, R_RV), nullptr, 2));
+      if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_RV, 1, 1);
+      break;
+    case 40:
+      PHX_CHECK(prof_begin(s));
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.shat, V.t, 2, V.sv, slot_base(S, par, R_TS), slot_base(S, par, R_TT), 1));
+      PHX_CHECK(prof_end(s));
+      break;
+    case 41:
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.shat, V.t, 2, V.sv, slot_base(S, par, R_TS), slot_base(S, par, R_TT), 2));
+      if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_TS, 2, 1);
+      break;
+    // --- verification of the TRUE residual (as phx_solve): 11: t = A y (the driver has exchanged the halo of y),
+    // 12: r = own ? b - t : 0 and (r, r) -> R[R_RR] (all-reduced by the driver), 13: restart of the recurrences from r
+    case 11:
+      PHX_CHECK(launch_spmv(s, s->sell_val, V.y, V.t, 0, nullptr, nullptr, nullptr));
+      break;
+    case 12:
+      if (n > 0) k_true_residual<<<vec_grid(n), block, 0, st>>>(n, s->own, V.b, V.t, V.r, S);
+      k_reduce_slots<<<1, 64, 0, st>>>(S, 0, R_RR, 1, 1);
+      break;
+    case 13:
+      k_restart_from_r<<<vec_grid(n), block, 0, st>>>(n, V.r, V.rhat, V.p, S, rop);
       break;
     case 9:   // slab-exact preconditioner: second half of phase 7, after the all-gather of the carries
       if (s->precond_state == 1 && s->precond->dist) PHX_CHECK(box_precond_apply(s, V.p, V.phat, 2));

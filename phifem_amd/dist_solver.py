@@ -273,36 +273,64 @@ class DistributedSolver:
         hat = pc or getattr(b, "precond_active", lambda: False)()
         exact = bool(pc and getattr(b, "exact", False))
         vp, vs = (self.phat, self.shat) if hat else (self.p, self.s)
-        check_every = 2 if pc else self.check_every
-        while bb != 0.0 and it < self.max_iter:
-            if hat:
-                b.phase(7)
-                if exact:
-                    self._allgather_carries()
-                    b.phase(9)
-            self.halo_exchange(vp)
-            b.phase(2)
-            self._allreduce(R_RV, R_RV + 1)
-            b.phase(3)
-            if hat:
-                b.phase(8)
-                if exact:
-                    self._allgather_carries()
-                    b.phase(10)
-            self.halo_exchange(vs)
-            b.phase(4)
-            self._allreduce(R_TS, R_TT + 1)
-            b.phase(5)
-            self._allreduce(R_RHO, R_RR + 1)
-            it += 1
-            if it % check_every == 0 or it == self.max_iter:
-                rr = float(self.scal[R_OFF + R_RR].item())
-                relres = (rr / bb) ** 0.5
-                if not np.isfinite(rr):
-                    raise ArithmeticError(f"BiCGStab breakdown at iteration {it}")
-                if relres <= self.rtol:
-                    break
-            b.phase(6)
+        # convergence checks as in phx_solve / phx_solve_distributed: with the box preconditioner the next check is
+        # scheduled from the observed rate; every rank reads the same all-reduced numbers and schedules the same checks
+        import math
+        base_step = 2 if pc else self.check_every
+        next_check, last_check, last_relres, verifications = base_step, 0, 1.0, 0
+        vy = self.work[6 * self.b.n:7 * self.b.n]
+        while True:
+            while bb != 0.0 and it < self.max_iter:
+                if hat:
+                    b.phase(7)
+                    if exact:
+                        self._allgather_carries()
+                        b.phase(9)
+                self.halo_exchange(vp)
+                b.phase(2)
+                self._allreduce(R_RV, R_RV + 1)
+                b.phase(3)
+                if hat:
+                    b.phase(8)
+                    if exact:
+                        self._allgather_carries()
+                        b.phase(10)
+                self.halo_exchange(vs)
+                b.phase(4)
+                self._allreduce(R_TS, R_TT + 1)
+                b.phase(5)
+                self._allreduce(R_RHO, R_RR + 1)
+                it += 1
+                if it >= next_check or it == self.max_iter:
+                    rr = float(self.scal[R_OFF + R_RR].item())
+                    if not np.isfinite(rr):
+                        raise ArithmeticError(f"BiCGStab breakdown at iteration {it}")
+                    relres = (rr / bb) ** 0.5
+                    if relres <= self.rtol:
+                        break
+                    step = base_step
+                    if pc and 0.0 < relres < last_relres:
+                        rate = math.log(last_relres / relres) / (it - last_check)
+                        remaining = math.log(relres / self.rtol) / rate
+                        step = max(2, min(12, int(0.5 * remaining))) & ~1
+                    last_check, last_relres, next_check = it, relres, it + step
+                b.phase(6)
+            if bb == 0.0 or not relres <= self.rtol:
+                break
+            # the recurrences say converged: verify the TRUE residual b - A y, restart from it should it miss rtol
+            self.halo_exchange(vy)
+            b.phase(11)
+            b.phase(12)
+            self._allreduce(R_RR, R_RR + 1)
+            rr = float(self.scal[R_OFF + R_RR].item())
+            if not np.isfinite(rr):
+                raise ArithmeticError("non-finite true residual")
+            relres = (rr / bb) ** 0.5
+            verifications += 1
+            if relres <= self.rtol or verifications > 8 or it >= self.max_iter:
+                break
+            b.phase(13)
+            last_check, last_relres, next_check = it, relres, it + 2
         b.finish(out)
         b.synchronize()
         dt = time.perf_counter() - t0
@@ -313,6 +341,59 @@ class DistributedSolver:
             if prof:
                 st["spmv_avg_s"], st["spmv_timed"] = prof
         return st
+
+
+WATCHDOG_EXIT_CODE = 87
+
+
+class Watchdog:
+    """Bounds a call into RCCL (communicator set-up, halo self-test, the native loop).  A collective whose partner
+    never arrives blocks inside the library where no exception can reach it; after `PHIFEM_DIST_TIMEOUT_S`
+    (default 600 s, 0 = off) the rank says so and EXITS with code 87.  Nothing is re-exec'd: this process has
+    initialised the GPU and its stream is wedged.  A launcher that has not touched the GPU (`bench.py --gpus N`
+    started without one) may start fresh ranks with PHIFEM_NATIVE_LOOP=0; under an external launcher the non-zero
+    exit ends the job instead of hanging it."""
+
+    def __init__(self, what, rank):
+        import os
+        import threading
+        self.what, self.rank = what, rank
+        self.limit = float(os.environ.get("PHIFEM_DIST_TIMEOUT_S", "600"))
+        self._done = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.limit > 0 else None
+
+    @staticmethod
+    def _leave():
+        import os
+        mark = os.environ.get("PHIFEM_WATCHDOG_FILE")
+        if mark:
+            try:
+                open(mark, "w").close()
+            except OSError:
+                pass
+        os._exit(WATCHDOG_EXIT_CODE)
+
+    def _run(self):
+        import sys
+        if not self._done.wait(self.limit):
+            print(f"phifem_amd: rank {self.rank}: {self.what} did not return within {self.limit:g} s "
+                  f"(PHIFEM_DIST_TIMEOUT_S) -- exiting with code {WATCHDOG_EXIT_CODE}", file=sys.stderr, flush=True)
+            self._leave()
+
+    def __enter__(self):
+        if self._thread:
+            self._thread.start()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        self._done.set()
+        if et is not None and issubclass(et, TimeoutError):
+            # PHX_ERR_TIMEOUT: the library's own bound on a host wait fired first -- same situation, same way out
+            import sys
+            print(f"phifem_amd: rank {self.rank}: {self.what}: {ev} -- exiting with code {WATCHDOG_EXIT_CODE}",
+                  file=sys.stderr, flush=True)
+            self._leave()
+        return False
 
 
 class DistributedKrylov:
@@ -438,9 +519,10 @@ class DistributedKrylov:
             zb = [r * n_per for r in range(prob.world)] + [lay["nz"] + 1]
             backend.setup_exact_precond(self.dist, prob.rank, prob.world, zb, stage_cpu=ds.stage_cpu)
         if self.native is None:
-            self._init_native()
-            if self.native:
-                self.native = self._all_ok(self._selftest(backend, ds, self._halo_arrays(ds)))
+            with Watchdog("RCCL communicator set-up + halo self-test", prob.rank):
+                self._init_native()
+                if self.native:
+                    self.native = self._all_ok(self._selftest(backend, ds, self._halo_arrays(ds)))
         if not self.native:
             self.path = "python"
             return ds.solve(out, profile_spmv=profile_spmv)
@@ -449,10 +531,11 @@ class DistributedKrylov:
         st = (C.c_double * 8)()
         self.torch.cuda.synchronize(self.dev)
         t0 = time.perf_counter()
-        L.check(L.lib.phx_solve_distributed(backend.sys, self.comm, np_, peers, counts, idx,
-                                            float(prob.rtol), int(prob.max_iter),
-                                            C.c_void_p(out.data_ptr()), L.DEVICE, st))
-        self.torch.cuda.synchronize(self.dev)
+        with Watchdog("phx_solve_distributed", prob.rank):
+            L.check(L.lib.phx_solve_distributed(backend.sys, self.comm, np_, peers, counts, idx,
+                                                float(prob.rtol), int(prob.max_iter),
+                                                C.c_void_p(out.data_ptr()), L.DEVICE, st))
+            self.torch.cuda.synchronize(self.dev)
         return {"iterations": int(st[0]), "relres": st[1], "seconds": time.perf_counter() - t0,
                 "n_owned": ds.n_owned, "spmv_avg_s": st[4], "spmv_timed": int(st[5]),
                 "converged": bool(st[6]), "precond_all": bool(st[7]),

@@ -114,7 +114,7 @@ class SlabProblem:
                         "solve": st["seconds"]},
             "spmv_avg_s": st.get("spmv_avg_s", 0.0), "spmv_count": st.get("spmv_timed", 0),
             "spmv_algorithmic_bytes": 12.0 * info["sell_nnz"] + 20.0 * info["n_active"],
-            "spmv_stream_bytes": info["spmv_matrix_bytes"],
+            "spmv_stream_bytes": info["spmv_matrix_bytes"], "spmv_rows": info["n_active"],
             # sine-transform y pass of the preconditioner: reads and writes every lattice point once
             "precond": pc["precond"], "precond_L": pc["precond_L"],
             "dst_avg_s": pc["dst_avg_s"], "dst_count": pc["dst_timed"],

@@ -62,6 +62,7 @@ class Mesh:
         self._h = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
         self.parent = parent
         self._lazy_tags = weakref.WeakSet()
+        self._tag_generation = 0        # bumped by every Python entry that changes the tags of this mesh
         self.device = int(device) if device is not None else (parent.device if parent is not None else 0)
         cnt = (C.c_int64 * 6)()
         L.check(L.lib.phx_mesh_counts(self._h, cnt))
@@ -98,7 +99,10 @@ class Mesh:
 
     # --- accessors ----------------------------------------------------------------------
     def _flush_lazy_tags(self):
-        """Materialise the MeshTags handed out so far (called before the tags of this mesh change)."""
+        """Materialise the MeshTags handed out so far.  Called by every Python entry that is about to change the
+        tags of this mesh (`_tag_cells`, `_tag_facets`, the overwrite path), so a MeshTags object always shows
+        the state it was created in; callers that change tags through the raw C ABI call it themselves."""
+        self._tag_generation += 1
         for t in list(self._lazy_tags):
             t._load()
 

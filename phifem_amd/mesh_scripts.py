@@ -147,14 +147,18 @@ def _device_points(mesh, degree, nodal=None, expr=None):
         if n != want:
             raise ValueError(what)
         p, loc = L.ptr(v)
+        L.sync_torch_stream(dev)        # `out` was allocated (and possibly recycled) on torch's stream
         L.check(L.lib.phx_levelset_eval_points(mesh._h, degree, p, loc, C.c_void_p(out.data_ptr())))
         return L.PHI_POINTS, C.c_void_p(out.data_ptr()), L.DEVICE, (out, v)
     xq = torch.empty((cnt.value, mesh.gdim), dtype=torch.float64, device=dev)
+    L.sync_torch_stream(dev)
     L.check(L.lib.phx_detection_points_physical(mesh._h, degree, C.c_void_p(xq.data_ptr())))
+    mesh.synchronize()                  # ... and torch's stream does not wait for the mesh stream either
     vals = expr(xq.t())
     if not hasattr(vals, "data_ptr") or not vals.is_cuda or vals.numel() != cnt.value:
         raise ValueError("a DeviceExpression must return one value per point as a tensor on the mesh's GPU")
     out.copy_(vals.reshape(-1).to(torch.float64))
+    L.sync_torch_stream(dev)            # `f` and the copy ran on torch's stream, the tagging kernels will not
     return L.PHI_POINTS, C.c_void_p(out.data_ptr()), L.DEVICE, out
 
 
@@ -309,6 +313,7 @@ def _reshape_map(offsets, array):
 
 def _tag_cells(mesh, levelset, detection_degree, single_layer_cut=False):
     """mesh_scripts.py:284-390."""
+    mesh._flush_lazy_tags()     # MeshTags of an earlier call keep the state they were created in
     kind, p, loc, keep = _levelset_args(mesh, levelset, detection_degree)
     warn = C.c_int(0)
     L.check(L.lib.phx_tag_cells(mesh._h, kind, p, loc, detection_degree,
@@ -320,6 +325,7 @@ def _tag_cells(mesh, levelset, detection_degree, single_layer_cut=False):
 
 def _tag_facets(mesh, staged, detection_degree):
     """mesh_scripts.py:393-558."""
+    mesh._flush_lazy_tags()
     kind, p, loc, keep = staged
     L.check(L.lib.phx_tag_facets(mesh._h, kind, p, loc, detection_degree))
     if mesh.nbf < mesh.nc:
@@ -349,7 +355,6 @@ def compute_tags_measures(mesh, discrete_levelset, detection_degree, box_mode=Fa
 
     Returns (cells_tags, facets_tags, submesh|None, boundaries_measure, submesh_maps|None).
     """
-    mesh._flush_lazy_tags()     # MeshTags of an earlier call keep the state they were created in
     staged = _tag_cells(mesh, discrete_levelset, detection_degree, single_layer_cut)
     if debug_mode:
         cv = mesh.cell_tag_values()
@@ -372,6 +377,7 @@ def compute_tags_measures(mesh, discrete_levelset, detection_degree, box_mode=Fa
             ow = overwrite_tags[key]
             idx = np.ascontiguousarray(ow.indices, dtype=np.int32)
             val = np.ascontiguousarray(ow.values, dtype=np.int32)
+            mesh._flush_lazy_tags()
             L.check(L.lib.phx_overwrite_tags(mesh._h, is_facet, idx.size,
                                              idx.ctypes.data_as(C.c_void_p),
                                              val.ctypes.data_as(C.c_void_p)))

@@ -90,6 +90,7 @@ class PhiFEMSolver:
         if len(locs) != 1:
             raise ValueError("phi_h, f_h and u_D must all live on the host or all on the device")
         self._keep = (phi_h, f_h, u_D)   # inputs stay alive as long as the system they were read for
+        self._tag_generation = self.mesh._tag_generation
         self._sys = self._assemble_raw()
         return self.info()
 
@@ -113,11 +114,11 @@ class PhiFEMSolver:
         return self.mesh.nv if self.degree == 1 else self.mesh.nv + self.mesh.ne
 
     def info(self):
-        i = (C.c_int64 * 13)()
+        i = (C.c_int64 * 14)()
         L.check(L.lib.phx_system_info(self._sys, i))
         keys = ("n_active", "n_active_u", "nnz", "n_full", "sell_padded_nnz", "slot_capacity",
                 "sell_nnz", "n_slices", "indexed_slices", "spmv_matrix_bytes", "indexed_slices_lds",
-                "stencil_rows", "stencil_runs")
+                "stencil_rows", "stencil_runs", "has_csr")
         return dict(zip(keys, (int(v) for v in i)))
 
     def export_csr(self):
@@ -134,8 +135,13 @@ class PhiFEMSolver:
         rhs = np.empty(n, dtype=np.float64)
         dof = np.empty(n, dtype=np.int64)
         args = [a.ctypes.data_as(C.c_void_p) for a in (rowptr, col, val, rhs, dof)]
-        rc = L.lib.phx_system_export(self._sys, *args)
-        if rc == L.ERR_VALUE and hasattr(self, "_assemble_raw") and getattr(self, "_keep", None) is not None:
+        if i["has_csr"]:
+            L.check(L.lib.phx_system_export(self._sys, *args))
+        elif getattr(self, "_keep", None) is not None and getattr(self, "_tag_generation", None) is not None:
+            if self._tag_generation != self.mesh._tag_generation:
+                warnings.warn("the mesh was tagged again after assemble(): the exported CSR is rebuilt from the CURRENT "
+                              "tags and equals the solved system only if they are unchanged (set PHX_OPT_EXPORT_CSR "
+                              "before assembling to keep the solved system's own copy)", RuntimeWarning, stacklevel=2)
             L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_EXPORT_CSR, 1))
             try:
                 h = self._assemble_raw()
@@ -146,7 +152,7 @@ class PhiFEMSolver:
             finally:
                 L.lib.phx_system_destroy(h)
         else:
-            L.check(rc)
+            L.check(L.lib.phx_system_export(self._sys, *args))   # reports "assembled without its CSR copy"
         return rowptr, col, val, rhs, dof
 
     def export_rhs_dof(self):

@@ -111,6 +111,16 @@ class CpuBackend:
                 self.p[:] = np.where(own, self.r + beta * (self.p - S[S_OMEGA] * self.v), 0.0)
                 S[S_RHO] = S[R_OFF + R_RHO]
             S[S_RR] = S[R_OFF + R_RR]
+        elif k == 11:   # true-residual verification: t = A y
+            self.t[:] = np.where(own, self.As @ self.y, 0.0)
+        elif k == 12:   # r = b - t, (r, r)
+            self.r[:] = np.where(own, self.bv - self.t, 0.0)
+            S[R_OFF + R_RR] = self.r @ self.r
+        elif k == 13:   # restart from r (k_restart_from_r)
+            self.p[:] = self.r
+            self.rhat[:] = self.r
+            S[S_RHO] = S[S_RR] = S[R_OFF + R_RR]
+            S[S_ALPHA] = S[S_OMEGA] = 1.0
 
     def finish(self, out):
         o = out.numpy()

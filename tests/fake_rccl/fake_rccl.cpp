@@ -3,18 +3,28 @@
 // A host-staged stand-in for the ten RCCL entry points phifem_amd/csrc/phx_dist.inc.hip binds with dlopen.
 // RCCL refuses two ranks on one device, and the test box has exactly one GPU, so the library's NATIVE
 // multi-GPU loop (phx_solve_distributed: pack kernel -> ncclSend/ncclRecv group -> unpack kernel,
-// ncclAllReduce of the batched dot products) could otherwise only ever run with a one-rank communicator.
-// With this library every rank is a process sharing the one GPU; "communication" goes through a POSIX
-// shared-memory segment: send = stream sync + D2H copy into a mailbox, recv = wait + H2D copy, all-reduce =
-// every rank deposits its values, all ranks add them in rank order (so every rank obtains the same bits).
-// Stream semantics: each call completes on the host before it returns, which is stronger than RCCL's
-// enqueue-on-stream contract, so everything the loop enqueues afterwards sees the data.
+// ncclAllReduce of the batched dot products, ncclAllGather of the preconditioner carries) could otherwise only
+// ever run with a one-rank communicator.  With this library every rank is a process sharing the one GPU;
+// "communication" goes through a POSIX shared-memory segment.
+//
+// Stream semantics (round 3): like RCCL, every call only ENQUEUES work on the caller's stream and returns.
+//   send       = async D2H copy into pinned staging -> host function (hipLaunchHostFunc) that moves the staging
+//                into the mailbox of the ordered pair
+//   recv       = host function that waits for the mailbox and moves it into pinned staging -> async H2D copy
+//   all-reduce = async D2H -> host function (deposit, barrier, sum in rank order, barrier) -> async H2D
+//   all-gather = async D2H -> host function (deposit, barrier, collect, barrier) -> async H2D
+// Nothing is complete when the call returns, so a consumer that forgets a stream dependency (a buffer reused
+// before the enqueued send has run, a kernel on another stream without an event, a host read without a
+// synchronisation) reads stale data here exactly as it would with RCCL.  PHX_FAKE_RCCL_SYNC=1 restores the
+// round-2 behaviour (every call complete on return), for bisecting.
+// Every wait inside a host function is bounded (120 s) and aborts the process with a message.
 //
 // build: hipcc -O2 -fPIC -shared -o libfake_rccl.so fake_rccl.cpp -lrt   (tests/fake_rccl/Makefile)
 #include <hip/hip_runtime.h>
 #include <fcntl.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -22,6 +32,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 typedef struct { char internal[128]; } fake_uid;
@@ -29,12 +40,13 @@ typedef struct { char internal[128]; } fake_uid;
 #define MAXR 8
 #define MBOX_BYTES (8u << 20)   // per ordered pair; pages are only committed when touched
 #define RED_MAX 64
+#define WAIT_LIMIT_S 120.0
 
 struct Shared {
   std::atomic<int> attached;
   std::atomic<int> bar_count;
   std::atomic<int> bar_sense;
-  std::atomic<unsigned> full[MAXR][MAXR];      // mailbox src -> dst holds `full` bytes (0: free)
+  std::atomic<unsigned> full[MAXR][MAXR];      // mailbox src -> dst holds `full - 1` bytes (0: free)
   double red[MAXR][RED_MAX];
   char mbox[MAXR][MAXR][MBOX_BYTES];
 };
@@ -42,52 +54,138 @@ struct Shared {
 struct FakeComm {
   Shared *sh = nullptr;
   int nranks = 1, rank = 0;
-  int local_sense = 0;
+  int local_sense = 0;     // touched by host functions only (they run one at a time per process and stream order)
   char name[64];
 };
 
-struct Op { int kind; void *buf; size_t bytes; int peer; FakeComm *c; hipStream_t st; };
-static thread_local int g_depth = 0;
-static thread_local std::vector<Op> g_ops;
+static bool g_sync = getenv("PHX_FAKE_RCCL_SYNC") && atoi(getenv("PHX_FAKE_RCCL_SYNC")) != 0;
 
+static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 static void nap() { struct timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }
-
 static int fail(const char *what) { fprintf(stderr, "fake_rccl: %s\n", what); return 1; }
+[[noreturn]] static void die(const char *what) { fprintf(stderr, "fake_rccl: %s -- aborting\n", what); fflush(stderr); abort(); }
+
+template <typename F>
+static void wait_until(F cond, const char *what) {
+  const double t0 = now_s();
+  while (!cond()) {
+    nap();
+    if (now_s() - t0 > WAIT_LIMIT_S) die(what);
+  }
+}
 
 static void barrier(FakeComm *c) {
   Shared *s = c->sh;
   c->local_sense ^= 1;
+  const int sense = c->local_sense;
   if (s->bar_count.fetch_add(1) + 1 == c->nranks) {
     s->bar_count.store(0);
-    s->bar_sense.store(c->local_sense);
+    s->bar_sense.store(sense);
   } else {
-    while (s->bar_sense.load() != c->local_sense) nap();
+    wait_until([&] { return s->bar_sense.load() == sense; }, "barrier: a rank never arrived");
   }
 }
 
 static size_t dtype_bytes(int dt) { return dt == 8 ? 8 : (dt == 7 ? 4 : (dt == 2 || dt == 3 ? 4 : (dt == 4 || dt == 5 ? 8 : 1))); }
 
+// ---- pinned staging blocks, recycled once the stream has passed the event recorded behind their last use ----------
+struct Block { void *p; size_t cap; hipEvent_t ev; int state; };   // 0 free, 1 handed out (no event yet), 2 waiting for its event
+static std::mutex g_pool_mu;
+static std::vector<Block> g_pool;
+
+static void *stage_get(size_t bytes, size_t *slot) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  for (size_t i = 0; i < g_pool.size(); ++i) {
+    Block &b = g_pool[i];
+    if (b.state == 2 && hipEventQuery(b.ev) == hipSuccess) b.state = 0;
+    if (b.state == 0 && b.cap >= bytes && b.cap <= 4 * (bytes < 256 ? 256 : bytes)) { b.state = 1; *slot = i; return b.p; }
+  }
+  Block b{nullptr, bytes < 256 ? 256 : bytes, nullptr, 1};
+  if (hipHostMalloc(&b.p, b.cap, hipHostMallocDefault) != hipSuccess) die("hipHostMalloc of a staging block");
+  if (hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) die("hipEventCreate");
+  g_pool.push_back(b);
+  *slot = g_pool.size() - 1;
+  return b.p;
+}
+static void stage_release_after(size_t slot, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (hipEventRecord(g_pool[slot].ev, st) != hipSuccess) die("hipEventRecord");
+  g_pool[slot].state = 2;
+}
+
+// ---- host functions ------------------------------------------------------------------------------------------------
+struct Ctx {
+  int kind;            // 0 send, 1 recv, 2 all-reduce, 3 all-gather
+  FakeComm *c;
+  int peer;
+  size_t bytes, count;
+  char *in, *out;      // pinned staging
+};
+
+static void host_fn(void *arg) {
+  Ctx *x = (Ctx *)arg;
+  FakeComm *c = x->c;
+  Shared *s = c->sh;
+  if (x->kind == 0) {
+    wait_until([&] { return s->full[c->rank][x->peer].load() == 0; }, "send: the peer never emptied the mailbox");
+    memcpy(s->mbox[c->rank][x->peer], x->in, x->bytes);
+    s->full[c->rank][x->peer].store((unsigned)x->bytes + 1u);
+  } else if (x->kind == 1) {
+    unsigned f = 0;
+    wait_until([&] { return (f = s->full[x->peer][c->rank].load()) != 0; }, "recv: the peer never sent");
+    if ((size_t)(f - 1u) != x->bytes) die("send / recv size mismatch");
+    memcpy(x->out, s->mbox[x->peer][c->rank], x->bytes);
+    s->full[x->peer][c->rank].store(0);
+  } else if (x->kind == 2) {
+    const double *mine = (const double *)x->in;
+    double *out = (double *)x->out;
+    for (size_t i = 0; i < x->count; ++i) s->red[c->rank][i] = mine[i];
+    barrier(c);
+    for (size_t i = 0; i < x->count; ++i) {
+      double sum = 0.0;
+      for (int r = 0; r < c->nranks; ++r) sum += s->red[r][i];   // rank order: every rank obtains the same bits
+      out[i] = sum;
+    }
+    barrier(c);   // nobody overwrites its deposit before everyone has read it
+  } else {
+    memcpy(s->mbox[c->rank][c->rank], x->in, x->bytes);
+    barrier(c);
+    for (int r = 0; r < c->nranks; ++r) memcpy(x->out + (size_t)r * x->bytes, s->mbox[r][r], x->bytes);
+    barrier(c);
+  }
+  delete x;
+}
+
+static int enqueue(Ctx *x, const void *src, void *dst, size_t in_bytes, size_t out_bytes, hipStream_t st) {
+  size_t si = 0, so = 0;
+  if (in_bytes) {
+    x->in = (char *)stage_get(in_bytes, &si);
+    if (hipMemcpyAsync(x->in, src, in_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return fail("D2H");
+  }
+  if (out_bytes) x->out = (char *)stage_get(out_bytes, &so);
+  if (hipLaunchHostFunc(st, host_fn, x) != hipSuccess) return fail("hipLaunchHostFunc");
+  if (out_bytes && hipMemcpyAsync(dst, x->out, out_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return fail("H2D");
+  if (in_bytes) stage_release_after(si, st);
+  if (out_bytes) stage_release_after(so, st);
+  if (g_sync && hipStreamSynchronize(st) != hipSuccess) return fail("stream sync");
+  return 0;
+}
+
+struct Op { int kind; void *buf; size_t bytes; int peer; FakeComm *c; hipStream_t st; };
+static thread_local int g_depth = 0;
+static thread_local std::vector<Op> g_ops;
+
 static int run_ops(std::vector<Op> &ops) {
-  if (ops.empty()) return 0;
-  if (hipStreamSynchronize(ops[0].st) != hipSuccess) return fail("stream sync");
-  // all sends first (a mailbox per ordered pair: never blocks on the peer's recv order), then the receives
-  for (auto &o : ops) {
-    if (o.kind != 0) continue;
-    if (o.bytes > MBOX_BYTES) return fail("message larger than the mailbox");
-    Shared *s = o.c->sh;
-    while (s->full[o.c->rank][o.peer].load() != 0) nap();
-    if (hipMemcpy(s->mbox[o.c->rank][o.peer], o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail("D2H");
-    s->full[o.c->rank][o.peer].store((unsigned)o.bytes + 1u);
-  }
-  for (auto &o : ops) {
-    if (o.kind != 1) continue;
-    Shared *s = o.c->sh;
-    unsigned f;
-    while ((f = s->full[o.peer][o.c->rank].load()) == 0) nap();
-    if ((size_t)(f - 1u) != o.bytes) return fail("send / recv size mismatch");
-    if (hipMemcpy(o.buf, s->mbox[o.peer][o.c->rank], o.bytes, hipMemcpyHostToDevice) != hipSuccess) return fail("H2D");
-    s->full[o.peer][o.c->rank].store(0);
-  }
+  // all sends first (a mailbox per ordered pair: a send never waits for the peer's recv of the SAME exchange), then
+  // the receives
+  for (int kind = 0; kind < 2; ++kind)
+    for (auto &o : ops) {
+      if (o.kind != kind) continue;
+      if (o.bytes > MBOX_BYTES) return fail("message larger than the mailbox");
+      Ctx *x = new Ctx{kind, o.c, o.peer, o.bytes, 0, nullptr, nullptr};
+      const int rc = kind == 0 ? enqueue(x, o.buf, nullptr, o.bytes, 0, o.st) : enqueue(x, nullptr, o.buf, 0, o.bytes, o.st);
+      if (rc) return rc;
+    }
   return 0;
 }
 
@@ -124,7 +222,7 @@ int ncclCommInitRank(void **comm, int nranks, fake_uid id, int rank) {
   if (p == MAP_FAILED) return fail("mmap");
   c->sh = (Shared *)p;   // a fresh segment is zero-filled: counters, senses and flags start at 0
   c->sh->attached.fetch_add(1);
-  while (c->sh->attached.load() < nranks) nap();
+  wait_until([&] { return c->sh->attached.load() >= nranks; }, "communicator set-up: a rank never attached");
   barrier(c);
   *comm = c;
   return 0;
@@ -133,6 +231,7 @@ int ncclCommInitRank(void **comm, int nranks, fake_uid id, int rank) {
 int ncclCommDestroy(void *comm) {
   FakeComm *c = (FakeComm *)comm;
   if (!c) return 0;
+  (void)hipDeviceSynchronize();   // no host function of this communicator is left in any stream
   barrier(c);
   munmap(c->sh, sizeof(Shared));
   if (c->rank == 0) shm_unlink(c->name);
@@ -161,21 +260,9 @@ int ncclRecv(void *buf, size_t count, int dtype, int peer, void *comm, hipStream
 
 // f64 SUM only (what the solver uses)
 int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t st) {
-  FakeComm *c = (FakeComm *)comm;
   if (dtype != 8 || op != 0 || count > RED_MAX) return fail("all-reduce: only f64 SUM of <= 64 values");
-  if (hipStreamSynchronize(st) != hipSuccess) return fail("stream sync");
-  double mine[RED_MAX], out[RED_MAX];
-  if (hipMemcpy(mine, send, count * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail("D2H");
-  for (size_t i = 0; i < count; ++i) c->sh->red[c->rank][i] = mine[i];
-  barrier(c);
-  for (size_t i = 0; i < count; ++i) {
-    double s = 0.0;
-    for (int r = 0; r < c->nranks; ++r) s += c->sh->red[r][i];
-    out[i] = s;
-  }
-  barrier(c);   // nobody overwrites its deposit before everyone has read it
-  if (hipMemcpy(recv, out, count * 8, hipMemcpyHostToDevice) != hipSuccess) return fail("H2D");
-  return 0;
+  Ctx *x = new Ctx{2, (FakeComm *)comm, -1, count * 8, count, nullptr, nullptr};
+  return enqueue(x, send, recv, count * 8, count * 8, st);
 }
 
 // every rank deposits its block in its own diagonal mailbox, all ranks read all blocks
@@ -183,13 +270,8 @@ int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *c
   FakeComm *c = (FakeComm *)comm;
   const size_t bytes = count * dtype_bytes(dtype);
   if (bytes > MBOX_BYTES) return fail("all-gather block larger than the mailbox");
-  if (hipStreamSynchronize(st) != hipSuccess) return fail("stream sync");
-  if (hipMemcpy(c->sh->mbox[c->rank][c->rank], send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail("D2H");
-  barrier(c);
-  for (int r = 0; r < c->nranks; ++r)
-    if (hipMemcpy((char *)recv + (size_t)r * bytes, c->sh->mbox[r][r], bytes, hipMemcpyHostToDevice) != hipSuccess) return fail("H2D");
-  barrier(c);
-  return 0;
+  Ctx *x = new Ctx{3, c, -1, bytes, count, nullptr, nullptr};
+  return enqueue(x, send, recv, bytes, bytes * (size_t)c->nranks, st);
 }
 
 const char *ncclGetErrorString(int e) { return e == 0 ? "ok" : "fake_rccl failure (see stderr)"; }

@@ -58,3 +58,27 @@ def test_gpus_2_without_launcher_starts_ranks_and_fails_without_a_gpu():
     assert r.returncode != 0
     assert "no GPU visible" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_watchdog_leaves_with_its_exit_code_and_marker(tmp_path):
+    """The RCCL watchdog (phifem_amd.dist_solver.Watchdog): a call that does not return within
+    PHIFEM_DIST_TIMEOUT_S makes the rank exit with code 87 and leave the marker file the launcher looks for; a
+    call that returns in time leaves nothing."""
+    import subprocess
+    import sys
+    mark = tmp_path / "mark"
+    code = ("import time, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from phifem_amd.dist_solver import Watchdog\n"
+            "with Watchdog('quick call', 0):\n"
+            "    pass\n"
+            "print('first ok', flush=True)\n"
+            "with Watchdog('stuck collective', 3):\n"
+            "    time.sleep(30)\n"
+            "print('not reached')\n") % ROOT
+    env = dict(os.environ, PHIFEM_DIST_TIMEOUT_S="0.5", PHIFEM_WATCHDOG_FILE=str(mark))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 87, (r.returncode, r.stderr[-500:])
+    assert "first ok" in r.stdout and "not reached" not in r.stdout
+    assert "stuck collective" in r.stderr and "rank 3" in r.stderr
+    assert mark.exists()

@@ -356,3 +356,30 @@ def test_structured_interior_rows_match_the_stored_matrix(P, d, n):
     finally:
         L.check(L.lib.phx_set_option(work._h, L.OPT_PRECOND, 1))
     assert np.abs(w - w3).max() <= 1e-7 * np.abs(w).max()
+
+
+def test_export_after_retagging_warns(P):
+    """the lazy CSR export re-assembles from the CURRENT tags; when the mesh was tagged again after
+    assemble() it must say so instead of silently exporting a different system, and `has_csr` tells the two cases
+    apart (a system assembled with PHX_OPT_EXPORT_CSR exports its own copy, no warning)."""
+    from phifem_amd import _lib as L
+    from phifem_amd.mesh_scripts import NodalFunction, _tag_cells, _tag_facets
+    work, phi, f, uex, A, b, act = setup_problem(P, 3, 12)
+    s = P.PhiFEMSolver(work)
+    info = s.assemble(phi, f, uex)
+    assert info["has_csr"] == 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        s.export_csr()                      # tags unchanged since assemble(): no warning
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        st = _tag_cells(work, NodalFunction(phi), 1, single_layer_cut=True)
+        _tag_facets(work, st, 1)
+    with pytest.warns(RuntimeWarning, match="tagged again"):
+        s.export_csr()
+    L.check(L.lib.phx_set_option(work._h, L.OPT_EXPORT_CSR, 1))
+    try:
+        s2 = P.PhiFEMSolver(work)
+        assert s2.assemble(phi, f, uex)["has_csr"] == 1
+    finally:
+        L.check(L.lib.phx_set_option(work._h, L.OPT_EXPORT_CSR, 0))
