@@ -349,6 +349,7 @@ def main(argv=None):
                 "parallelism": f"slab{world}", "ranks_seen": ranks_seen,
                 "dist_backend": backend if world > 1 else None,
                 "dist_loop": getattr(getattr(prob, "dk", None), "path", "native-single"),
+                "system": res.get("system"),
             },
             "roofline": dominant,
         }

@@ -81,8 +81,11 @@ __device__ __forceinline__ int64_t slot_base(const Slots &s, int32_t row, int *W
   return (int64_t)row * s.W;
 }
 
+// ANYKEY: the key may be negative (structured P2 systems encode a p column e as -2 - e: 2 (nv + ne) exceeds 2^31 at
+// 512^3); -1 stays the empty marker
+template <bool ANYKEY = false>
 __device__ __forceinline__ void slot_add(const Slots &s, int32_t row, int32_t col, double v) {
-  if (row < 0 || col < 0) return;  // inactive DoF (only reachable through user-overwritten tags)
+  if (row < 0 || (ANYKEY ? col == -1 : col < 0)) return;  // inactive DoF (only reachable through user-overwritten tags)
   int W;
   const int64_t base = slot_base(s, row, &W);
   int32_t *rc = s.cols + base;
@@ -1126,6 +1129,10 @@ extern "C" int phx_system_destroy(phx_system *s) {
                   s->sell_val_raw, s->sell_kind, s->perm, s->iperm, s->work, s->scal, s->row_nz,
                   s->c0, s->stencil, s->seg, s->slice_seg, s->sell_rows, s->cscale, s->pvec, s->bnd, s->bnd_rec};
   for (void *p : ptrs) (void)phx_free(p);
+  if (s->p2s) {
+    (void)phx_free(s->p2s->coef); (void)phx_free(s->p2s->mask); (void)phx_free(s->p2s->runs);
+    delete s->p2s;
+  }
   phx_box_precond_destroy(s->precond);
   delete s;
   return PHX_OK;
@@ -1530,7 +1537,7 @@ extern "C" int phx_system_info(const phx_system *s, int64_t *info) {
   info[0] = s->n; info[1] = s->nu; info[2] = s->nnz; info[3] = s->nfull;
   info[4] = s->sell_nnz; info[5] = s->slot_cap; info[6] = s->sell_true_nnz; info[7] = s->nslices;
   info[8] = s->sell_indexed_slices; info[9] = s->sell_stream_bytes; info[10] = s->sell_indexed_large;
-  info[11] = s->nc0; info[12] = s->nseg; info[13] = s->rowptr != nullptr;
+  info[11] = s->nc0; info[12] = s->p2s ? s->p2s->nrun : s->nseg; info[13] = s->rowptr != nullptr;
   return PHX_OK;
 }
 

@@ -155,6 +155,7 @@ struct P2Args {
   const int32_t *c2e;
   int32_t nvert;          // nv
   int kphi;               // degree of phi_h (1: values at vertices, 2: at vertices then edges)
+  int pneg;               // structured systems: the column key of p DoF e is -2 - e (phx_slot_view::pneg)
   DevRule cell, cut, facet;
 };
 
@@ -163,6 +164,11 @@ __device__ __forceinline__ void p2_cell_dofs(const P2Args &P, int64_t c, const i
   using B = P2B<D>;
   for (int i = 0; i < B::N; ++i) dof[i] = v[i];
   for (int k = 0; k < B::NE; ++k) dof[B::N + k] = P.nvert + P.c2e[c * B::NE + k];
+}
+
+// structured systems: rows the solver applies from a stencil own no slots (their offset is a shared dummy slot)
+__device__ __forceinline__ bool p2_row_skipped(const P2Args &P, int32_t row) {
+  return row < 0 || (P.A.c0 && P.A.c0[row]);
 }
 
 template <int D>
@@ -202,6 +208,7 @@ __global__ void __launch_bounds__(256) k_p2_cells(int64_t nlist, const int32_t *
   double X[B::N][D];
   load_cell<D>(P.A.cells, P.A.x, c, v, X);
   p2_cell_dofs<D>(P, c, v, dof);
+  if (p2_row_skipped(P, P.A.du[dof[r]])) return;
   Geo<D> G;
   simplex_geometry<D>(X, G);
   double GG[B::N][B::N];
@@ -221,6 +228,7 @@ __global__ void __launch_bounds__(256) k_p2_cells(int64_t nlist, const int32_t *
     if (s == 0) rhs += P.cell.w[q] * B::interp(2, lam, fn) * B::val(r, lam);
   }
   const int32_t row = P.A.du[dof[r]];
+  if (p2_row_skipped(P, row)) return;
   slot_add(P.A.slots, row, dof[s], acc * G.vol);
   if (s == 0) unsafeAtomicAdd(&P.A.rhs[row], rhs * G.vol);
 }
@@ -267,7 +275,9 @@ __global__ void __launch_bounds__(256) k_p2_cut(int64_t nlist, const int32_t *__
     else if (e_phi == 1) val = -gam * h1 * h1 * h1 * acc;
     else val = gam * h1 * h1 * h1 * h1 * acc;
     const int32_t row = ap ? P.A.dp[dof[r]] : P.A.du[dof[r]];
-    slot_add(P.A.slots, row, (bp ? P.A.nv : 0) + dof[s], val);
+    if (p2_row_skipped(P, row)) continue;
+    if (P.pneg) slot_add<true>(P.A.slots, row, bp ? -2 - dof[s] : dof[s], val);
+    else slot_add(P.A.slots, row, (bp ? P.A.nv : 0) + dof[s], val);
   }
   // right-hand side: one thread per row of the mixed tensor
   if (threadIdx.x < M) {
@@ -287,7 +297,8 @@ __global__ void __launch_bounds__(256) k_p2_cut(int64_t nlist, const int32_t *__
     double rv;
     if (!ap) rv = gam * h1 * h1 * acc - P.A.sigma * G.h * G.h * G.vol * fbar * B::lapl(r, GG);   // :147 (v), :150
     else rv = -gam * h1 * h1 * h1 * acc;                                                          // :147 (q)
-    unsafeAtomicAdd(&P.A.rhs[ap ? P.A.dp[dof[r]] : P.A.du[dof[r]]], rv);
+    const int32_t rrow = ap ? P.A.dp[dof[r]] : P.A.du[dof[r]];
+    if (!p2_row_skipped(P, rrow)) unsafeAtomicAdd(&P.A.rhs[rrow], rv);
   }
 }
 
@@ -336,7 +347,7 @@ __global__ void __launch_bounds__(256) k_p2_ds(int64_t nent, const int64_t *__re
     for (int m = 0; m < B::N; ++m) dn += cs[m] * gdotn[m];
     acc += P.facet.w[q] * B::val(r, lam) * dn;
   }
-  slot_add(P.A.slots, P.A.du[dof[r]], dof[s], -area * acc);
+  if (!p2_row_skipped(P, P.A.du[dof[r]])) slot_add(P.A.slots, P.A.du[dof[r]], dof[s], -area * acc);
 }
 
 // --- dS((2,3)): main.py:129-134  sigma avg(h) int_F [grad u . n][grad v . n] ----------------------
@@ -405,16 +416,22 @@ __global__ void __launch_bounds__(256) k_p2_facets(int64_t nlist, const int32_t 
       }
       acc += P.facet.w[q] * J[0] * J[1];
     }
-    slot_add(P.A.slots, P.A.du[dofs[a]], dofs[b], wgt * acc);
+    if (!p2_row_skipped(P, P.A.du[dofs[a]])) slot_add(P.A.slots, P.A.du[dofs[a]], dofs[b], wgt * acc);
   }
 }
+
+#include "phx_assemble_p2s.inc.hip"
 
 static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_coef, int kphi,
                                      const double *dphi, const double *df, const double *dud,
                                      int W, phx_system **out) {
   const int D = m->gdim;
   const int64_t nent = m->nv + m->ne;
-  PHX_REQUIRE(2 * nent < INT32_MAX, PHX_ERR_VALUE, "too many P2 DoFs for 32-bit column keys");
+  // 3-D Kuhn boxes: structured system -- the interior rows are applied from stencils, only the band around Gamma_h is
+  // assembled and stored (phx_assemble_p2s.inc.hip).  Not with PHX_OPT_EXPORT_CSR (the export wants every row).
+  const bool structured = D == 3 && m->is_box && !m->is_submesh && m->structured != 0 && !m->export_csr;
+  PHX_REQUIRE(nent < INT32_MAX - 2 && (structured || 2 * nent < INT32_MAX), PHX_ERR_VALUE,
+              "too many P2 DoFs for 32-bit column keys");
   phx_system *s = new phx_system();
   s->mesh = m; s->device = m->device; s->nfull = 2 * nent; s->slot_cap = W; s->nent = nent;
   s->u_p2_block = true;
@@ -453,20 +470,32 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
   PHX_HIP(phx_free(fu)); PHX_HIP(phx_free(fp)); PHX_HIP(phx_free(su)); PHX_HIP(phx_free(sp));
   Slots sl;
   sl.W = W;
-  PHX_HIP(phx_malloc(&sl.cols, sizeof(int32_t) * (size_t)s->n * W));
-  PHX_HIP(phx_malloc(&sl.vals, sizeof(double) * (size_t)s->n * W));
-  PHX_HIP(phx_malloc(&sl.overflow, sizeof(int)));
-  PHX_HIP(hipMemsetAsync(sl.cols, 0xff, sizeof(int32_t) * (size_t)s->n * W, m->stream));
-  PHX_HIP(hipMemsetAsync(sl.vals, 0, sizeof(double) * (size_t)s->n * W, m->stream));
-  PHX_HIP(hipMemsetAsync(sl.overflow, 0, sizeof(int), m->stream));
+  sl.cols = nullptr; sl.vals = nullptr; sl.overflow = nullptr;
   PHX_HIP(phx_malloc(&s->rhs, sizeof(double) * (size_t)s->n));
   PHX_HIP(hipMemsetAsync(s->rhs, 0, sizeof(double) * (size_t)s->n, m->stream));
-  P.A.du = s->dof_of_vertex_u; P.A.dp = s->dof_of_vertex_p; P.A.rhs = s->rhs; P.A.slots = sl;
+  P.A.du = s->dof_of_vertex_u; P.A.dp = s->dof_of_vertex_p; P.A.rhs = s->rhs;
   int32_t *l_om = nullptr, *l_cut = nullptr, *l_fac = nullptr;
   int64_t n_om = 0, n_cut = 0, n_fac = 0;
-  PHX_CHECK(build_list(m, m->nc, SelOmega{m->cell_tags}, &l_om, &n_om));
   PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut));
   PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac));
+  P2SPrep prep;
+  if (structured) {
+    s->structured = true;
+    s->u_unscaled = true;
+    P.pneg = 1;
+    const int rcp = p2s_prepare(s, P, sl, l_fac, n_fac, W, &prep);
+    if (rcp != PHX_OK) { (void)phx_free(l_cut); (void)phx_free(l_fac); phx_system_destroy(s); return rcp; }
+    l_om = prep.l_cells; n_om = prep.n_cells;
+  } else {
+    PHX_HIP(phx_malloc(&sl.cols, sizeof(int32_t) * (size_t)s->n * W));
+    PHX_HIP(phx_malloc(&sl.vals, sizeof(double) * (size_t)s->n * W));
+    PHX_HIP(phx_malloc(&sl.overflow, sizeof(int)));
+    PHX_HIP(hipMemsetAsync(sl.cols, 0xff, sizeof(int32_t) * (size_t)s->n * W, m->stream));
+    PHX_HIP(hipMemsetAsync(sl.vals, 0, sizeof(double) * (size_t)s->n * W, m->stream));
+    PHX_HIP(hipMemsetAsync(sl.overflow, 0, sizeof(int), m->stream));
+    PHX_CHECK(build_list(m, m->nc, SelOmega{m->cell_tags}, &l_om, &n_om));
+  }
+  P.A.slots = sl;
   if (n_om > 0) {
     PHX_REQUIRE_GRID(n_om * (D == 2 ? 64 : 128), "P2 cell assembly");
     if (D == 2) k_p2_cells<2, 64><<<dim3((unsigned)phx_div_up(n_om * 64, 256)), block, 0, m->stream>>>(n_om, l_om, P);
@@ -493,6 +522,18 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(l_om)); PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_fac));
   for (void *p : keep) PHX_HIP(phx_free(p));
+  if (structured) {
+    int rc = check_overflow(m, sl);
+    if (rc == PHX_OK) {
+      const phx_slot_view sv{sl.cols, sl.vals, sl.W, sl.clean, sl.off, sl.wlog, true};
+      rc = phx_system_build_structured_p2(s, sv, (int32_t)nent, prep.latc0, prep.latc0i);
+      (void)free_slots(sl);
+    }
+    (void)phx_free(prep.latc0); (void)phx_free(prep.latc0i); (void)phx_free(prep.coefM);
+    if (rc != PHX_OK) { phx_system_destroy(s); return rc; }
+    *out = s;
+    return PHX_OK;
+  }
   const int rc = phx_finish_system(s, sl, (int32_t)nent);
   if (rc != PHX_OK) { phx_system_destroy(s); return rc; }
   *out = s;

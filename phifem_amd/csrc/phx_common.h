@@ -139,6 +139,55 @@ struct phx_mesh {
   int allow_empty = 0;             // PHX_OPT_ALLOW_EMPTY: assembly returns an EMPTY system when no cell is tagged 1 / 2
 };
 
+// ---- P2 on a Kuhn box: the DoFs (vertices and edge midpoints) are exactly the points of the lattice of spacing h / 2
+// ("fine lattice", F_a = 2 n_a + 1 points per axis).  Closed-form maps both ways: the edge numbering of a generated box
+// is base[class] + anchor index inside the class extent (phx_mesh.hip, k_box_c2e).
+struct phx_p2_lattice {
+  int64_t n[3];        // cubes per axis
+  int64_t F[3];        // fine points per axis
+  int64_t nv;          // vertices
+  int64_t base[8];     // edge class c holds the ids base[c] .. base[c+1]-1
+  int64_t ext[7][3];   // anchor extents of the class
+};
+// edge class of a direction (a, b, c) in {0,1}^3 \ 0: x, y, z, (x,y), (x,z), (y,z), (x,y,z)
+__host__ __device__ __forceinline__ int phx_p2_edge_class(int a, int b, int c) {
+  const int nd = a + b + c;
+  return nd == 1 ? (a ? 0 : (b ? 1 : 2)) : (nd == 2 ? (!c ? 3 : (!b ? 4 : 5)) : 6);
+}
+__host__ __device__ __forceinline__ int64_t phx_p2_entity_of_fine(const phx_p2_lattice &L, int64_t I, int64_t J, int64_t K) {
+  const int a = (int)(I & 1), b = (int)(J & 1), c = (int)(K & 1);
+  const int64_t i = I >> 1, j = J >> 1, k = K >> 1;
+  if (!(a | b | c)) return i + (L.n[0] + 1) * (j + (L.n[1] + 1) * k);
+  const int cls = phx_p2_edge_class(a, b, c);
+  return L.nv + L.base[cls] + i + L.ext[cls][0] * (j + L.ext[cls][1] * k);
+}
+__host__ __device__ __forceinline__ void phx_p2_fine_of_entity(const phx_p2_lattice &L, int64_t e, int64_t *q) {
+  if (e < L.nv) {
+    const int64_t n0 = L.n[0] + 1, n1 = L.n[1] + 1, r = e / n0;
+    q[0] = 2 * (e - r * n0); q[1] = 2 * (r % n1); q[2] = 2 * (r / n1);
+    return;
+  }
+  const int64_t id = e - L.nv;
+  int cls = 0;
+  while (cls < 6 && id >= L.base[cls + 1]) ++cls;
+  const int64_t rem = id - L.base[cls], r = rem / L.ext[cls][0];
+  const int dir[7][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+  q[0] = 2 * (rem - r * L.ext[cls][0]) + dir[cls][0];
+  q[1] = 2 * (r % L.ext[cls][1]) + dir[cls][1];
+  q[2] = 2 * (r / L.ext[cls][1]) + dir[cls][2];
+}
+// Structured P2 system: interior rows (every DoF of the 5 x 5 x 5 fine neighbourhood has its whole support tagged
+// inside) are applied from 8 translation-invariant stencils (one per parity class of the fine point) over runs of
+// consecutive fine points of one x line; everything else sits in SELL over a row list, as for P1.
+#define PHX_P2S_REC 32   // ints per run record: {first position, length, (b + 2 c) | a0 << 2, 25 line offsets, pad}
+struct phx_p2_struct {
+  phx_p2_lattice lat;
+  double *coef = nullptr;      // device [8][125]: class a + 2 b + 4 c, offset (dx+2) + 5 (dy+2) + 25 (dz+2)
+  unsigned long long *mask = nullptr;  // device [4][2]: offsets with a non-zero coefficient for a = 0 or a = 1, per (b + 2 c)
+  int32_t *runs = nullptr;     // device [nrun][PHX_P2S_REC]
+  int64_t nrun = 0, nc0i = 0;
+};
+
 struct phx_system {
   phx_mesh *mesh = nullptr;
   int device = 0;
@@ -203,6 +252,7 @@ struct phx_system {
   uint8_t *bnd = nullptr;          // [n] 1: row references an entry some neighbour sends
   int32_t *bnd_rec = nullptr;      // [nbnd][6] {row, kind (0 stencil / 1 SELL-16 / 2 SELL-64), 4 kind-specific ints}
   int64_t nbnd = 0;
+  phx_p2_struct *p2s = nullptr;    // structured P2 system (3-D Kuhn boxes), else nullptr
 };
 
 // helpers implemented in phx_mesh.hip
@@ -223,7 +273,12 @@ struct phx_slot_view {
   const uint8_t *clean;   // clean[row] = c > 0: the row's c entries sit at slots 0 .. c-1
   const int64_t *off;     // per-row slot offsets (nullptr: row * W)
   const uint8_t *wlog;
+  bool pneg = false;      // column key of a p DoF e: -2 - e (structured P2) instead of nent + e
 };
 int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t nent);  // phx_solve.hip
+// structured P2: lattice flags of the C0 rows / of the rows the stencils apply (uint8 [F0 F1 F2]), s->c0 = the latter
+// in active numbering, s->p2s with lattice + coefficient tables set (phx_solve.hip)
+int phx_system_build_structured_p2(phx_system *s, const phx_slot_view &sv, int32_t nent, const uint8_t *latc0,
+                                   const uint8_t *latc0i);
 struct phx_box_precond;
 void phx_box_precond_destroy(phx_box_precond *bp);  // phx_solve.hip

@@ -292,6 +292,12 @@ __device__ __forceinline__ int64_t sv_base(const phx_slot_view &sv, int64_t row,
   return row * sv.W;
 }
 
+// active row of the column key `cc` of a slot
+__device__ __forceinline__ int32_t sv_col(const phx_slot_view &sv, int32_t cc, int32_t nent, const int32_t *du, const int32_t *dp) {
+  if (sv.pneg) return cc < -1 ? dp[-2 - cc] : du[cc];
+  return cc < nent ? du[cc] : dp[cc - nent];
+}
+
 // per stored row (one wavefront each, over the compacted list): entries the SELL copy keeps (non-zero, or the
 // diagonal), the diagonal itself, the structural count.  A C0 row in the list (C0 rows next to a non-C0 row are
 // stored, not applied) has no slots unless the CSR is exported: its row IS the stencil row.
@@ -303,7 +309,7 @@ k_slot_row_meta(int64_t ns, const int32_t *__restrict__ list, phx_slot_view sv, 
   const int64_t i = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
   if (i >= ns) return;
   const int32_t row = list[i];
-  if (c0[row]) {
+  if (c0 && c0[row]) {
     if (lane == 0) { len[i] = gdim == 3 ? 7 : 5; nstruct[i] = gdim == 3 ? 15 : 7; }
     return;
   }
@@ -315,7 +321,7 @@ k_slot_row_meta(int64_t ns, const int32_t *__restrict__ list, phx_slot_view sv, 
   for (int k = lane; k < limit; k += 64) {
     const int32_t cc = sv.cols[base + k];
     if (cc == -1) continue;
-    const int32_t col = cc < nent ? du[cc] : dp[cc - nent];
+    const int32_t col = sv_col(sv, cc, nent, du, dp);
     const double v = sv.vals[base + k];
     ++st;
     if (col == row) { diag[row] = v; ++keep; }
@@ -1107,6 +1113,8 @@ k_spmv_bnd(int64_t nrec, const int32_t *__restrict__ rec, const int64_t *__restr
   }
 }
 
+#include "phx_spmv_p2s.inc.hip"
+
 // ---------------------------------------------------------------------------------------------
 // BiCGStab.  All scalars live on the device: S[0..7] is solver state, R = S+8 holds the dot
 // products of the running iteration (local partial sums; a multi-GPU driver all-reduces R between
@@ -1352,15 +1360,25 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
     sa = StencilArgs{s->nstencil_pos, s->seg, s->nseg, s->slice_seg, s->stencil, (nbst + 7) / 8};
     nb = nb_sell + 8 * sa.chunk;
   }
-  if (nb == 0) return PHX_OK;
-  const dim3 g2((unsigned)nb);
-  if (dots == 0)
+  if (nb == 0 && !s->p2s) return PHX_OK;
+  const dim3 g2((unsigned)std::max<int64_t>(nb, 1));
+  if (nb == 0) {}
+  else if (dots == 0)
     k_spmv_sell<0><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd);
   else if (dots == 1)
     k_spmv_sell<1><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd);
   else
     k_spmv_sell<2><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd);
   PHX_HIP(hipGetLastError());
+  if (s->p2s && s->p2s->nrun > 0 && part_of == 0 && part != 1) {
+    // structured P2: the interior rows from the eight class stencils, one wavefront per run
+    const phx_p2_struct *ps = s->p2s;
+    const dim3 gp((unsigned)std::min<int64_t>(phx_div_up(ps->nrun, 4), 4096));
+    if (dots == 0) k_spmv_p2s<0><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->coef, ps->mask, x, y, d0, o0, o1);
+    else if (dots == 1) k_spmv_p2s<1><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->coef, ps->mask, x, y, d0, o0, o1);
+    else k_spmv_p2s<2><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->coef, ps->mask, x, y, d0, o0, o1);
+    PHX_HIP(hipGetLastError());
+  }
   return PHX_OK;
 }
 

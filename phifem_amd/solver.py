@@ -128,14 +128,14 @@ class PhiFEMSolver:
         (stencil-coded interior rows + SELL, PHX_OPT_STRUCTURED) and never form it; the first export
         re-assembles the same inputs once with PHX_OPT_EXPORT_CSR set and reads the CSR of that system."""
         i = self.info()
-        n, nnz = i["n_active"], i["nnz"]
-        rowptr = np.empty(n + 1, dtype=np.int64)
-        col = np.empty(nnz, dtype=np.int32)
-        val = np.empty(nnz, dtype=np.float64)
-        rhs = np.empty(n, dtype=np.float64)
-        dof = np.empty(n, dtype=np.int64)
-        args = [a.ctypes.data_as(C.c_void_p) for a in (rowptr, col, val, rhs, dof)]
+
+        def buffers(n, nnz):
+            arrs = (np.empty(n + 1, dtype=np.int64), np.empty(nnz, dtype=np.int32), np.empty(nnz, dtype=np.float64),
+                    np.empty(n, dtype=np.float64), np.empty(n, dtype=np.int64))
+            return arrs, [a.ctypes.data_as(C.c_void_p) for a in arrs]
+
         if i["has_csr"]:
+            (rowptr, col, val, rhs, dof), args = buffers(i["n_active"], i["nnz"])
             L.check(L.lib.phx_system_export(self._sys, *args))
         elif getattr(self, "_keep", None) is not None and getattr(self, "_tag_generation", None) is not None:
             if self._tag_generation != self.mesh._tag_generation:
@@ -148,10 +148,15 @@ class PhiFEMSolver:
             finally:
                 L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_EXPORT_CSR, 0))
             try:
+                # sizes of the RE-ASSEMBLED system: a structured system only estimates its structural count
+                j = (C.c_int64 * 14)()
+                L.check(L.lib.phx_system_info(h, j))
+                (rowptr, col, val, rhs, dof), args = buffers(int(j[0]), int(j[2]))
                 L.check(L.lib.phx_system_export(h, *args))
             finally:
                 L.lib.phx_system_destroy(h)
         else:
+            (rowptr, col, val, rhs, dof), args = buffers(i["n_active"], i["nnz"])
             L.check(L.lib.phx_system_export(self._sys, *args))   # reports "assembled without its CSR copy"
         return rowptr, col, val, rhs, dof
 

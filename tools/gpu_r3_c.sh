@@ -1,0 +1,14 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 300 python -m pytest tests/test_hip_p2.py -x -q -m gpu > gpurun_out/c_p2.log 2>&1 || { tail -20 gpurun_out/c_p2.log; exit 1; }
+tail -2 gpurun_out/c_p2.log
+for n in 128 256; do
+  timeout -k 10 600 python bench.py --config3 --cubes $n --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/c_p2_$n.json 2> gpurun_out/c_p2_$n.err
+  echo "cubes $n rc=$?"; python - <<PY
+import json
+d=json.load(open("gpurun_out/c_p2_$n.json"))
+c=d["config"]; print(d["value"], d["ms_per_step"], c["active_dofs"], c["iterations"], c["converged"], c["stage_ms"], d["roofline"]["avg_launch_us"])
+PY
+done
+rocm-smi --showmeminfo vram | head -8
