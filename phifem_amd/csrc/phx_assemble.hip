@@ -1131,6 +1131,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
   for (void *p : ptrs) (void)phx_free(p);
   if (s->p2s) {
     (void)phx_free(s->p2s->coef); (void)phx_free(s->p2s->mask); (void)phx_free(s->p2s->runs);
+    (void)phx_free(s->p2s->tabE); (void)phx_free(s->p2s->tabO); (void)phx_free(s->p2s->linemask);
     delete s->p2s;
   }
   phx_box_precond_destroy(s->precond);

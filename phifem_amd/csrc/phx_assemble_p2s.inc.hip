@@ -230,7 +230,24 @@ static int p2s_prepare(phx_system *s, P2Args &P, Slots &sl, const int32_t *l_fac
   PHX_HIP(hipMemcpyAsync(ps->coef, K.data(), sizeof(double) * 1000, hipMemcpyHostToDevice, st));
   PHX_HIP(hipMemcpyAsync(out->coefM, M.data(), sizeof(double) * 1000, hipMemcpyHostToDevice, st));
   PHX_HIP(hipMemcpyAsync(ps->mask, mask, sizeof(mask), hipMemcpyHostToDevice, st));
-  PHX_HIP(hipStreamSynchronize(st));   // K, M, mask are host temporaries
+  std::vector<double> tabE(500), tabO(500);
+  unsigned linemask[4] = {0, 0, 0, 0};
+  for (int bc = 0; bc < 4; ++bc)
+    for (int l = 0; l < 25; ++l)
+      for (int dx = 0; dx < 5; ++dx) {
+        const int o = dx + 5 * l;
+        const double ce = K[(size_t)(2 * bc) * 125 + o], co = K[(size_t)(2 * bc + 1) * 125 + o];
+        tabE[(size_t)(bc * 25 + l) * 5 + dx] = ce;
+        tabO[(size_t)(bc * 25 + l) * 5 + dx] = co;
+        if (ce != 0.0 || co != 0.0) linemask[bc] |= 1u << l;
+      }
+  PHX_HIP(phx_malloc(&ps->tabE, sizeof(double) * 500));
+  PHX_HIP(phx_malloc(&ps->tabO, sizeof(double) * 500));
+  PHX_HIP(phx_malloc(&ps->linemask, sizeof(linemask)));
+  PHX_HIP(hipMemcpyAsync(ps->tabE, tabE.data(), sizeof(double) * 500, hipMemcpyHostToDevice, st));
+  PHX_HIP(hipMemcpyAsync(ps->tabO, tabO.data(), sizeof(double) * 500, hipMemcpyHostToDevice, st));
+  PHX_HIP(hipMemcpyAsync(ps->linemask, linemask, sizeof(linemask), hipMemcpyHostToDevice, st));
+  PHX_HIP(hipStreamSynchronize(st));   // K, M, mask, tab are host temporaries
   // ---- C0 on the fine lattice, c0i by erosion with the 5 x 5 x 5 box
   uint8_t *bad = nullptr, *tmp = nullptr;
   PHX_HIP(phx_malloc(&bad, (size_t)nent));

@@ -184,6 +184,10 @@ struct phx_p2_struct {
   phx_p2_lattice lat;
   double *coef = nullptr;      // device [8][125]: class a + 2 b + 4 c, offset (dx+2) + 5 (dy+2) + 25 (dz+2)
   unsigned long long *mask = nullptr;  // device [4][2]: offsets with a non-zero coefficient for a = 0 or a = 1, per (b + 2 c)
+  // the same coefficients as k_spmv_p2s reads them: per line type bc = b + 2 c and neighbouring line l = (dy+2) + 5 (dz+2)
+  // the five dx coefficients for a = 0 (tabE) and a = 1 (tabO); linemask[bc] bit l = the line has a non-zero coefficient
+  double *tabE = nullptr, *tabO = nullptr;   // device [4][25][5]
+  unsigned *linemask = nullptr;              // device [4]
   int32_t *runs = nullptr;     // device [nrun][PHX_P2S_REC]
   int64_t nrun = 0, nc0i = 0;
 };

@@ -1374,9 +1374,9 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
     // structured P2: the interior rows from the eight class stencils, one wavefront per run
     const phx_p2_struct *ps = s->p2s;
     const dim3 gp((unsigned)std::min<int64_t>(phx_div_up(ps->nrun, 4), 4096));
-    if (dots == 0) k_spmv_p2s<0><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->coef, ps->mask, x, y, d0, o0, o1);
-    else if (dots == 1) k_spmv_p2s<1><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->coef, ps->mask, x, y, d0, o0, o1);
-    else k_spmv_p2s<2><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->coef, ps->mask, x, y, d0, o0, o1);
+    if (dots == 0) k_spmv_p2s<0><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->tabE, ps->tabO, ps->linemask, x, y, d0, o0, o1);
+    else if (dots == 1) k_spmv_p2s<1><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->tabE, ps->tabO, ps->linemask, x, y, d0, o0, o1);
+    else k_spmv_p2s<2><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->tabE, ps->tabO, ps->linemask, x, y, d0, o0, o1);
     PHX_HIP(hipGetLastError());
   }
   return PHX_OK;
