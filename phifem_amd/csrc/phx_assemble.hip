@@ -1509,6 +1509,45 @@ static int to_device(phx_mesh *m, const double *p, int loc, int64_t n, const dou
   return PHX_OK;
 }
 
+// caller-supplied Kuhn box (phx_mesh::inner): tags and nodal data into the numbering of the generated box
+__global__ void k_push_tags(int64_t n, const int32_t *__restrict__ map, const int8_t *__restrict__ src, int8_t *__restrict__ dst) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n && map[i] >= 0) dst[map[i]] = src[i];
+}
+__global__ void k_gather_nodal(int64_t n, const int32_t *__restrict__ lat2v, const double *__restrict__ src, double *__restrict__ dst) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[lat2v[i]];
+}
+
+static int assemble_poisson_wd_on_inner(phx_mesh *m, double pen_coef, double stab_coef, const double *phi_h,
+                                        const double *f_h, const double *u_D, int loc, phx_system **out) {
+  phx_mesh *in = m->inner;
+  hipStream_t st = m->stream;
+  const dim3 block(256);
+  k_push_tags<<<dim3((unsigned)phx_div_up(m->nc, 256)), block, 0, st>>>(m->nc, m->in_cmap, m->cell_tags, in->cell_tags);
+  k_push_tags<<<dim3((unsigned)phx_div_up(m->nf, 256)), block, 0, st>>>(m->nf, m->in_fmap, m->facet_tags, in->facet_tags);
+  in->have_cell_tags = in->have_facet_tags = true;
+  in->have_entities = false;
+  for (int i = 0; i < 4; ++i) in->tag_hist[i] = m->tag_hist[i];
+  for (int i = 0; i < 8; ++i) in->ftag_hist[i] = m->ftag_hist[i];
+  in->has_exterior_override = m->has_exterior_override;
+  const double *src[3], *dev[3];
+  double *owned[3] = {nullptr, nullptr, nullptr}, *perm[3] = {nullptr, nullptr, nullptr};
+  src[0] = phi_h; src[1] = f_h; src[2] = u_D;
+  const dim3 gv((unsigned)phx_div_up(m->nv, 256));
+  for (int k = 0; k < 3; ++k) {
+    PHX_CHECK(to_device(m, src[k], loc, m->nv, &dev[k], &owned[k]));
+    PHX_HIP(phx_malloc(&perm[k], sizeof(double) * (size_t)m->nv));
+    k_gather_nodal<<<gv, block, 0, st>>>(m->nv, m->lat2v, dev[k], perm[k]);
+  }
+  PHX_HIP(hipGetLastError());
+  const int rc = phx_assemble_poisson_wd(in, pen_coef, stab_coef, perm[0], perm[1], perm[2], PHX_DEVICE, out);
+  PHX_HIP(hipStreamSynchronize(st));
+  for (int k = 0; k < 3; ++k) { if (owned[k]) (void)phx_free(owned[k]); (void)phx_free(perm[k]); }
+  if (rc == PHX_OK) { (*out)->out_vertex = m->lat2v; (*out)->outer = m; }
+  return rc;
+}
+
 extern "C" int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab_coef,
                                        const double *phi_h, const double *f_h, const double *u_D,
                                        int loc, phx_system **out) {
@@ -1517,6 +1556,8 @@ extern "C" int phx_assemble_poisson_wd(phx_mesh *m, double pen_coef, double stab
               PHX_ERR_NOT_IMPLEMENTED, "assembly supports simplices (triangle, tetrahedron) only");
   PHX_REQUIRE(m->have_cell_tags && m->have_facet_tags, PHX_ERR_VALUE,
               "cell and facet tags must be computed before assembly");
+  // a caller-supplied mesh that is a Kuhn box in disguise: assemble (and later solve) on the generated box behind it
+  if (m->inner) return assemble_poisson_wd_on_inner(m, pen_coef, stab_coef, phi_h, f_h, u_D, loc, out);
   if (!m->is_box) PHX_CHECK(build_v2c(m));  // Kuhn boxes enumerate vertex stars in closed form
   const double *dphi, *df, *dud;
   double *o1, *o2, *o3;
@@ -1564,6 +1605,11 @@ extern "C" int phx_system_export(phx_system *s, int64_t *rowptr, int32_t *col, d
   if (val) PHX_HIP(hipMemcpy(val, s->val, sizeof(double) * (size_t)s->nnz, hipMemcpyDeviceToHost));
   if (rhs) PHX_HIP(hipMemcpy(rhs, s->rhs, sizeof(double) * (size_t)s->n, hipMemcpyDeviceToHost));
   if (dof) PHX_HIP(hipMemcpy(dof, s->full_of_active, sizeof(int64_t) * (size_t)s->n, hipMemcpyDeviceToHost));
+  if (dof && s->out_vertex) {   // assembled on the inner box of a caller-supplied mesh: full indices in the caller's numbering
+    std::vector<int32_t> map((size_t)s->nent);
+    PHX_HIP(hipMemcpy(map.data(), s->out_vertex, sizeof(int32_t) * (size_t)s->nent, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < s->n; ++i) dof[i] = (dof[i] / s->nent) * s->nent + map[(size_t)(dof[i] % s->nent)];
+  }
   return PHX_OK;
 }
 

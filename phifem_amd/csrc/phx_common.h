@@ -137,6 +137,14 @@ struct phx_mesh {
   int export_csr = 0;              // PHX_OPT_EXPORT_CSR: assembly also builds the CSR copy phx_system_export reads
   int structured = 1;              // PHX_OPT_STRUCTURED: stencil-coded interior rows on Kuhn boxes (P1 weak Dirichlet)
   int allow_empty = 0;             // PHX_OPT_ALLOW_EMPTY: assembly returns an EMPTY system when no cell is tagged 1 / 2
+  // A caller-supplied mesh that IS a Kuhn box in some vertex / cell order (what dolfinx's create_box / create_rectangle
+  // hand over, demo/weak-dirichlet/flower/main.py:45-46): `inner` is the generated box with the same lattice, the maps
+  // translate.  Tags are computed on THIS mesh (caller numbering, bit-exact as before); the P1 weak-Dirichlet assembly
+  // pushes them to `inner` and assembles / solves there -- closed-form rows, stencil operator, SELL-16, lattice
+  // preconditioner -- and the solution comes back in the caller's numbering.  Vertex maps: v2lat / lat2v.
+  phx_mesh *inner = nullptr;
+  int32_t *in_cmap = nullptr;      // [nc] cell -> cell of `inner`
+  int32_t *in_fmap = nullptr;      // [nf] facet -> facet of `inner`
 };
 
 // ---- P2 on a Kuhn box: the DoFs (vertices and edge midpoints) are exactly the points of the lattice of spacing h / 2
@@ -257,6 +265,10 @@ struct phx_system {
   int32_t *bnd_rec = nullptr;      // [nbnd][6] {row, kind (0 stencil / 1 SELL-16 / 2 SELL-64), 4 kind-specific ints}
   int64_t nbnd = 0;
   phx_p2_struct *p2s = nullptr;    // structured P2 system (3-D Kuhn boxes), else nullptr
+  // system assembled on the `inner` box of a caller-supplied mesh: vertex of s->mesh -> vertex of the caller's mesh
+  // (applied where full DoF indices leave the library: the solution vector, phx_system_export's dof map)
+  const int32_t *out_vertex = nullptr;
+  phx_mesh *outer = nullptr;       // the caller's mesh (timings are mirrored there)
 };
 
 // helpers implemented in phx_mesh.hip

@@ -377,7 +377,8 @@ static int build_boundary_list(phx_mesh *m) {
 // Conditions: per axis the coordinates take n_a + 1 equispaced values (1e-9 of the extent), prod (n_a + 1) = nv,
 // vertex -> lattice point is a bijection, and every cell lies inside one lattice cube.  Host work, O(nv log nv).
 static bool detect_lattice(int gdim, int nvpc, int64_t nv, const double *coords, int64_t nc, const int32_t *cells,
-                           int64_t n_out[3], double h_out[3], std::vector<int32_t> &v2lat, std::vector<int32_t> &lat2v) {
+                           int64_t n_out[3], double h_out[3], std::vector<int32_t> &v2lat, std::vector<int32_t> &lat2v,
+                           double lo_out[3], double hi_out[3]) {
   if (nv < 8 || nv >= INT32_MAX) return false;
   double lo[3] = {0, 0, 0}, h[3] = {0, 0, 0};
   int64_t n[3] = {1, 1, 1};
@@ -394,6 +395,8 @@ static bool detect_lattice(int gdim, int nvpc, int64_t nv, const double *coords,
     n[a] = distinct - 1;
     lo[a] = tmp.front();
     h[a] = ext / (double)n[a];
+    lo_out[a] = tmp.front();
+    hi_out[a] = tmp.back();
   }
   int64_t prod = 1;
   for (int a = 0; a < gdim; ++a) prod *= n[a] + 1;
@@ -427,6 +430,108 @@ static bool detect_lattice(int gdim, int nvpc, int64_t nv, const double *coords,
 }
 
 #include "phx_topology.inc.hip"
+
+// ---- caller-supplied Kuhn boxes ---------------------------------------------------------------------------------------
+// cell c of the caller's mesh -> cell of the generated box with the same lattice: cube = lower corner of its vertices,
+// t = the axis permutation its vertices walk (o, o + e_p0, o + e_p0 + e_p1, ...).  bad: some cell is not such a path.
+__global__ void k_inner_cmap(int64_t nc, int d, const int32_t *__restrict__ cells, const int32_t *__restrict__ v2lat,
+                             int64_t n0, int64_t n1, int64_t n2, int32_t *__restrict__ cmap, int *__restrict__ bad) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int N = d + 1;
+  int64_t idx[4][3];
+  int64_t o[3] = {INT64_MAX, INT64_MAX, INT64_MAX};
+  for (int k = 0; k < N; ++k) {
+    const int64_t id = v2lat[cells[c * N + k]];
+    idx[k][0] = id % (n0 + 1);
+    idx[k][1] = d == 3 ? (id / (n0 + 1)) % (n1 + 1) : id / (n0 + 1);
+    idx[k][2] = d == 3 ? id / ((n0 + 1) * (n1 + 1)) : 0;
+    for (int a = 0; a < 3; ++a) o[a] = min(o[a], idx[k][a]);
+  }
+  // vertex with m ones in its offset from o is path vertex m; the axis that appears at step m is p[m-1]
+  int bits_of[4] = {-1, -1, -1, -1};
+  bool ok = true;
+  for (int k = 0; k < N; ++k) {
+    int bits = 0, cnt = 0;
+    for (int a = 0; a < d; ++a) {
+      const int64_t off = idx[k][a] - o[a];
+      if (off < 0 || off > 1) ok = false;
+      if (off == 1) { bits |= 1 << a; ++cnt; }
+    }
+    if (cnt > d || bits_of[cnt] != -1) ok = false; else bits_of[cnt] = bits;
+  }
+  int p[3] = {0, 1, 2};
+  for (int mstep = 1; ok && mstep <= d; ++mstep) {
+    const int add = bits_of[mstep] & ~bits_of[mstep - 1];
+    if ((bits_of[mstep] & bits_of[mstep - 1]) != bits_of[mstep - 1] || __popc(add) != 1) ok = false;
+    else p[mstep - 1] = __ffs(add) - 1;
+  }
+  if (!ok || o[0] >= n0 || o[1] >= n1 || (d == 3 && o[2] >= n2)) { atomicOr(bad, 1); cmap[c] = 0; return; }
+  const int t = d == 3 ? p[0] * 2 + (p[1] > p[2] ? 1 : 0) : p[0];
+  const int64_t cube = o[0] + n0 * (o[1] + (d == 3 ? n1 * o[2] : 0));
+  cmap[c] = (int32_t)(cube * (d == 3 ? 6 : 2) + t);
+}
+
+// facet f of the caller's mesh -> facet of the generated box: the facet opposite local vertex lf of cell c is the facet
+// opposite the same lattice vertex in cell cmap[c]
+__global__ void k_inner_fmap(int64_t nc, int N, const int32_t *__restrict__ cells, const int32_t *__restrict__ c2f,
+                             const int32_t *__restrict__ v2lat, const int32_t *__restrict__ cmap,
+                             const int32_t *__restrict__ icells, const int32_t *__restrict__ ic2f,
+                             int32_t *__restrict__ fmap, int *__restrict__ bad) {
+  const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int64_t ci = cmap[c];
+  for (int lf = 0; lf < N; ++lf) {
+    const int32_t lat = v2lat[cells[c * N + lf]];
+    int k = -1;
+    for (int q = 0; q < N; ++q) if (icells[ci * N + q] == lat) k = q;
+    if (k < 0) { atomicOr(bad, 1); continue; }
+    fmap[c2f[c * N + lf]] = ic2f[ci * N + k];
+  }
+}
+
+extern "C" int phx_mesh_create_box(int gdim, const double *lo, const double *hi, const int64_t *n,
+                                   const int64_t *offset, const int64_t *n_global, int device, phx_mesh **out);
+
+static int mesh_attach_inner_box(phx_mesh *m, const double lo[3], const double hi[3]) {
+  const int d = m->gdim, N = d + 1;
+  int *bad = nullptr, hbad = 0;
+  PHX_HIP(phx_malloc(&m->in_cmap, sizeof(int32_t) * (size_t)m->nc));
+  PHX_HIP(phx_malloc(&bad, sizeof(int)));
+  PHX_HIP(hipMemsetAsync(bad, 0, sizeof(int), m->stream));
+  const dim3 block(256), gc((unsigned)phx_div_up(m->nc, 256));
+  k_inner_cmap<<<gc, block, 0, m->stream>>>(m->nc, d, m->cells, m->v2lat, m->box_n[0], m->box_n[1], d == 3 ? m->box_n[2] : 1,
+                                            m->in_cmap, bad);
+  PHX_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  int64_t ncube = 1;
+  for (int a = 0; a < d; ++a) ncube *= m->box_n[a];
+  if (hbad || m->nc != ncube * (d == 3 ? 6 : 2)) {   // another triangulation of the lattice: the generic path serves it
+    PHX_HIP(phx_free(bad)); PHX_HIP(phx_free(m->in_cmap));
+    m->in_cmap = nullptr;
+    return PHX_OK;
+  }
+  phx_mesh *in = nullptr;
+  PHX_CHECK(phx_mesh_create_box(d, lo, hi, m->box_n, nullptr, nullptr, m->device, &in));
+  // one stream for both: the pushes of tags and nodal data and the kernels that read them stay ordered
+  PHX_HIP(hipStreamDestroy(in->stream));
+  in->stream = m->stream;
+  in->own_stream = false;
+  m->inner = in;
+  PHX_HIP(phx_malloc(&m->in_fmap, sizeof(int32_t) * (size_t)m->nf));
+  PHX_HIP(hipMemsetAsync(m->in_fmap, 0xff, sizeof(int32_t) * (size_t)m->nf, m->stream));
+  k_inner_fmap<<<gc, block, 0, m->stream>>>(m->nc, N, m->cells, m->c2f, m->v2lat, m->in_cmap, in->cells, in->c2f, m->in_fmap, bad);
+  PHX_HIP(hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(phx_free(bad));
+  if (hbad || in->nf != m->nf || in->nv != m->nv) {
+    phx_mesh_destroy(in);
+    m->inner = nullptr;
+    PHX_HIP(phx_free(m->in_cmap)); PHX_HIP(phx_free(m->in_fmap));
+    m->in_cmap = nullptr; m->in_fmap = nullptr;
+  }
+  return PHX_OK;
+}
 
 // coords / cells at `loc` (host arrays from a caller, or device arrays of a parent mesh: phx_submesh.hip).  The facet
 // numbering and both connectivities are built on the device (phx_topology.inc.hip); PHX_TOPOLOGY_HOST=1 takes the
@@ -479,8 +584,8 @@ int phx_mesh_create_from(int gdim, int cell_type, int64_t nv, const double *coor
   if (loc != PHX_DEVICE && (cell_type == PHX_TRIANGLE || cell_type == PHX_TETRAHEDRON)) {
     std::vector<int32_t> v2lat, lat2v;
     int64_t ln[3];
-    double lh[3];
-    if (detect_lattice(gdim, ci.nvpc, nv, coords, nc, cells, ln, lh, v2lat, lat2v)) {
+    double lh[3], llo[3] = {0, 0, 0}, lhi[3] = {0, 0, 0};
+    if (detect_lattice(gdim, ci.nvpc, nv, coords, nc, cells, ln, lh, v2lat, lat2v, llo, lhi)) {
       m->on_box_lattice = true;
       for (int a = 0; a < 3; ++a) { m->box_n[a] = ln[a]; m->box_h[a] = lh[a]; }
       if (phx_malloc(&m->v2lat, sizeof(int32_t) * (size_t)nv) != hipSuccess ||
@@ -489,6 +594,11 @@ int phx_mesh_create_from(int gdim, int cell_type, int64_t nv, const double *coor
           hipMemcpy(m->lat2v, lat2v.data(), sizeof(int32_t) * (size_t)nv, hipMemcpyHostToDevice) != hipSuccess) {
         phx_set_error("mesh upload failed");
         return fail(PHX_ERR_HIP);
+      }
+      static const bool no_inner = getenv("PHX_INNER_BOX") && atoi(getenv("PHX_INNER_BOX")) == 0;   // A/B aid
+      if (!no_inner) {
+        rc = mesh_attach_inner_box(m, llo, lhi);   // leaves m->inner == nullptr when the cells are not the Kuhn split
+        if (rc != PHX_OK) return fail(rc);
       }
     }
   }
@@ -873,6 +983,8 @@ extern "C" int phx_mesh_destroy(phx_mesh *m) {
   for (void *p : ptrs) (void)phx_free(p);
   free(m->c_map_h); free(m->v_map_h);
   (void)phx_free(m->v2lat); (void)phx_free(m->lat2v);
+  (void)phx_free(m->in_cmap); (void)phx_free(m->in_fmap);
+  if (m->inner) { phx_mesh_destroy(m->inner); m->inner = nullptr; }
   if (m->scal_h) (void)hipHostFree(m->scal_h);
   for (auto &pe : m->prof_ev) for (auto &e : pe) (void)hipEventDestroy(e);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -905,10 +1017,12 @@ extern "C" int phx_mesh_set_stream(phx_mesh *m, uint64_t stream) {
   if (m->own_stream) PHX_HIP(hipStreamDestroy(m->stream));
   m->stream = (hipStream_t)(uintptr_t)stream;
   m->own_stream = false;
+  if (m->inner) m->inner->stream = m->stream;   // (the inner box never owns a stream)
   return PHX_OK;
 }
 
 extern "C" int phx_set_option(phx_mesh *m, int option, int64_t value) {
+  if (m->inner) PHX_CHECK(phx_set_option(m->inner, option, value));
   switch (option) {
     case PHX_OPT_PROFILE_SPMV:
       PHX_REQUIRE(value >= 0 && value <= 1024, PHX_ERR_VALUE, "SpMV profiling stride out of range");
@@ -991,5 +1105,6 @@ extern "C" int phx_mesh_get_array(phx_mesh *m, int which, void *out, int loc) {
 
 extern "C" int phx_last_timings(const phx_mesh *m, double *t) {
   for (int i = 0; i < 8; ++i) t[i] = m->timings[i];
+  if (m->inner) for (int i = 2; i < 8; ++i) if (m->inner->timings[i] != 0.0) t[i] = m->inner->timings[i];   // assemble / solve ran there
   return PHX_OK;
 }

@@ -1313,12 +1313,15 @@ __global__ void k_gather(int64_t n, const int32_t *__restrict__ perm, const doub
 __global__ void k_scatter_solution(int64_t n, const int32_t *__restrict__ perm,
                                    const int64_t *__restrict__ full_of_active,
                                    const double *__restrict__ diag, const double *__restrict__ cscale,
-                                   const double *__restrict__ y, double *__restrict__ xfull) {
+                                   const double *__restrict__ y, double *__restrict__ xfull,
+                                   const int32_t *__restrict__ out_vertex, int64_t nent) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t r = perm[i];
+  int64_t f = full_of_active[r];
+  if (out_vertex) { const int64_t blk = f / nent; f = blk * nent + out_vertex[f - blk * nent]; }   // caller's numbering
   // x = S y: the column scaling folded into the stored values (1 / diag, or 1 for unscaled u columns)
-  xfull[full_of_active[r]] = cscale ? y[i] * cscale[i] : y[i] / diag[r];
+  xfull[f] = cscale ? y[i] * cscale[i] : y[i] / diag[r];
 }
 
 static inline dim3 vec_grid(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(phx_div_up(n, 256), 2048))); }
@@ -1678,7 +1681,7 @@ extern "C" int phx_krylov_finish(phx_system *s, double *x_out, int loc) {
   PHX_HIP(hipMemsetAsync(xfull, 0, sizeof(double) * (size_t)s->nfull, st));
   if (n > 0)
     k_scatter_solution<<<dim3((unsigned)phx_div_up(n, 256)), dim3(256), 0, st>>>(
-        n, s->perm, s->full_of_active, s->diag, s->cscale, V.y, xfull);
+        n, s->perm, s->full_of_active, s->diag, s->cscale, V.y, xfull, s->out_vertex, s->nent);
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(st));
   if (owned) {

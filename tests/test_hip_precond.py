@@ -169,8 +169,9 @@ def test_caller_supplied_lattice_mesh_gets_the_box_preconditioner(P, d, n):
     inv = np.empty_like(perm)
     inv[perm] = np.arange(perm.size)
     xs = x[perm]
-    cs = inv[cells][rng.permutation(cells.shape[0])].astype(np.int32)
-    mesh = P.Mesh.from_arrays("tetrahedron" if d == 3 else "triangle", xs, cs)
+    cs = inv[cells][rng.permutation(cells.shape[0])]
+    cs = np.take_along_axis(cs, rng.permuted(np.tile(np.arange(d + 1), (cs.shape[0], 1)), axis=1), axis=1).astype(np.int32)
+    mesh = P.Mesh.from_arrays("tetrahedron" if d == 3 else "triangle", xs, cs)   # any vertex, cell and local order
 
     def run(m, xx):
         phi = (xx ** 2).sum(axis=1) - 1.0
@@ -179,12 +180,19 @@ def test_caller_supplied_lattice_mesh_gets_the_box_preconditioner(P, d, n):
             warnings.simplefilter("ignore")
             P.compute_tags_measures(m, NodalFunction(phi), 1, box_mode=True, single_layer_cut=True)
         s = P.PhiFEMSolver(m)
-        s.assemble(phi, float(d) * uex, uex)
+        info = s.assemble(phi, float(d) * uex, uex)
         w = s.solve(rtol=1e-10, max_iter=20000)
-        return w, s.stats
+        # the exported system (lazy CSR) in the caller's numbering is satisfied by the returned solution
+        rowptr, col, val, rhs, dof = s.export_csr()
+        import scipy.sparse as sp
+        A = sp.csr_matrix((val, col, rowptr), shape=(rowptr.size - 1,) * 2)
+        assert np.linalg.norm(A @ w[dof] - rhs) <= 1e-8 * np.linalg.norm(rhs)
+        return w, dict(s.stats, **info)
     w_box, st_box = run(box, x)
     w_arr, st_arr = run(mesh, xs)
     assert st_box["precond"] == "box-dst" and st_arr["precond"] == "box-dst"
+    # the caller's mesh is served by the generated box behind it -- closed-form rows, stencil operator
+    assert st_arr["stencil_rows"] == st_box["stencil_rows"] > 0 and st_arr["n_active"] == st_box["n_active"]
     assert abs(st_arr["iterations"] - st_box["iterations"]) <= max(3, 0.15 * st_box["iterations"]), \
         (st_arr["iterations"], st_box["iterations"])
     nv = x.shape[0]

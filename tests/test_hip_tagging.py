@@ -343,6 +343,7 @@ def test_degree2_levelset_is_tabulated_on_the_device(P, ctype, n, deg):
         # the same values handed over from the host, as round 1 did
         staged = (P._lib.PHI_POINTS,) + P._lib.ptr(ref) + (ref,)
         warn = __import__("ctypes").c_int(0)
+        m._flush_lazy_tags()     # tags are about to change through the raw C ABI: MeshTags handed out keep their state
         P._lib.check(P._lib.lib.phx_tag_cells(m._h, staged[0], staged[1], staged[2], deg, 0, __import__("ctypes").byref(warn)))
         MS._tag_facets(m, staged, deg)
         c_host, f_host = m.cell_tag_values().copy(), m.facet_tag_values().copy()
