@@ -163,7 +163,14 @@ enum phx_option {
   PHX_OPT_STRUCTURED = 8, /* 1 (default): P1 weak-Dirichlet systems on Kuhn boxes apply their
                                translation-invariant interior rows from a 7-point stencil over runs of
                                consecutive rows (no stored columns or values); only the rows near Gamma_h keep
-                               SELL storage.  0: every row stored (SELL), as for all other systems           */
+                               SELL storage; P2 weak-Dirichlet systems on 3-D Kuhn boxes likewise (eight class
+                               stencils, interior rows never assembled).  0: every row stored (SELL)          */
+  PHX_OPT_DETERMINISTIC = 9, /* 1: bit-reproducible results for the scattering assemblies (P2 weak Dirichlet,
+                               interface elasticity) and the Krylov solve: the element kernels run twice and
+                               accumulate exactly (per-slot exponent, two accumulators), the dot products are
+                               summed in a fixed order.  Costs one more pass of the element kernels and 12 bytes
+                               per row slot while assembling (skipped beyond PHX_DET_LIMIT_GB, default 48).
+                               Default 0: f64 atomics in arrival order (results equal to round-off)           */
   PHX_OPT_ALLOW_EMPTY = 6, /* 1: phx_assemble_poisson_wd returns an EMPTY system (n_active = 0) when no cell
                                is tagged 1 / 2 instead of PHX_ERR_VALUE: a slab of a partitioned box that
                                does not touch the domain still joins every collective of the solve          */

@@ -73,7 +73,38 @@ struct Slots {
   // vertices): row r owns slots [off[r], off[r] + (1 << wlog[r])).  nullptr: every row has W slots.
   const int64_t *off = nullptr;
   const uint8_t *wlog = nullptr;
+  // Deterministic accumulation (PHX_OPT_DETERMINISTIC; P2 and elasticity assemblies): f64 atomics add in an order that
+  // changes from run to run, the last bits of the matrix with it, and BiCGStab amplifies them over hundreds of
+  // iterations (694-892 for the same P2 problem).  The element kernels then run TWICE: pass 1 records per slot the
+  // largest exponent among its contributions (integer atomicMax: order-free), pass 2 splits every contribution v into
+  // hi = v rounded to 2^(E-40) and lo = the rest rounded to 2^(E-81) and adds them to two accumulators -- sums of
+  // fewer than 2^11 such terms are EXACT in f64, so any order gives the same bits.  The slot value is hi + lo (one
+  // rounding; what is dropped is below 2^-81 of the largest contribution).  emax == nullptr: plain atomic adds.
+  int32_t *emax = nullptr;   // [slots]
+  double *lo = nullptr;      // [slots]
+  int32_t *remax = nullptr;  // [rows] the same for the right-hand side
+  double *rlo = nullptr;     // [rows]
+  int pass = 0;
 };
+
+__device__ __forceinline__ int det_expo(double v) { return (int)((__double_as_longlong(v) >> 52) & 0x7ff); }
+__device__ __forceinline__ void det_split(double v, int e, double &hi, double &lo) {
+  const int E = e - 1023;                       // every |contribution| < 2^(E+1)
+  hi = ldexp(rint(ldexp(v, 40 - E)), E - 40);
+  lo = ldexp(rint(ldexp(v - hi, 81 - E)), E - 81);
+}
+// accumulate v into acc[i] (plain atomics, or the two-pass exact scheme above)
+__device__ __forceinline__ void det_add(const Slots &s, double *acc, int32_t *emax, double *lo, int64_t i, double v) {
+  if (!emax) { unsafeAtomicAdd(&acc[i], v); return; }
+  if (s.pass == 1) { atomicMax(&emax[i], det_expo(v)); return; }
+  double hi, l;
+  det_split(v, emax[i], hi, l);
+  unsafeAtomicAdd(&acc[i], hi);
+  unsafeAtomicAdd(&lo[i], l);
+}
+__device__ __forceinline__ void slot_rhs_add(const Slots &s, double *rhs, int32_t row, double v) {
+  det_add(s, rhs, s.remax, s.rlo, row, v);
+}
 
 __device__ __forceinline__ int64_t slot_base(const Slots &s, int32_t row, int *W) {
   if (s.off) { *W = 1 << s.wlog[row]; return s.off[row]; }
@@ -101,7 +132,7 @@ __device__ __forceinline__ void slot_add(const Slots &s, int32_t row, int32_t co
       if (cur == -1) cur = col;
     }
     if (cur == col) {
-      unsafeAtomicAdd(&rv[k], v);
+      det_add(s, s.vals, s.emax, s.lo, base + k, v);
       return;
     }
   }
@@ -246,6 +277,7 @@ __global__ void k_v2c_fill(int64_t nc, int nvpc, const int32_t *__restrict__ cel
 
 // plain (non-atomic) insert into a row this thread owns exclusively; same hash as slot_add
 __device__ __forceinline__ void slot_add_owned(const Slots &s, int32_t row, int32_t col, double v) {
+  if (s.emax) { slot_add(s, row, col, v); return; }   // deterministic mode: a contribution like any other (both passes)
   int W;
   const int64_t base = slot_base(s, row, &W);
   int32_t *rc = s.cols + base;
@@ -881,6 +913,40 @@ __global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const in
     for (int b = 0; b < M; ++b) slot_add(A.slots, rows[a], vd[b], w * Jd[a] * Jd[b]);
 }
 
+// deterministic accumulation: value = hi + lo
+__global__ void k_det_finalize(int64_t n, double *__restrict__ acc, const double *__restrict__ lo) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) acc[i] += lo[i];
+}
+// second accumulators of PHX_OPT_DETERMINISTIC for `nslots` slots and `nrows` right-hand-side entries; false when the
+// extra 12 bytes per slot do not fit the budget (then the assembly keeps plain atomics)
+static int det_alloc(phx_mesh *m, Slots &sl, int64_t nslots, int64_t nrows, bool *on) {
+  *on = false;
+  if (!m->deterministic) return PHX_OK;
+  static const double limit_gb = getenv("PHX_DET_LIMIT_GB") ? atof(getenv("PHX_DET_LIMIT_GB")) : 48.0;
+  if (12.0 * (double)nslots > limit_gb * 1073741824.0) return PHX_OK;
+  PHX_HIP(phx_malloc(&sl.emax, sizeof(int32_t) * (size_t)nslots));
+  PHX_HIP(phx_malloc(&sl.lo, sizeof(double) * (size_t)nslots));
+  PHX_HIP(phx_malloc(&sl.remax, sizeof(int32_t) * (size_t)nrows));
+  PHX_HIP(phx_malloc(&sl.rlo, sizeof(double) * (size_t)nrows));
+  PHX_HIP(hipMemsetAsync(sl.emax, 0, sizeof(int32_t) * (size_t)nslots, m->stream));
+  PHX_HIP(hipMemsetAsync(sl.lo, 0, sizeof(double) * (size_t)nslots, m->stream));
+  PHX_HIP(hipMemsetAsync(sl.remax, 0, sizeof(int32_t) * (size_t)nrows, m->stream));
+  PHX_HIP(hipMemsetAsync(sl.rlo, 0, sizeof(double) * (size_t)nrows, m->stream));
+  *on = true;
+  return PHX_OK;
+}
+static int det_finish(phx_mesh *m, Slots &sl, int64_t nslots, int64_t nrows, double *rhs) {
+  if (!sl.emax) return PHX_OK;
+  k_det_finalize<<<dim3((unsigned)phx_div_up(nslots, 256)), dim3(256), 0, m->stream>>>(nslots, sl.vals, sl.lo);
+  k_det_finalize<<<dim3((unsigned)phx_div_up(nrows, 256)), dim3(256), 0, m->stream>>>(nrows, rhs, sl.rlo);
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipStreamSynchronize(m->stream));
+  PHX_HIP(phx_free(sl.emax)); PHX_HIP(phx_free(sl.lo)); PHX_HIP(phx_free(sl.remax)); PHX_HIP(phx_free(sl.rlo));
+  sl.emax = nullptr; sl.lo = nullptr; sl.remax = nullptr; sl.rlo = nullptr;
+  return PHX_OK;
+}
+
 template <typename Pred>
 static int build_list(phx_mesh *m, int64_t n, Pred pred, int32_t **list, int64_t *count) {
   return phx_select_indices(m->stream, n, pred, list, count);
@@ -1127,7 +1193,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
   void *ptrs[] = {s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active, s->rowptr, s->col,
                   s->val, s->rhs, s->diag, s->slice_ptr, s->sell_col, s->sell_val,
                   s->sell_val_raw, s->sell_kind, s->perm, s->iperm, s->work, s->scal, s->row_nz,
-                  s->c0, s->stencil, s->seg, s->slice_seg, s->sell_rows, s->cscale, s->pvec, s->bnd, s->bnd_rec};
+                  s->c0, s->stencil, s->seg, s->slice_seg, s->sell_rows, s->cscale, s->pvec, s->bnd, s->bnd_rec, s->dpart};
   for (void *p : ptrs) (void)phx_free(p);
   if (s->p2s) {
     (void)phx_free(s->p2s->coef); (void)phx_free(s->p2s->mask); (void)phx_free(s->p2s->runs);

@@ -56,7 +56,7 @@ template <int D>
 __device__ __forceinline__ void el_add(const ElArgs &A, int32_t row_full, int32_t col_full, double v) {
   const bool rbc = el_is_bc(A, row_full, D), cbc = el_is_bc(A, col_full, D);
   if (cbc) {
-    if (!rbc) unsafeAtomicAdd(&A.rhs[A.dofmap[row_full]], -v * A.ud[col_full]);
+    if (!rbc) slot_rhs_add(A.slots, A.rhs, A.dofmap[row_full], -v * A.ud[col_full]);
     return;
   }
   if (rbc) return;
@@ -65,7 +65,7 @@ __device__ __forceinline__ void el_add(const ElArgs &A, int32_t row_full, int32_
 template <int D>
 __device__ __forceinline__ void el_rhs(const ElArgs &A, int32_t row_full, double v) {
   if (el_is_bc(A, row_full, D)) return;
-  unsafeAtomicAdd(&A.rhs[A.dofmap[row_full]], v);
+  slot_rhs_add(A.slots, A.rhs, A.dofmap[row_full], v);
 }
 
 template <int D>
@@ -253,7 +253,8 @@ k_el_bulk_box(int64_t nthreads, BoxDims bd, const uint8_t *__restrict__ touched,
     }
   }
   if (clean) A.slots.clean[row] = (uint8_t)cnt;
-  A.rhs[row] += rhs;
+  if (A.slots.remax) slot_rhs_add(A.slots, A.rhs, row, rhs);   // deterministic mode: a contribution like the scattered ones
+  else A.rhs[row] += rhs;
 }
 
 // --- cut cells: penalization main.py:188-203, cell stabilisation :211-217, rhs :255-260 ------------
@@ -548,33 +549,42 @@ static int assemble_el_with_capacity(phx_mesh *m, const double *params, const do
     } while (0)
     if (D == 2) PHX_MARK(3); else PHX_MARK(4);
 #undef PHX_MARK
-    A.slots = sl;
-    const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}, {m->box_h[0], m->box_h[1], m->box_h[2]}};
-    const int64_t nthreads = 2 * (int64_t)D * m->nv;
-    const dim3 g((unsigned)phx_div_up(nthreads, 256));
-    if (D == 2) k_el_bulk_box<2><<<g, block, 0, m->stream>>>(nthreads, bd, touched, A);
-    else k_el_bulk_box<3><<<g, block, 0, m->stream>>>(nthreads, bd, touched, A);
   }
   if (!m->is_box) PHX_REQUIRE_GRID(m->nc * 256, "elasticity bulk assembly");
   PHX_REQUIRE_GRID(n_cut * 256, "elasticity cut-cell assembly");
-  if (D == 2) {
-    if (!m->is_box) k_el_bulk<2><<<dim3((unsigned)m->nc), block, 0, m->stream>>>(m->nc, A);
-    if (n_cut) k_el_cut<2><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, A);
-    for (int sd = 0; sd < 2; ++sd)
-      if (m->ent_count[sd]) k_el_ds<2><<<dim3((unsigned)m->ent_count[sd]), block, 0, m->stream>>>(m->ent_count[sd], m->ent_buf[sd], sd, A);
-    if (n_f3) k_el_facets<2><<<dim3((unsigned)n_f3), block, 0, m->stream>>>(n_f3, l_f3, 0, A);
-    if (n_f4) k_el_facets<2><<<dim3((unsigned)n_f4), block, 0, m->stream>>>(n_f4, l_f4, 1, A);
-  } else {
-    if (!m->is_box) k_el_bulk<3><<<dim3((unsigned)m->nc), block, 0, m->stream>>>(m->nc, A);
-    if (n_cut) k_el_cut<3><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, A);
-    for (int sd = 0; sd < 2; ++sd)
-      if (m->ent_count[sd]) k_el_ds<3><<<dim3((unsigned)m->ent_count[sd]), block, 0, m->stream>>>(m->ent_count[sd], m->ent_buf[sd], sd, A);
-    if (n_f3) k_el_facets<3><<<dim3((unsigned)n_f3), block, 0, m->stream>>>(n_f3, l_f3, 0, A);
-    if (n_f4) k_el_facets<3><<<dim3((unsigned)n_f4), block, 0, m->stream>>>(n_f4, l_f4, 1, A);
+  // PHX_OPT_DETERMINISTIC: every kernel that adds into the slots or the right-hand side runs twice (Slots)
+  bool det = false;
+  PHX_CHECK(det_alloc(m, sl, total_slots, n, &det));
+  for (int pass = det ? 1 : 0; pass <= (det ? 2 : 0); ++pass) {
+    sl.pass = pass;
+    A.slots = sl;
+    if (m->is_box) {
+      const BoxDims bd{{m->box_n[0], m->box_n[1], m->box_n[2]}, {m->box_h[0], m->box_h[1], m->box_h[2]}};
+      const int64_t nthreads = 2 * (int64_t)D * m->nv;
+      const dim3 g((unsigned)phx_div_up(nthreads, 256));
+      if (D == 2) k_el_bulk_box<2><<<g, block, 0, m->stream>>>(nthreads, bd, touched, A);
+      else k_el_bulk_box<3><<<g, block, 0, m->stream>>>(nthreads, bd, touched, A);
+    }
+    if (D == 2) {
+      if (!m->is_box) k_el_bulk<2><<<dim3((unsigned)m->nc), block, 0, m->stream>>>(m->nc, A);
+      if (n_cut) k_el_cut<2><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, A);
+      for (int sd = 0; sd < 2; ++sd)
+        if (m->ent_count[sd]) k_el_ds<2><<<dim3((unsigned)m->ent_count[sd]), block, 0, m->stream>>>(m->ent_count[sd], m->ent_buf[sd], sd, A);
+      if (n_f3) k_el_facets<2><<<dim3((unsigned)n_f3), block, 0, m->stream>>>(n_f3, l_f3, 0, A);
+      if (n_f4) k_el_facets<2><<<dim3((unsigned)n_f4), block, 0, m->stream>>>(n_f4, l_f4, 1, A);
+    } else {
+      if (!m->is_box) k_el_bulk<3><<<dim3((unsigned)m->nc), block, 0, m->stream>>>(m->nc, A);
+      if (n_cut) k_el_cut<3><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, A);
+      for (int sd = 0; sd < 2; ++sd)
+        if (m->ent_count[sd]) k_el_ds<3><<<dim3((unsigned)m->ent_count[sd]), block, 0, m->stream>>>(m->ent_count[sd], m->ent_buf[sd], sd, A);
+      if (n_f3) k_el_facets<3><<<dim3((unsigned)n_f3), block, 0, m->stream>>>(n_f3, l_f3, 0, A);
+      if (n_f4) k_el_facets<3><<<dim3((unsigned)n_f4), block, 0, m->stream>>>(n_f4, l_f4, 1, A);
+    }
+    PHX_HIP(hipGetLastError());
+    if (nbc > 0) k_el_bc_rows<<<dim3((unsigned)phx_div_up(nbc * D, 256)), block, 0, m->stream>>>(nbc, D, A, dbcv);
+    PHX_HIP(hipGetLastError());
   }
-  PHX_HIP(hipGetLastError());
-  if (nbc > 0) k_el_bc_rows<<<dim3((unsigned)phx_div_up(nbc * D, 256)), block, 0, m->stream>>>(nbc, D, A, dbcv);
-  PHX_HIP(hipGetLastError());
+  PHX_CHECK(det_finish(m, sl, total_slots, n, s->rhs));
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_f3)); PHX_HIP(phx_free(l_f4)); PHX_HIP(phx_free(bc));
   PHX_HIP(phx_free(touched));

@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) k_p2_cells(int64_t nlist, const int32_t *
   const int32_t row = P.A.du[dof[r]];
   if (p2_row_skipped(P, row)) return;
   slot_add(P.A.slots, row, dof[s], acc * G.vol);
-  if (s == 0) unsafeAtomicAdd(&P.A.rhs[row], rhs * G.vol);
+  if (s == 0) slot_rhs_add(P.A.slots, P.A.rhs, row, rhs * G.vol);
 }
 
 // --- dx(2): penalisation main.py:115-122,144-149 and div(grad) terms :123-128,150 -----------------
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) k_p2_cut(int64_t nlist, const int32_t *__
     if (!ap) rv = gam * h1 * h1 * acc - P.A.sigma * G.h * G.h * G.vol * fbar * B::lapl(r, GG);   // :147 (v), :150
     else rv = -gam * h1 * h1 * h1 * acc;                                                          // :147 (q)
     const int32_t rrow = ap ? P.A.dp[dof[r]] : P.A.du[dof[r]];
-    if (!p2_row_skipped(P, rrow)) unsafeAtomicAdd(&P.A.rhs[rrow], rv);
+    if (!p2_row_skipped(P, rrow)) slot_rhs_add(P.A.slots, P.A.rhs, rrow, rv);
   }
 }
 
@@ -495,29 +495,38 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
     PHX_HIP(hipMemsetAsync(sl.overflow, 0, sizeof(int), m->stream));
     PHX_CHECK(build_list(m, m->nc, SelOmega{m->cell_tags}, &l_om, &n_om));
   }
-  P.A.slots = sl;
-  if (n_om > 0) {
-    PHX_REQUIRE_GRID(n_om * (D == 2 ? 64 : 128), "P2 cell assembly");
-    if (D == 2) k_p2_cells<2, 64><<<dim3((unsigned)phx_div_up(n_om * 64, 256)), block, 0, m->stream>>>(n_om, l_om, P);
-    else k_p2_cells<3, 128><<<dim3((unsigned)phx_div_up(n_om * 128, 256)), block, 0, m->stream>>>(n_om, l_om, P);
-  }
-  if (n_cut > 0) {
-    if (D == 2) k_p2_cut<2><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, P);
-    else k_p2_cut<3><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, P);
-  }
-  PHX_HIP(hipGetLastError());
+  // PHX_OPT_DETERMINISTIC: the element kernels run twice (exponent pass, exact accumulation pass; Slots)
+  const int64_t nslots = structured ? prep.slot_rows * (int64_t)W + 64 : s->n * (int64_t)W;
+  bool det = false;
+  PHX_CHECK(det_alloc(m, sl, nslots, s->n, &det));
   const int64_t nds = m->is_submesh ? m->nbf : (phx_collect_entities(m) == PHX_OK ? m->ent_count[0] : -1);
   PHX_REQUIRE(nds >= 0, PHX_ERR_VALUE, "integration entities unavailable");
-  if (nds > 0) {
-    const int64_t *pk = m->is_submesh ? nullptr : m->ent_buf[0];
-    const int32_t *pr = m->is_submesh ? m->bfacets : nullptr;
-    if (D == 2) k_p2_ds<2, 64><<<dim3((unsigned)phx_div_up(nds * 64, 256)), block, 0, m->stream>>>(nds, pk, pr, P);
-    else k_p2_ds<3, 128><<<dim3((unsigned)phx_div_up(nds * 128, 256)), block, 0, m->stream>>>(nds, pk, pr, P);
+  for (int pass = det ? 1 : 0; pass <= (det ? 2 : 0); ++pass) {
+    sl.pass = pass;
+    P.A.slots = sl;
+    if (n_om > 0) {
+      PHX_REQUIRE_GRID(n_om * (D == 2 ? 64 : 128), "P2 cell assembly");
+      if (D == 2) k_p2_cells<2, 64><<<dim3((unsigned)phx_div_up(n_om * 64, 256)), block, 0, m->stream>>>(n_om, l_om, P);
+      else k_p2_cells<3, 128><<<dim3((unsigned)phx_div_up(n_om * 128, 256)), block, 0, m->stream>>>(n_om, l_om, P);
+    }
+    if (n_cut > 0) {
+      if (D == 2) k_p2_cut<2><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, P);
+      else k_p2_cut<3><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, P);
+    }
+    PHX_HIP(hipGetLastError());
+    if (nds > 0) {
+      const int64_t *pk = m->is_submesh ? nullptr : m->ent_buf[0];
+      const int32_t *pr = m->is_submesh ? m->bfacets : nullptr;
+      if (D == 2) k_p2_ds<2, 64><<<dim3((unsigned)phx_div_up(nds * 64, 256)), block, 0, m->stream>>>(nds, pk, pr, P);
+      else k_p2_ds<3, 128><<<dim3((unsigned)phx_div_up(nds * 128, 256)), block, 0, m->stream>>>(nds, pk, pr, P);
+    }
+    if (n_fac > 0) {
+      if (D == 2) k_p2_facets<2><<<dim3((unsigned)n_fac), block, 0, m->stream>>>(n_fac, l_fac, P);
+      else k_p2_facets<3><<<dim3((unsigned)n_fac), block, 0, m->stream>>>(n_fac, l_fac, P);
+    }
+    PHX_HIP(hipGetLastError());
   }
-  if (n_fac > 0) {
-    if (D == 2) k_p2_facets<2><<<dim3((unsigned)n_fac), block, 0, m->stream>>>(n_fac, l_fac, P);
-    else k_p2_facets<3><<<dim3((unsigned)n_fac), block, 0, m->stream>>>(n_fac, l_fac, P);
-  }
+  PHX_CHECK(det_finish(m, sl, nslots, s->n, s->rhs));
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(l_om)); PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_fac));

@@ -137,6 +137,7 @@ struct phx_mesh {
   int export_csr = 0;              // PHX_OPT_EXPORT_CSR: assembly also builds the CSR copy phx_system_export reads
   int structured = 1;              // PHX_OPT_STRUCTURED: stencil-coded interior rows on Kuhn boxes (P1 weak Dirichlet)
   int allow_empty = 0;             // PHX_OPT_ALLOW_EMPTY: assembly returns an EMPTY system when no cell is tagged 1 / 2
+  int deterministic = 0;           // PHX_OPT_DETERMINISTIC: bit-reproducible P2 / elasticity assembly and Krylov dot products
   // A caller-supplied mesh that IS a Kuhn box in some vertex / cell order (what dolfinx's create_box / create_rectangle
   // hand over, demo/weak-dirichlet/flower/main.py:45-46): `inner` is the generated box with the same lattice, the maps
   // translate.  Tags are computed on THIS mesh (caller numbering, bit-exact as before); the P1 weak-Dirichlet assembly
@@ -265,6 +266,10 @@ struct phx_system {
   int32_t *bnd_rec = nullptr;      // [nbnd][6] {row, kind (0 stencil / 1 SELL-16 / 2 SELL-64), 4 kind-specific ints}
   int64_t nbnd = 0;
   phx_p2_struct *p2s = nullptr;    // structured P2 system (3-D Kuhn boxes), else nullptr
+  // PHX_OPT_DETERMINISTIC: every block of a dot-product kernel leaves its partial sum in its own entry of `dpart`
+  // ([2][dpart_cap]) instead of adding it to a slot atomically; k_fold_partials sums them in a fixed order
+  double *dpart = nullptr;
+  int64_t dpart_cap = 0, dpart_used = 0;
   // system assembled on the `inner` box of a caller-supplied mesh: vertex of s->mesh -> vertex of the caller's mesh
   // (applied where full DoF indices leave the library: the solution vector, phx_system_export's dof map)
   const int32_t *out_vertex = nullptr;

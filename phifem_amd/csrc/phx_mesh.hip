@@ -1033,6 +1033,7 @@ extern "C" int phx_set_option(phx_mesh *m, int option, int64_t value) {
     case PHX_OPT_ALLOW_EMPTY: m->allow_empty = value != 0; return PHX_OK;
     case PHX_OPT_EXPORT_CSR: m->export_csr = value != 0; return PHX_OK;
     case PHX_OPT_STRUCTURED: m->structured = value != 0; return PHX_OK;
+    case PHX_OPT_DETERMINISTIC: m->deterministic = value != 0; return PHX_OK;
     case PHX_OPT_PRECOND:
       PHX_REQUIRE(value >= 0 && value <= 2, PHX_ERR_VALUE, "unknown preconditioner %lld", (long long)value);
       m->precond = (int)value;

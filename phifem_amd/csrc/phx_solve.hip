@@ -749,6 +749,28 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// PHX_OPT_DETERMINISTIC: where the blocks of a dot-product kernel leave their partial sums (p0 == nullptr: atomics)
+struct DotPart { double *p0, *p1; };
+// fixed-order sum of nb partials per quantity into slot 0 of its slot set (the other slots stay zero: no atomics ran)
+__global__ void __launch_bounds__(256) k_fold_partials(int64_t nb, DotPart part, double *out0, double *out1) {
+  __shared__ double red[256];
+  for (int q = 0; q < 2; ++q) {
+    const double *p = q == 0 ? part.p0 : part.p1;
+    double *out = q == 0 ? out0 : out1;
+    if (!p || !out) continue;
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < nb; i += 256) a += p[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+    __syncthreads();
+  }
+}
+
 struct StencilArgs {
   int64_t nu;             // solver positions the stencil slices cover (the C0 rows)
   const int32_t *seg;     // [nseg][6]
@@ -766,7 +788,7 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
             const uint8_t *__restrict__ own, const double *__restrict__ d0,
             double *__restrict__ out0, double *__restrict__ out1, int xcd_group,
             const uint8_t *__restrict__ kind, const int32_t *__restrict__ rows, int64_t nb_sell, StencilArgs sa,
-            const uint8_t *__restrict__ bnd) {
+            const uint8_t *__restrict__ bnd, DotPart part) {
   // bnd (nullable, multi-GPU): rows flagged here reference halo entries that are still in flight; this launch
   // leaves them (no store, no dot-product share) to k_spmv_bnd, which runs after the halo has been unpacked
   __shared__ double vi_dict[4][VI_MAX];
@@ -978,9 +1000,15 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
     if (lane == 0) { red[0][w] = p0; red[1][w] = p1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int slot = (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE;
-      unsafeAtomicAdd(out0 + slot, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-      if (DOTS > 1) unsafeAtomicAdd(out1 + slot, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+      const double s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3], s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      if (part.p0) {   // PHX_OPT_DETERMINISTIC: one entry per block, summed in a fixed order by k_fold_partials
+        part.p0[blockIdx.x] = s0;
+        if (DOTS > 1) part.p1[blockIdx.x] = s1;
+      } else {
+        const int slot = (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE;
+        unsafeAtomicAdd(out0 + slot, s0);
+        if (DOTS > 1) unsafeAtomicAdd(out1 + slot, s1);
+      }
     }
   }
 }
@@ -1061,7 +1089,7 @@ __global__ void __launch_bounds__(256)
 k_spmv_bnd(int64_t nrec, const int32_t *__restrict__ rec, const int64_t *__restrict__ slice_ptr,
            const int32_t *__restrict__ scol, const double *__restrict__ sval, const uint8_t *__restrict__ kind,
            const double *__restrict__ st, const double *__restrict__ x, double *__restrict__ y,
-           const double *__restrict__ d0, double *__restrict__ out0, double *__restrict__ out1) {
+           const double *__restrict__ d0, double *__restrict__ out0, double *__restrict__ out1, DotPart part) {
   double p0 = 0.0, p1 = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nrec; i += (int64_t)gridDim.x * blockDim.x) {
     const int32_t *q = rec + 6 * i;
@@ -1106,9 +1134,15 @@ k_spmv_bnd(int64_t nrec, const int32_t *__restrict__ rec, const int64_t *__restr
     if ((threadIdx.x & 63) == 0) { red[0][w] = p0; red[1][w] = p1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int slot = (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE;
-      unsafeAtomicAdd(out0 + slot, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-      if (DOTS > 1) unsafeAtomicAdd(out1 + slot, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+      const double s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3], s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      if (part.p0) {   // PHX_OPT_DETERMINISTIC: one entry per block, summed in a fixed order by k_fold_partials
+        part.p0[blockIdx.x] = s0;
+        if (DOTS > 1) part.p1[blockIdx.x] = s1;
+      } else {
+        const int slot = (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE;
+        unsafeAtomicAdd(out0 + slot, s0);
+        if (DOTS > 1) unsafeAtomicAdd(out1 + slot, s1);
+      }
     }
   }
 }
@@ -1136,13 +1170,15 @@ __host__ __device__ __forceinline__ double *slot_base(double *S, int par, int q)
   return S + P_OFF + ((par * 8 + q) * NSLOT) * SLOT_STRIDE;
 }
 
-__device__ __forceinline__ void block_atomic_sum(double v, double *out) {
+__device__ __forceinline__ void block_atomic_sum(double v, double *out, double *part = nullptr) {
   __shared__ double red[4];
   v = wave_sum(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0)
-    unsafeAtomicAdd(out + (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    if (part) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];   // PHX_OPT_DETERMINISTIC
+    else unsafeAtomicAdd(out + (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE, red[0] + red[1] + red[2] + red[3]);
+  }
   __syncthreads();
 }
 
@@ -1188,7 +1224,7 @@ __global__ void __launch_bounds__(256)
 k_kr_begin(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ rhs,
            const uint8_t *__restrict__ own, double *__restrict__ b, double *__restrict__ r,
            double *__restrict__ rhat, double *__restrict__ p, double *__restrict__ y,
-           double *__restrict__ S, RestOut ro) {
+           double *__restrict__ S, RestOut ro, DotPart part) {
   double acc = 0.0;
   GRID_STRIDE(i, n) {
     const bool mine = !own || own[i];
@@ -1197,7 +1233,7 @@ k_kr_begin(int64_t n, const int32_t *__restrict__ perm, const double *__restrict
     ro.put(i, bi);
     acc += bi * bi;
   }
-  block_atomic_sum(acc, slot_base(S, 0, R_RHO));
+  block_atomic_sum(acc, slot_base(S, 0, R_RHO), part.p0);
 }
 
 // Multi-GPU: the preconditioner must be chosen by ALL ranks together.  Phase 0 leaves this rank's veto (1: the
@@ -1236,7 +1272,7 @@ __global__ void __launch_bounds__(256)
 k_update_xr(int64_t n, int par, const uint8_t *__restrict__ own, const double *__restrict__ phat,
             const double *__restrict__ shat, const double *__restrict__ sv, const double *__restrict__ t,
             const double *__restrict__ rhat, double *__restrict__ x, double *__restrict__ r,
-            double *__restrict__ S) {
+            double *__restrict__ S, DotPart part) {
   const double alpha = S[S_ALPHA];
   const double omega = dotv(S, par, R_TS) / dotv(S, par, R_TT);
   double a0 = 0.0, a1 = 0.0;
@@ -1252,8 +1288,8 @@ k_update_xr(int64_t n, int par, const uint8_t *__restrict__ own, const double *_
     a0 += rhat[i] * ri;
     a1 += ri * ri;
   }
-  block_atomic_sum(a0, slot_base(S, par, R_RHO));
-  block_atomic_sum(a1, slot_base(S, par, R_RR));
+  block_atomic_sum(a0, slot_base(S, par, R_RHO), part.p0);
+  block_atomic_sum(a1, slot_base(S, par, R_RR), part.p1);
   if (blockIdx.x == 0 && threadIdx.x == 0) S[S_OMEGA] = omega;
 }
 
@@ -1326,6 +1362,31 @@ __global__ void k_scatter_solution(int64_t n, const int32_t *__restrict__ perm,
 
 static inline dim3 vec_grid(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(phx_div_up(n, 256), 2048))); }
 
+// PHX_OPT_DETERMINISTIC: `nb` entries per quantity for the blocks of the next dot-product launch, behind the ones handed
+// out since the last fold (a product may take several launches: SELL + stencil blocks, interior + halo rows)
+static int det_part(phx_system *s, int64_t nb, DotPart *out) {
+  out->p0 = out->p1 = nullptr;
+  if (!s->mesh->deterministic) return PHX_OK;
+  if (!s->dpart) {
+    s->dpart_cap = phx_div_up(s->nslices, 4) + phx_div_up(s->nstencil_pos, 1024) + 16384;
+    PHX_HIP(phx_malloc(&s->dpart, sizeof(double) * 2 * (size_t)s->dpart_cap));
+    s->dpart_used = 0;
+  }
+  PHX_REQUIRE(s->dpart_used + nb <= s->dpart_cap, PHX_ERR_HIP, "deterministic dot products: %lld partial sums exceed the buffer",
+              (long long)(s->dpart_used + nb));
+  out->p0 = s->dpart + s->dpart_used;
+  out->p1 = s->dpart + s->dpart_cap + s->dpart_used;
+  s->dpart_used += nb;
+  return PHX_OK;
+}
+static int det_fold(phx_system *s, double *out0, double *out1) {
+  if (!s->mesh->deterministic || s->dpart_used == 0) return PHX_OK;
+  k_fold_partials<<<1, 256, 0, s->mesh->stream>>>(s->dpart_used, DotPart{s->dpart, s->dpart + s->dpart_cap}, out0, out1);
+  PHX_HIP(hipGetLastError());
+  s->dpart_used = 0;
+  return PHX_OK;
+}
+
 // part 0: every row.  Multi-GPU overlap (s->bnd set by phx_spmv_flag_rows): part 1 = every row that references no halo
 // entry (runs while the halo is in flight), part 2 = the flagged rows (after the unpack); both add into the same slots.
 static int launch_spmv(phx_system *s, const double *vals, const double *x, double *y, int dots,
@@ -1337,13 +1398,17 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   const int xg = s->mesh->spmv_xcd_group;
   const uint8_t *kinds = vals == s->sell_val ? s->sell_kind : s->sell_kind_raw;
   const int32_t *rows = s->structured ? s->sell_rows : nullptr;
+  DotPart dp{nullptr, nullptr};
   if (part_of == 2) {
-    if (s->nbnd == 0) return PHX_OK;
-    const dim3 gb((unsigned)std::min<int64_t>(phx_div_up(s->nbnd, 256), 2048));
-    if (dots == 0) k_spmv_bnd<0><<<gb, block, 0, st>>>(s->nbnd, s->bnd_rec, s->slice_ptr, s->sell_col, vals, kinds, s->stencil, x, y, d0, o0, o1);
-    else if (dots == 1) k_spmv_bnd<1><<<gb, block, 0, st>>>(s->nbnd, s->bnd_rec, s->slice_ptr, s->sell_col, vals, kinds, s->stencil, x, y, d0, o0, o1);
-    else k_spmv_bnd<2><<<gb, block, 0, st>>>(s->nbnd, s->bnd_rec, s->slice_ptr, s->sell_col, vals, kinds, s->stencil, x, y, d0, o0, o1);
-    PHX_HIP(hipGetLastError());
+    if (s->nbnd > 0) {
+      const dim3 gb((unsigned)std::min<int64_t>(phx_div_up(s->nbnd, 256), 2048));
+      if (dots > 0) PHX_CHECK(det_part(s, gb.x, &dp));
+      if (dots == 0) k_spmv_bnd<0><<<gb, block, 0, st>>>(s->nbnd, s->bnd_rec, s->slice_ptr, s->sell_col, vals, kinds, s->stencil, x, y, d0, o0, o1, dp);
+      else if (dots == 1) k_spmv_bnd<1><<<gb, block, 0, st>>>(s->nbnd, s->bnd_rec, s->slice_ptr, s->sell_col, vals, kinds, s->stencil, x, y, d0, o0, o1, dp);
+      else k_spmv_bnd<2><<<gb, block, 0, st>>>(s->nbnd, s->bnd_rec, s->slice_ptr, s->sell_col, vals, kinds, s->stencil, x, y, d0, o0, o1, dp);
+      PHX_HIP(hipGetLastError());
+    }
+    if (dots > 0) PHX_CHECK(det_fold(s, o0, o1));   // ... together with the partial sums of the interior launch
     return PHX_OK;
   }
   const uint8_t *bnd = part_of == 1 ? s->bnd : nullptr;
@@ -1365,23 +1430,27 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   }
   if (nb == 0 && !s->p2s) return PHX_OK;
   const dim3 g2((unsigned)std::max<int64_t>(nb, 1));
+  if (dots > 0 && nb > 0) PHX_CHECK(det_part(s, nb, &dp));
   if (nb == 0) {}
   else if (dots == 0)
-    k_spmv_sell<0><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd);
+    k_spmv_sell<0><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd, dp);
   else if (dots == 1)
-    k_spmv_sell<1><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd);
+    k_spmv_sell<1><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd, dp);
   else
-    k_spmv_sell<2><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd);
+    k_spmv_sell<2><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd, dp);
   PHX_HIP(hipGetLastError());
   if (s->p2s && s->p2s->nrun > 0 && part_of == 0 && part != 1) {
     // structured P2: the interior rows from the eight class stencils, one wavefront per run
     const phx_p2_struct *ps = s->p2s;
     const dim3 gp((unsigned)std::min<int64_t>(phx_div_up(ps->nrun, 4), 4096));
-    if (dots == 0) k_spmv_p2s<0><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->tabE, ps->tabO, ps->linemask, x, y, d0, o0, o1);
-    else if (dots == 1) k_spmv_p2s<1><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->tabE, ps->tabO, ps->linemask, x, y, d0, o0, o1);
-    else k_spmv_p2s<2><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->tabE, ps->tabO, ps->linemask, x, y, d0, o0, o1);
+    DotPart dq{nullptr, nullptr};
+    if (dots > 0) PHX_CHECK(det_part(s, gp.x, &dq));
+    if (dots == 0) k_spmv_p2s<0><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->tabE, ps->tabO, ps->linemask, x, y, d0, o0, o1, dq);
+    else if (dots == 1) k_spmv_p2s<1><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->tabE, ps->tabO, ps->linemask, x, y, d0, o0, o1, dq);
+    else k_spmv_p2s<2><<<gp, block, 0, st>>>(ps->nrun, ps->runs, ps->tabE, ps->tabO, ps->linemask, x, y, d0, o0, o1, dq);
     PHX_HIP(hipGetLastError());
   }
+  if (dots > 0 && part_of == 0) PHX_CHECK(det_fold(s, o0, o1));
   return PHX_OK;
 }
 
@@ -1510,14 +1579,14 @@ __global__ void k_jacobi_u(int64_t n, int64_t nu, const int32_t *__restrict__ pe
 // r = own ? b - t : 0 (t = A y, the TRUE residual of the accumulated iterate); (r, r) into slot set 0
 __global__ void __launch_bounds__(256)
 k_true_residual(int64_t n, const uint8_t *__restrict__ own, const double *__restrict__ b,
-                const double *__restrict__ t, double *__restrict__ r, double *__restrict__ S) {
+                const double *__restrict__ t, double *__restrict__ r, double *__restrict__ S, DotPart part) {
   double acc = 0.0;
   GRID_STRIDE(i, n) {
     const double ri = (!own || own[i]) ? b[i] - t[i] : 0.0;
     r[i] = ri;
     acc += ri * ri;
   }
-  block_atomic_sum(acc, slot_base(S, 0, R_RR));
+  block_atomic_sum(acc, slot_base(S, 0, R_RR), part.p0);
 }
 
 // restart of the recurrences from r (x keeps its value): rhat = p = r, rho = (r, r) = S[R_OFF + R_RR]
@@ -1581,7 +1650,12 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
   switch (phase) {
     case 0:
       PHX_HIP(hipMemsetAsync(S, 0, sizeof(double) * PHX_SCAL_DOUBLES, st));
-      k_kr_begin<<<vec_grid(n), block, 0, st>>>(n, s->perm, s->rhs, s->own, V.b, V.r, V.rhat, V.p, V.y, S, rop);
+      {
+        DotPart dp{nullptr, nullptr};
+        PHX_CHECK(det_part(s, vec_grid(n).x, &dp));
+        k_kr_begin<<<vec_grid(n), block, 0, st>>>(n, s->perm, s->rhs, s->own, V.b, V.r, V.rhat, V.p, V.y, S, rop, dp);
+        PHX_CHECK(det_fold(s, slot_base(S, 0, R_RHO), nullptr));
+      }
       k_reduce_slots<<<1, 64, 0, st>>>(S, 0, R_RHO, 1, 1);
       if (mode) k_set_scalar<<<1, 1, 0, st>>>(S + R_OFF + R_RR, s->precond_veto ? 1.0 : 0.0);
       break;
@@ -1604,7 +1678,12 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_TS, 2, 1);
       break;
     case 5:
-      k_update_xr<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.phat, V.shat, V.sv, V.t, V.rhat, V.y, V.r, S);
+      {
+        DotPart dp{nullptr, nullptr};
+        PHX_CHECK(det_part(s, vec_grid(n).x, &dp));
+        k_update_xr<<<vec_grid(n), block, 0, st>>>(n, par, s->own, V.phat, V.shat, V.sv, V.t, V.rhat, V.y, V.r, S, dp);
+        PHX_CHECK(det_fold(s, slot_base(S, par, R_RHO), slot_base(S, par, R_RR)));
+      }
       if (mode) k_reduce_slots<<<1, 64, 0, st>>>(S, par, R_RHO, 2, 1);
       break;
     case 6:
@@ -1643,7 +1722,12 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       PHX_CHECK(launch_spmv(s, s->sell_val, V.y, V.t, 0, nullptr, nullptr, nullptr));
       break;
     case 12:
-      if (n > 0) k_true_residual<<<vec_grid(n), block, 0, st>>>(n, s->own, V.b, V.t, V.r, S);
+      if (n > 0) {
+        DotPart dp{nullptr, nullptr};
+        PHX_CHECK(det_part(s, vec_grid(n).x, &dp));
+        k_true_residual<<<vec_grid(n), block, 0, st>>>(n, s->own, V.b, V.t, V.r, S, dp);
+        PHX_CHECK(det_fold(s, slot_base(S, 0, R_RR), nullptr));
+      }
       k_reduce_slots<<<1, 64, 0, st>>>(S, 0, R_RR, 1, 1);
       break;
     case 13:
@@ -1836,7 +1920,12 @@ extern "C" int phx_solve(phx_system *s, int method, double rtol, int64_t max_ite
     const KrVecs V = kr_vecs(s);
     PHX_HIP(hipMemsetAsync(S + P_OFF, 0, sizeof(double) * (PHX_SCAL_DOUBLES - P_OFF), st));
     PHX_CHECK(launch_spmv(s, s->sell_val, V.y, V.t, 0, nullptr, nullptr, nullptr));
-    k_true_residual<<<vec_grid(s->n), dim3(256), 0, st>>>(s->n, s->own, V.b, V.t, V.r, S);
+    {
+      DotPart dp{nullptr, nullptr};
+      PHX_CHECK(det_part(s, vec_grid(s->n).x, &dp));
+      k_true_residual<<<vec_grid(s->n), dim3(256), 0, st>>>(s->n, s->own, V.b, V.t, V.r, S, dp);
+      PHX_CHECK(det_fold(s, slot_base(S, 0, R_RR), nullptr));
+    }
     k_reduce_slots<<<1, 64, 0, st>>>(S, 0, R_RR, 1, 1);
     PHX_HIP(hipMemcpyAsync(s->scal_h, S, sizeof(double) * 16, hipMemcpyDeviceToHost, st));
     PHX_HIP(hipStreamSynchronize(st));

@@ -273,7 +273,8 @@ template <int DOTS>
 __global__ void __launch_bounds__(256)
 k_spmv_p2s(int64_t nrun, const int32_t *__restrict__ runs, const double *__restrict__ tabE,
            const double *__restrict__ tabO, const unsigned *__restrict__ linemask, const double *__restrict__ x,
-           double *__restrict__ y, const double *__restrict__ d0, double *__restrict__ out0, double *__restrict__ out1) {
+           double *__restrict__ y, const double *__restrict__ d0, double *__restrict__ out0, double *__restrict__ out1,
+           DotPart part) {
   __shared__ double xs_all[4][5][72];
   const int lane = threadIdx.x & 63;
   double (*xs)[72] = xs_all[threadIdx.x >> 6];
@@ -346,9 +347,15 @@ k_spmv_p2s(int64_t nrun, const int32_t *__restrict__ runs, const double *__restr
     if (lane == 0) { red[0][wv] = p0; red[1][wv] = p1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      const int slot = (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE;
-      unsafeAtomicAdd(out0 + slot, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-      if (DOTS > 1) unsafeAtomicAdd(out1 + slot, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+      const double s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3], s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+      if (part.p0) {   // PHX_OPT_DETERMINISTIC
+        part.p0[blockIdx.x] = s0;
+        if (DOTS > 1) part.p1[blockIdx.x] = s1;
+      } else {
+        const int slot = (blockIdx.x & (NSLOT - 1)) * SLOT_STRIDE;
+        unsafeAtomicAdd(out0 + slot, s0);
+        if (DOTS > 1) unsafeAtomicAdd(out1 + slot, s1);
+      }
     }
   }
 }

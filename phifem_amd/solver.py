@@ -31,8 +31,12 @@ def check_converged(stats, rtol, strict=False):
 
 
 class PhiFEMSolver:
-    def __init__(self, mesh, pen_coef=1.0, stab_coef=1.0, degree=1, levelset_degree=1):
-        """mesh: a tagged `phifem_amd.Mesh` (box mode) or the sub-mesh returned by
+    def __init__(self, mesh, pen_coef=1.0, stab_coef=1.0, degree=1, levelset_degree=1, deterministic=False):
+        """deterministic=True (PHX_OPT_DETERMINISTIC): bit-reproducible assembly (degree 2: the element kernels run
+        twice and accumulate exactly) and Krylov dot products -- the same matrix bits, iteration count and solution
+        on every run; costs one more pass of the element kernels.
+
+        mesh: a tagged `phifem_amd.Mesh` (box mode) or the sub-mesh returned by
         `compute_tags_measures(..., box_mode=False)`; coefficients as main.py:42-43;
         degree = primal_degree = auxiliary degree (main.py:38, 76-78), levelset_degree as main.py:40.
         Degree-2 nodal arrays list the vertex values first, then the edge-midpoint values
@@ -47,6 +51,10 @@ class PhiFEMSolver:
         self.stab_coef = float(stab_coef)
         self._sys = None
         self.stats = {}
+        self.deterministic = bool(deterministic)
+
+    def _apply_options(self):
+        L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_DETERMINISTIC, int(getattr(self, "deterministic", False))))
 
     def __del__(self):
         self._free()
@@ -98,6 +106,7 @@ class PhiFEMSolver:
         phi_h, f_h, u_D = self._keep
         loc = L.ptr(phi_h)[1]
         h = C.c_void_p()
+        self._apply_options()
         if self.degree == 1:
             L.check(L.lib.phx_assemble_poisson_wd(
                 self.mesh._h, self.pen_coef, self.stab_coef, L.ptr(phi_h)[0], L.ptr(f_h)[0],
@@ -185,6 +194,7 @@ class PhiFEMSolver:
                 raise ValueError(f"`out` must be a contiguous float64 tensor of {nfull} values")
         p, loc = L.ptr(out)
         st = (C.c_double * 8)()
+        self._apply_options()
         L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_PROFILE_SPMV, int(profile_spmv)))
         L.check(L.lib.phx_solve(self._sys, 0, float(rtol), int(max_iter), p, loc, st))
         self.stats = {"iterations": int(st[0]), "relres": st[1], "seconds": st[2],
@@ -317,9 +327,9 @@ class InterfaceElasticitySolver(PhiFEMSolver):
     blocks of nv entries, see `blocks()`."""
 
     def __init__(self, mesh, E_in=1.0, nu_in=0.3, E_out=1.0e-3, nu_out=0.3,
-                 penalization_coefficient=1.0, stabilization_coefficient=1.0):
+                 penalization_coefficient=1.0, stabilization_coefficient=1.0, deterministic=False):
         # material parameters demo/interface-elasticity/data.py:14-22, coefficients param1.yaml:16-17
-        super().__init__(mesh)
+        super().__init__(mesh, deterministic=deterministic)
         self.params = np.array([E_in, nu_in, E_out, nu_out, penalization_coefficient,
                                 stabilization_coefficient], dtype=np.float64)
 
@@ -327,6 +337,7 @@ class InterfaceElasticitySolver(PhiFEMSolver):
         """phi_h: (nv,) nodal level-set; f_h, u_D: (nv, d) nodal vector fields; bc_vertices:
         vertices where u_in = u_D is imposed (the box boundary in the demo, main.py:158-177)."""
         self._free()
+        self._apply_options()
         m = self.mesh
         d = m.gdim
         h = C.c_void_p()
