@@ -53,7 +53,8 @@ def test_p2_runs_are_bit_identical(P, n):
     assert np.array_equal(a[4], c[4]) and np.array_equal(a[5], c[5])
     assert np.abs(a[1] - c[1]).max() <= 1e-13 * np.abs(c[1]).max()
     assert np.abs(a[0] - c[0]).max() <= 1e-13 * np.abs(c[0]).max()
-    assert np.abs(a[2] - c[2]).max() <= 1e-6 * np.abs(c[2]).max()
+    # (two solves to rtol 1e-9 of a system of condition 1e6-1e7: the solutions agree to ~cond * rtol)
+    assert np.abs(a[2] - c[2]).max() <= 1e-4 * np.abs(c[2]).max()
     print(f"P2 n={n}: iterations deterministic {a[3]} / {b[3]}, plain atomics {c[3]}")
 
 
@@ -84,5 +85,5 @@ def test_elasticity_runs_are_bit_identical(P):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert a[3] == b[3] and np.array_equal(a[2], b[2]), (a[3], b[3])
     assert np.abs(a[1] - c[1]).max() <= 1e-13 * np.abs(c[1]).max()
-    assert np.abs(a[2] - c[2]).max() <= 1e-5 * np.abs(c[2]).max()
+    assert np.abs(a[2] - c[2]).max() <= 1e-4 * np.abs(c[2]).max()
     print(f"elasticity n={n}: iterations deterministic {a[3]} / {b[3]}, plain atomics {c[3]}")
