@@ -1201,6 +1201,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
     delete s->p2s;
   }
   phx_box_precond_destroy(s->precond);
+  phx_blockjac_destroy(s->bj);
   delete s;
   return PHX_OK;
 }

@@ -450,6 +450,7 @@ static int assemble_el_with_capacity(phx_mesh *m, const double *params, const do
   PHX_REQUIRE(nent < INT32_MAX, PHX_ERR_VALUE, "too many DoFs for 32-bit column keys");
   phx_system *s = new phx_system();
   s->mesh = m; s->device = m->device; s->nfull = nent; s->slot_cap = W; s->nent = nent;
+  s->el_nblk = C;
   const dim3 block(256);
   ElArgs A;
   memset(&A, 0, sizeof(A));

@@ -266,6 +266,10 @@ struct phx_system {
   int32_t *bnd_rec = nullptr;      // [nbnd][6] {row, kind (0 stencil / 1 SELL-16 / 2 SELL-64), 4 kind-specific ints}
   int64_t nbnd = 0;
   phx_p2_struct *p2s = nullptr;    // structured P2 system (3-D Kuhn boxes), else nullptr
+  // interface elasticity: vertex-block Jacobi (phx_blockjac.inc.hip), built on the first solve from the CSR copy
+  int el_nblk = 0;                 // > 0: block-major system with this many blocks of nv entries (27 / 14)
+  struct phx_blockjac *bj = nullptr;
+  bool bj_tried = false;
   // PHX_OPT_DETERMINISTIC: every block of a dot-product kernel leaves its partial sum in its own entry of `dpart`
   // ([2][dpart_cap]) instead of adding it to a slot atomically; k_fold_partials sums them in a fixed order
   double *dpart = nullptr;
@@ -303,3 +307,5 @@ int phx_system_build_structured_p2(phx_system *s, const phx_slot_view &sv, int32
                                    const uint8_t *latc0i);
 struct phx_box_precond;
 void phx_box_precond_destroy(phx_box_precond *bp);  // phx_solve.hip
+struct phx_blockjac;
+void phx_blockjac_destroy(phx_blockjac *b);         // phx_solve.hip

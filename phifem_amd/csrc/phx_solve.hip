@@ -1554,6 +1554,8 @@ static int prof_collect(phx_system *s, double *avg_s, int *count, int c = 0) {
 }
 
 #include "phx_precond.inc.hip"
+#include "phx_blockjac.inc.hip"
+void phx_blockjac_destroy(phx_blockjac *b) { blockjac_free(b); }
 
 // restart threshold of the native loop: ratio of |r| since the last restart below which BiCGStab restarts from r
 // (PHX_RESTART_DROP, e.g. 1e-4; default 0 = only on breakdown).  Measured with f32 transforms (round 2): the 3-D
@@ -1609,7 +1611,7 @@ static inline KrVecs kr_vecs(phx_system *s) {
   double *w = s->kr_work ? s->kr_work : s->work;
   const int64_t n = s->n;
   KrVecs V{w, w + n, w + 2 * n, w + 3 * n, w + 4 * n, w + 5 * n, w + 6 * n, w + 7 * n, w + 2 * n, w + 4 * n};
-  if (s->precond_state == 1 || s->u_unscaled) {
+  if (s->precond_state == 1 || s->u_unscaled || s->bj) {
     // attached workspaces (multi-GPU drivers, 10 n doubles) carry the two extra vectors themselves
     V.phat = s->kr_work ? w + 8 * n : s->pvec;
     V.shat = s->kr_work ? w + 9 * n : s->pvec + n;
@@ -1634,7 +1636,11 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       s->precond_state = 0;
     }
     if (s->precond_state == 0) PHX_CHECK(box_precond_setup(s));
-    if ((s->precond_state == 1 || s->u_unscaled) && n > 0 && !s->kr_work) {
+    if (s->el_nblk > 0 && !s->bj && !s->bj_tried && m->precond != 0 && s->rowptr && n > 0) {
+      s->bj_tried = true;
+      PHX_CHECK(blockjac_build(s, s->el_nblk, &s->bj));   // nullptr when a vertex block is singular: scalar Jacobi then
+    }
+    if ((s->precond_state == 1 || s->u_unscaled || s->bj) && n > 0 && !s->kr_work) {
       // phat / shat: rows the preconditioner never writes (u rows another rank owns) stay zero
       if (!s->pvec) PHX_HIP(phx_malloc(&s->pvec, sizeof(double) * (size_t)n * 2));
       PHX_HIP(hipMemsetAsync(s->pvec, 0, sizeof(double) * (size_t)n * 2, st));
@@ -1691,10 +1697,12 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       break;
     case 7:  // phat = P p   (before the halo exchange of phat and phase 2)
       if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.p, V.phat, s->precond->dist ? 1 : 0));
+      else if (s->bj) PHX_CHECK(blockjac_apply(s, s->bj, V.p, V.phat));
       else if (s->u_unscaled && n > 0) k_jacobi_u<<<vec_grid(n), block, 0, st>>>(n, s->nu, s->perm, s->diag, V.p, V.phat);
       break;
     case 8:  // shat = P s   (before the halo exchange of shat and phase 4)
       if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.sv, V.shat, s->precond->dist ? 1 : 0));
+      else if (s->bj) PHX_CHECK(blockjac_apply(s, s->bj, V.sv, V.shat));
       else if (s->u_unscaled && n > 0) k_jacobi_u<<<vec_grid(n), block, 0, st>>>(n, s->nu, s->perm, s->diag, V.sv, V.shat);
       break;
     // --- multi-GPU overlap: phases 2 / 4 in two launches (rows that read no halo entry | the rows that do)
@@ -1779,7 +1787,7 @@ extern "C" int phx_krylov_finish(phx_system *s, double *x_out, int loc) {
 // the vectors a multi-GPU driver must halo-exchange instead of p / s)
 extern "C" int phx_krylov_precond_active(const phx_system *s, int *active) {
   // 1: the SpMV inputs are phat / shat (box preconditioner, or the u-block Jacobi of a structured system)
-  *active = (s->precond_state == 1 || s->u_unscaled) ? 1 : 0;
+  *active = (s->precond_state == 1 || s->u_unscaled || s->bj) ? 1 : 0;
   return PHX_OK;
 }
 
