@@ -114,19 +114,29 @@ k_bj_build(int64_t nvert, int nblk, const int32_t *__restrict__ dofmap, const in
   }
 }
 
-// out = P in over the solver vector: one thread per entry (row of a vertex block)
+// out = P in over the solver vector: one thread per entry (row of a vertex block).  The entries of a vertex are
+// consecutive, so a block of 256 entries stages ITS inputs in LDS once (one coalesced-by-vpos gather per thread) and the
+// rows read their k inputs from there; only the entries of a vertex that straddles the block boundary go to global
+// memory.  (One dependent gather per term: 238 us per application at 96^3 against 353 us for the SpMV.)
 __global__ void __launch_bounds__(256)
 k_bj_apply(int64_t n, const int32_t *__restrict__ vptr, const int32_t *__restrict__ vpos, const int32_t *__restrict__ evert,
            const int64_t *__restrict__ bptr, const double *__restrict__ M, const uint8_t *__restrict__ own,
            const double *__restrict__ vin, double *__restrict__ vout) {
-  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  __shared__ double xs[256];
+  const int64_t b0 = blockIdx.x * (int64_t)blockDim.x, e = b0 + threadIdx.x;
+  int32_t pos = 0;
+  if (e < n) { pos = vpos[e]; xs[threadIdx.x] = vin[pos]; }
+  __syncthreads();
   if (e >= n) return;
   const int32_t v = evert[e], e0 = vptr[v];
   const int k = vptr[v + 1] - e0, i = (int)(e - e0);
   const double *Mc = M + bptr[v] + i;
   double acc = 0.0;
-  for (int j = 0; j < k; ++j) acc = __builtin_fma(Mc[(int64_t)j * k], vin[vpos[e0 + j]], acc);
-  const int32_t pos = vpos[e];
+  for (int j = 0; j < k; ++j) {
+    const int64_t ej = (int64_t)e0 + j;
+    const double xj = (ej >= b0 && ej < b0 + 256) ? xs[ej - b0] : vin[vpos[ej]];
+    acc = __builtin_fma(Mc[(int64_t)j * k], xj, acc);
+  }
   vout[pos] = (own && !own[pos]) ? 0.0 : acc;
 }
 

@@ -752,17 +752,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 // PHX_OPT_DETERMINISTIC: where the blocks of a dot-product kernel leave their partial sums (p0 == nullptr: atomics)
 struct DotPart { double *p0, *p1; };
 // fixed-order sum of nb partials per quantity into slot 0 of its slot set (the other slots stay zero: no atomics ran)
-__global__ void __launch_bounds__(256) k_fold_partials(int64_t nb, DotPart part, double *out0, double *out1) {
-  __shared__ double red[256];
+__global__ void __launch_bounds__(1024) k_fold_partials(int64_t nb, DotPart part, double *out0, double *out1) {
+  __shared__ double red[1024];
   for (int q = 0; q < 2; ++q) {
     const double *p = q == 0 ? part.p0 : part.p1;
     double *out = q == 0 ? out0 : out1;
     if (!p || !out) continue;
     double a = 0.0;
-    for (int64_t i = threadIdx.x; i < nb; i += 256) a += p[i];
+    for (int64_t i = threadIdx.x; i < nb; i += 1024) a += p[i];
     red[threadIdx.x] = a;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
       if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
       __syncthreads();
     }
@@ -1381,7 +1381,7 @@ static int det_part(phx_system *s, int64_t nb, DotPart *out) {
 }
 static int det_fold(phx_system *s, double *out0, double *out1) {
   if (!s->mesh->deterministic || s->dpart_used == 0) return PHX_OK;
-  k_fold_partials<<<1, 256, 0, s->mesh->stream>>>(s->dpart_used, DotPart{s->dpart, s->dpart + s->dpart_cap}, out0, out1);
+  k_fold_partials<<<1, 1024, 0, s->mesh->stream>>>(s->dpart_used, DotPart{s->dpart, s->dpart + s->dpart_cap}, out0, out1);
   PHX_HIP(hipGetLastError());
   s->dpart_used = 0;
   return PHX_OK;
