@@ -297,12 +297,15 @@ __device__ __forceinline__ void fft_pairs(C2<T> *z, const DstPlan &P, int t, boo
 // In:  w[ZP(j)] = (a_j, b_j), j = 1 .. L-1 (w[0] arbitrary).   Out: w[ZP(k)] = (F^a_k, F^b_k), k = 1 .. L-1,
 // F_k = sum_j x_j sin(pi j k / L).  `scr`: tp + tp/8 + 1 complex values of scan scratch of this pair.
 // Block-wide barriers inside: every thread of the block calls it.
-template <typename T, bool WAVE, int LL>
+// PRE = false: the caller has already written the folded sequence y_j = sin(pi j / L)(x_j + x_{L-j}) + (x_j - x_{L-j}) / 2
+// (w[0] = 0, w[H] = 2 x_H) -- the loaders of the x and y passes fold in registers, which saves a read and a write of
+// every LDS element and one synchronisation per transform.
+template <typename T, bool WAVE, int LL, bool PRE = true>
 __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P, int t, bool live,
                                          const C2<T> *tw, const T *sn) {
   const int L = plan_L<LL>(P), tp = plan_tp<LL>(P), H = L >> 1, slot = plan_slot<LL, WAVE>(P);
   const T hf = T(0.5);
-  if (live) {
+  if (PRE && live) {
     for (int j = 1 + t; j < H; j += tp) {
       const C2<T> X = w[ZP(j)], Y = w[ZP(L - j)];
       const T s = sn[j];
@@ -317,7 +320,7 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
       w[ZP(H)] = mk<T>(X.x + X.x, X.y + X.y);
     }
   }
-  psync<WAVE>();
+  if (PRE) psync<WAVE>();
   fft_pairs<T, WAVE, LL>(w, P, t, live, tw);
   // thread t owns k = 4 t .. 4 t + 3  (k < L / 2)
   // The running sums are kept in f64 whatever the transform precision: in f32 they are what turns the
@@ -454,47 +457,56 @@ k_dst_x(BoxGrid g, DstPlan P, T *__restrict__ G, const int32_t *__restrict__ gma
       has[c] = l < nlines && !((IO == 1 || IO == 2) && line_any && !line_any[l]);
       base[c] = has[c] ? (l % g.m[1]) * g.pitch + (l / g.m[1]) * g.plane : 0;
     }
-    // j = t + i tp, L / tp = 8 trips; all loads are issued before the first LDS write
-    T va[8], vb[8];
+    // the thread takes the PAIRS (j, L - j), j = 1 + t + i tp (4 trips: j = 1 .. L / 2) of both lines and folds them in
+    // registers (dst_core<..., PRE = false>); all loads are issued before the first LDS write
+    const int H = L >> 1;
+    const T *sng = PlanTab<T>::sn(P);
+    T va[4], vb[4], ua[4], ub[4], sj[4];   // line a / b at j (v) and at L - j (u)
     if (IO == 1) {
-      int32_t qa[8], qb[8];
+      int32_t qa[4], qb[4], pa[4], pb[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int j = t + i * Ptp;
-        const bool in = j >= 1 && j <= mx;
-        qa[i] = in && has[0] ? gmap[base[0] + j - 1] : -1;
-        qb[i] = in && has[1] ? gmap[base[1] + j - 1] : -1;
+      for (int i = 0; i < 4; ++i) {
+        const int j = 1 + t + i * Ptp;
+        qa[i] = has[0] ? gmap[base[0] + j - 1] : -1;
+        qb[i] = has[1] ? gmap[base[1] + j - 1] : -1;
+        pa[i] = has[0] && j < H ? gmap[base[0] + L - j - 1] : -1;
+        pb[i] = has[1] && j < H ? gmap[base[1] + L - j - 1] : -1;
+        sj[i] = sng[j];
       }
-      if (dscale) {  // weighted systems (u = phi w): the residual is scaled on the way in as well
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          va[i] = qa[i] >= 0 ? (T)(vin[qa[i]] * dscale[qa[i]]) : T(0);
-          vb[i] = qb[i] >= 0 ? (T)(vin[qb[i]] * dscale[qb[i]]) : T(0);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          va[i] = qa[i] >= 0 ? (T)vin[qa[i]] : T(0);
-          vb[i] = qb[i] >= 0 ? (T)vin[qb[i]] : T(0);
-        }
+      for (int i = 0; i < 4; ++i) {
+        va[i] = qa[i] >= 0 ? (T)(dscale ? vin[qa[i]] * dscale[qa[i]] : vin[qa[i]]) : T(0);
+        vb[i] = qb[i] >= 0 ? (T)(dscale ? vin[qb[i]] * dscale[qb[i]] : vin[qb[i]]) : T(0);
+        ua[i] = pa[i] >= 0 ? (T)(dscale ? vin[pa[i]] * dscale[pa[i]] : vin[pa[i]]) : T(0);
+        ub[i] = pb[i] >= 0 ? (T)(dscale ? vin[pb[i]] * dscale[pb[i]] : vin[pb[i]]) : T(0);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int j = t + i * Ptp;
-        const bool in = j >= 1 && j <= mx;
-        va[i] = in && has[0] ? G[base[0] + j - 1] : T(0);
-        vb[i] = in && has[1] ? G[base[1] + j - 1] : T(0);
+      for (int i = 0; i < 4; ++i) {
+        const int j = 1 + t + i * Ptp;
+        va[i] = has[0] ? G[base[0] + j - 1] : T(0);
+        vb[i] = has[1] ? G[base[1] + j - 1] : T(0);
+        ua[i] = has[0] && j < H ? G[base[0] + L - j - 1] : T(0);
+        ub[i] = has[1] && j < H ? G[base[1] + L - j - 1] : T(0);
+        sj[i] = sng[j];
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int j = t + i * Ptp;
-      if (j >= 1 && j < L) w[ZP(j)] = mk<T>(va[i], vb[i]);
+    for (int i = 0; i < 4; ++i) {
+      const int j = 1 + t + i * Ptp;
+      if (j < H) {
+        const C2<T> e = mk<T>(sj[i] * (va[i] + ua[i]), sj[i] * (vb[i] + ub[i]));
+        const C2<T> o = mk<T>(T(0.5) * (va[i] - ua[i]), T(0.5) * (vb[i] - ub[i]));
+        w[ZP(j)] = cadd(e, o);
+        w[ZP(L - j)] = csub(e, o);
+      } else {
+        w[ZP(H)] = mk<T>(va[i] + va[i], vb[i] + vb[i]);
+      }
     }
+    if (t == 0) w[0] = mk<T>(T(0), T(0));
   }
   __syncthreads();
-  dst_core<T, WAVE, LL>(w, scr, P, t, live, tw, sn);
+  dst_core<T, WAVE, LL, false>(w, scr, P, t, live, tw, sn);
   if (!live) return;
   if (IO == 2) {
     // k = t + 1 + i tp: all map loads, then all scale loads, then the stores
@@ -564,17 +576,47 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G, const int2 *__restrict__ row_an
   // rstep = L / 16: 16 trips, all loads in flight before the first LDS write)
   const int tcol = threadIdx.x % W, row0 = threadIdx.x / W, rstep = blockDim.x / W;
   T *wcol = reinterpret_cast<T *>(zs + (size_t)(tcol >> 1) * ZLEN(L)) + (tcol & 1);
-  {
+  if constexpr (!SOLVE) {
+    // plain transform: the thread takes the PAIRS (j, L - j), j = 1 + row0 + i rstep <= L / 2, and folds them in
+    // registers (dst_core<..., PRE = false>)
+    constexpr int NT = 8;
+    const int H = L >> 1;
+    T va[NT], vb[NT], sj[NT];
+    const T *sng = PlanTab<T>::sn(P);
+    int rlo = 0, rhi = len - 1;
+    if (AXIS == 1 && row_any && dir == 1) { const int2 iv = row_any[outer]; rlo = iv.x; rhi = iv.y; }
+    const bool colok = tcol < ncols;
+    const T *g0 = G + (base + tcol);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int j = 1 + row0 + i * rstep;
+      const int ra = j - 1, rb = L - 1 - j;
+      const bool ok = j <= H && colok;
+      va[i] = (ok && ra >= rlo && ra <= rhi) ? g0[(int64_t)ra * estride] : T(0);
+      vb[i] = (ok && j < H && rb >= rlo && rb <= rhi) ? g0[(int64_t)rb * estride] : T(0);
+      sj[i] = j <= H ? sng[j] : T(0);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int j = 1 + row0 + i * rstep;
+      if (j < H) {
+        const T e = sj[i] * (va[i] + vb[i]), o = T(0.5) * (va[i] - vb[i]);
+        wcol[2 * ZP(j)] = e + o;
+        wcol[2 * ZP(L - j)] = e - o;
+      } else if (j == H) {
+        wcol[2 * ZP(H)] = va[i] + va[i];
+      }
+    }
+    if (row0 == 0) wcol[0] = T(0);
+  } else {
     T vv[16];
     const T *gp = G + (base + (int64_t)row0 * estride + tcol);
     const int64_t gstep = (int64_t)rstep * estride;
     const bool colok = tcol < ncols;
-    int rlo = 0, rhi = len - 1;
-    if (AXIS == 1 && row_any && dir == 1) { const int2 iv = row_any[outer]; rlo = iv.x; rhi = iv.y; }
     int row = row0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      vv[i] = (row >= rlo && row <= rhi && colok) ? *gp : T(0);
+      vv[i] = (row < len && colok) ? *gp : T(0);
       gp += gstep;
       row += rstep;
     }
@@ -586,7 +628,7 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G, const int2 *__restrict__ row_an
     }
   }
   __syncthreads();
-  dst_core<T, WAVE, LL>(w, scr, P, t, live, tw, sn);
+  dst_core<T, WAVE, LL, SOLVE>(w, scr, P, t, live, tw, sn);
   if (SOLVE) {
     if (live) {
       const double *lx = g.lam[0], *ly = g.lam[1], *lz = g.lam[2];
