@@ -53,6 +53,16 @@ MESHTAG_DATA = {
 # depend on FFCx/basix round-off [3P]; reported, never gated.
 FP_FRAGILE = {"square_in_square"}
 FP_FRAGILE_DISCRETIZED = {"square_in_square", "nasty_levelset"}
+# Round 3: tests/golden/meshes.npz holds the EXACT coordinates of the reference's mesh files (rounds 1-2: h5dump's
+# 6-digit text).  With them the ellipse x^2 + (0.3 y - 0.1)^2 = 0.65 passes EXACTLY (in exact arithmetic) through the
+# mesh vertices (+-0.8, 0) and (+-0.8, 2/3) of the 30 x 30 square: the sign of phi there is round-off, and at detection
+# degree 3 ours and FFCx's differ in one cell (67 / 68 cut cells).  (dataset, degree): both legs, all modes -> 8 cases.
+FP_FRAGILE_DEGREE = {("ellipse_in_square", 3)}
+
+
+def is_fragile(name, deg, disc):
+    """Golden case decided by floating-point round-off of FFCx / basix [3P]: reported (xfail), never gated."""
+    return name in (FP_FRAGILE_DISCRETIZED if disc else FP_FRAGILE) or (name, deg) in FP_FRAGILE_DEGREE
 
 ONE_SIDED_DATA = {
     "line_in_square_quad": ("square_quad", line, lambda n: n[:, 0] + n[:, 1]),

@@ -43,19 +43,22 @@ H5DUMP = "/opt/conda/bin/h5dump"
 
 
 def h5_dataset(path, name, dtype):
-    # NOTE (round 2): h5dump's text output prints doubles with 6 significant digits, so the committed coordinates are
-    # the file's values rounded at 1e-7 relative (1/3 -> 0.333333; the square meshes differ from the file by <= 1 ulp).
-    # With the exact values (h5dump -b, as phifem_amd/io.py reads them) 8 more golden cases -- ellipse_in_square,
-    # detection degree 3, discretize -- join the floating-point-degenerate ones (decided by the last bit of the
-    # coordinates); the fixture is kept as generated in round 1, see DESIGN.md section 5.
-    out = subprocess.run([H5DUMP, "-d", name, "-y", "-w", "0", path],
-                         check=True, capture_output=True, text=True).stdout
-    m = re.search(r"DATASPACE\s+SIMPLE\s*\{\s*\(\s*(\d+)\s*,\s*(\d+)\s*\)", out)
+    """Dataset `name` of an HDF5 file through h5dump's RAW BINARY export (-b LE): the file's own bits.  (Rounds 1-2 parsed
+    h5dump's text output, which prints doubles with 6 significant digits: the committed coordinates were the file's
+    values rounded at 1e-7 relative.  Since round 3 the fixture holds the exact coordinates; with them 8 more golden
+    cases -- ellipse_in_square, detection degree 3, discretize -- are decided by the last bit of a coordinate and join
+    the floating-point-degenerate ones, tests/datasets.py.)"""
+    import tempfile
+    head = subprocess.run([H5DUMP, "-H", "-d", name, path], check=True, capture_output=True, text=True).stdout
+    m = re.search(r"DATASPACE\s+SIMPLE\s*\{\s*\(\s*(\d+)\s*,\s*(\d+)\s*\)", head)
     shape = (int(m.group(1)), int(m.group(2)))
-    body = out[out.index("DATA {") + 6:]
-    body = body[:body.index("}")]
-    vals = [v for v in re.split(r"[,\s]+", body.strip()) if v]
-    return np.array(vals, dtype=np.float64).astype(dtype).reshape(shape)
+    is_float = ("IEEE_F" in head) or ("FLOAT" in head)
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "d.bin")
+        subprocess.run([H5DUMP, "-d", name, "-b", "LE", "-o", out, path], check=True, capture_output=True)
+        item = os.path.getsize(out) // (shape[0] * shape[1])
+        raw = np.fromfile(out, dtype=np.dtype(f"<{'f' if is_float else 'i'}{item}"))
+    return raw.astype(dtype).reshape(shape)
 
 
 def main():

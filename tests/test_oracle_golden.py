@@ -15,7 +15,7 @@ import pytest
 from oracle import tagging as T
 from oracle.topology import Topology
 
-from datasets import (FP_FRAGILE, FP_FRAGILE_DISCRETIZED, MESHTAG_DATA, ONE_SIDED_DATA,
+from datasets import (FP_FRAGILE, FP_FRAGILE_DISCRETIZED, MESHTAG_DATA, ONE_SIDED_DATA, is_fragile,
                       load_mesh, nasty_interpolated)
 
 HERE = os.path.dirname(__file__)
@@ -43,7 +43,7 @@ CASES = [(n, d, disc, box, sl) for n in MESHTAG_DATA for d in (1, 2, 3)
 
 @pytest.mark.parametrize("name,deg,disc,box,sl", CASES)
 def test_tag_histograms(name, deg, disc, box, sl):
-    fragile = name in (FP_FRAGILE_DISCRETIZED if disc else FP_FRAGILE)
+    fragile = is_fragile(name, deg, disc)
     mesh, f = MESHTAG_DATA[name]
     if disc and name == "nasty_levelset":
         f = nasty_interpolated
@@ -128,7 +128,7 @@ def _robust_box_cases(mesh_name):
         for deg in (1, 2, 3):
             for disc in (False, True):
                 g = f
-                if name in (FP_FRAGILE_DISCRETIZED if disc else FP_FRAGILE):
+                if is_fragile(name, deg, disc):
                     if not (disc and name == "nasty_levelset" and deg != 2):
                         continue
                 if disc and name == "nasty_levelset":
