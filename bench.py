@@ -281,9 +281,14 @@ def main(argv=None):
         assert ach_req <= HBM_PEAK_GBS, "SpMV: more required bytes per second than the HBM peak -- the timed kernel is not doing the counted work"
         spmv_roof = {
             "bound": "hbm",
-            "kernel": "k_spmv_sell (f64 SpMV of the assembled system in one launch: 7-point stencil blocks over the "
-                      "translation-invariant interior rows of a structured P1 box system, SELL slices with f64 values / "
-                      "i32 columns for the stored rows)",
+            "kernel": ("k_spmv_sell + k_spmv_p2s (f64 SpMV of the structured P2 system: SELL-16 slices with f64 values / i32 "
+                       "columns for the stored band rows, the interior rows from eight class stencils over runs of fine-lattice "
+                       "points)" if args.config3 else
+                       "k_spmv_sell (f64 SpMV of the assembled system in one launch: SELL slices with f64 values / i32 columns, "
+                       "value-indexed where values repeat)" if args.config4 else
+                       "k_spmv_sell (f64 SpMV of the assembled system in one launch: 7-point stencil blocks over the "
+                       "translation-invariant interior rows of a structured P1 box system, SELL slices with f64 values / "
+                       "i32 columns for the stored rows)"),
             # `achieved` / `frac`: SURVEY 8(d)'s algorithmic bytes of the CSR product, 12 nnz + 20 n -- a THROUGHPUT
             # figure (CSR-equivalent GB/s); `achieved_required` / `frac_required`: bytes this format must move
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -350,6 +355,7 @@ def main(argv=None):
                 "dist_backend": backend if world > 1 else None,
                 "dist_loop": getattr(getattr(prob, "dk", None), "path", "native-single"),
                 "system": res.get("system"),
+                "deterministic": bool(getattr(prob.solver, "deterministic", False)),
             },
             "roofline": dominant,
         }
