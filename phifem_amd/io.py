@@ -3,12 +3,15 @@
 The reference writes its results with `dolfinx.io.XDMFFile` (`write_mesh` + `write_function`,
 demo/weak-dirichlet/flower/main.py:193-195) and reads its test meshes the same way
 (tests/test_compute_meshtags.py:136-137): an XML light-data file next to an HDF5 heavy-data file.  No HDF5 library
-exists in this image (no h5py, no libhdf5 headers), so:
+exists in this image (no h5py, no libhdf5 headers), so the package carries its own (`_h5lite.py`: the old-style
+groups + contiguous / chunked-deflate datasets that dolfinx, h5py and meshio produce):
 
-* `write_xdmf` writes XDMF 3 light data with the heavy data either inline (`Format="XML"`) or in raw little-endian
-  files (`Format="Binary"`) -- both are standard XDMF DataItem formats that ParaView / VisIt / meshio read;
-* `read_xdmf` reads those two formats directly and `Format="HDF"` items through h5py when it is importable, else
-  through the `h5dump` command-line tool when one is on PATH (it exports a dataset as raw binary), else it raises.
+* `write_xdmf` writes XDMF 3 light data with the heavy data in an HDF5 file laid out like dolfinx's
+  (`heavy="hdf"`: `<stem>.h5` with `/Mesh/mesh/geometry`, `/Mesh/mesh/topology`, `/Function/<name>/0`), inline
+  (`Format="XML"`) or in raw little-endian files (`Format="Binary"`) -- all three are standard XDMF DataItem formats
+  that ParaView / VisIt / meshio read;
+* `read_xdmf` reads the three formats; an HDF5 file outside `_h5lite`'s subset goes through h5py when it is
+  importable, else through the `h5dump` command-line tool (it exports a dataset as raw binary), else it raises.
 
 Cell orderings: XDMF quadrilaterals are cyclic (a, b, c, d); this package (like basix [3P]) keeps them in
 tensor-product order (a, b, d, c): converted on the way out and in.
@@ -27,12 +30,16 @@ _NUMPY = {("Float", 8): "<f8", ("Float", 4): "<f4", ("Int", 4): "<i4", ("Int", 8
           ("Char", 1): "i1", ("UChar", 1): "u1", ("UInt", 4): "<u4", ("UInt", 8): "<u8"}
 
 
-def _item(parent, arr, base, name, heavy):
+def _item(parent, arr, base, name, heavy, h5=None, h5path=None):
     arr = np.ascontiguousarray(arr)
     kind = "Float" if arr.dtype.kind == "f" else "Int"
     dims = " ".join(str(d) for d in arr.shape)
     it = ET.SubElement(parent, "DataItem", Dimensions=dims, NumberType=kind, Precision=str(arr.dtype.itemsize))
-    if heavy == "xml":
+    if heavy == "hdf":
+        h5[h5path] = arr
+        it.set("Format", "HDF")
+        it.text = f"{os.path.basename(base)}.h5:{h5path}"
+    elif heavy == "xml":
         it.set("Format", "XML")
         fmt = "%.17g" if kind == "Float" else "%d"
         it.text = "\n" + "\n".join(" ".join(fmt % v for v in row) for row in arr.reshape(arr.shape[0], -1)) + "\n"
@@ -46,13 +53,13 @@ def _item(parent, arr, base, name, heavy):
 
 
 def write_xdmf(path, cell_type, x, cells, point_data=None, cell_data=None, heavy="binary"):
-    """Mesh + nodal / cell-wise fields as `<path>` (light data) and `<stem>_*.bin` (heavy data, heavy="binary") or
-    everything inline (heavy="xml").  x: (nv, gdim); cells: (nc, nvpc) in this package's vertex order;
+    """Mesh + nodal / cell-wise fields as `<path>` (light data) and `<stem>_*.bin` (heavy data, heavy="binary"),
+    `<stem>.h5` (heavy="hdf", the layout dolfinx's XDMFFile writes) or everything inline (heavy="xml").  x: (nv, gdim); cells: (nc, nvpc) in this package's vertex order;
     point_data / cell_data: {name: array of nv / nc rows (scalars or vectors)}."""
     if cell_type not in _TOPO:
         raise NotImplementedError(f"unsupported cell type {cell_type!r}")
-    if heavy not in ("binary", "xml"):
-        raise ValueError("heavy must be 'binary' or 'xml'")
+    if heavy not in ("binary", "xml", "hdf"):
+        raise ValueError("heavy must be 'binary', 'xml' or 'hdf'")
     x = np.asarray(x, dtype=np.float64)
     cells = np.asarray(cells, dtype=np.int64)
     name, nvpc = _TOPO[cell_type]
@@ -70,9 +77,10 @@ def write_xdmf(path, cell_type, x, cells, point_data=None, cell_data=None, heavy
     grid = ET.SubElement(dom, "Grid", Name="mesh", GridType="Uniform")
     topo = ET.SubElement(grid, "Topology", TopologyType=name, NumberOfElements=str(cells.shape[0]),
                          NodesPerElement=str(nvpc))
-    _item(topo, cells, base, "topology", heavy)
+    h5 = {}
+    _item(topo, cells, base, "topology", heavy, h5, "/Mesh/mesh/topology")
     g = ET.SubElement(grid, "Geometry", GeometryType=geo)
-    _item(g, x3, base, "geometry", heavy)
+    _item(g, x3, base, "geometry", heavy, h5, "/Mesh/mesh/geometry")
     for center, data, n in (("Node", point_data or {}, x.shape[0]), ("Cell", cell_data or {}, cells.shape[0])):
         for key, arr in data.items():
             arr = np.asarray(arr)
@@ -84,7 +92,10 @@ def write_xdmf(path, cell_type, x, cells, point_data=None, cell_data=None, heavy
                 arr = np.concatenate([arr, np.zeros((n, 1))], axis=1)
             atype = "Scalar" if arr.shape[1] == 1 else ("Vector" if arr.shape[1] == 3 else "Matrix")
             a = ET.SubElement(grid, "Attribute", Name=key, AttributeType=atype, Center=center)
-            _item(a, arr, base, key, heavy)
+            _item(a, arr, base, key, heavy, h5, f"/Function/{key}/0")
+    if heavy == "hdf":
+        from ._h5lite import write_h5
+        write_h5(base + ".h5", h5)
     ET.indent(root)
     ET.ElementTree(root).write(path, xml_declaration=True, encoding="utf-8")
     return path
@@ -93,6 +104,11 @@ def write_xdmf(path, cell_type, x, cells, point_data=None, cell_data=None, heavy
 def _read_hdf(spec, shape, dtype, xdmf_dir):
     fn, _, dset = spec.strip().partition(":")
     fn = os.path.join(xdmf_dir, fn)
+    from ._h5lite import H5Unsupported, read_h5
+    try:
+        return read_h5(fn, dset).astype(dtype).reshape(shape)
+    except H5Unsupported:
+        pass
     try:
         import h5py  # noqa: F401
         with h5py.File(fn, "r") as f:
@@ -101,8 +117,8 @@ def _read_hdf(spec, shape, dtype, xdmf_dir):
         pass
     tool = shutil.which("h5dump") or next((p for p in ("/opt/conda/bin/h5dump", "/usr/bin/h5dump") if os.path.exists(p)), None)
     if tool is None:
-        raise ImportError(f"{fn}: HDF5 heavy data needs h5py or the h5dump tool; neither is available here "
-                          "(write_xdmf produces XML / Binary heavy data, which read_xdmf reads directly)")
+        raise ImportError(f"{fn}: this HDF5 file uses structures outside phifem_amd._h5lite's subset and needs h5py "
+                          "or the h5dump tool; neither is available here")
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "d.bin")
         subprocess.run([tool, "-d", dset, "-b", "LE", "-o", out, fn], check=True, capture_output=True)
@@ -163,7 +179,7 @@ def read_xdmf(path):
     return out
 
 
-def write_solution(path, mesh, **fields):
+def write_solution(path, mesh, heavy="hdf", **fields):
     """`of.write_mesh(mesh); of.write_function(u)` (demo/weak-dirichlet/flower/main.py:193-195): nodal fields
     (nv rows) become point data, cell-wise ones (nc rows) cell data."""
     pd, cd = {}, {}
@@ -177,4 +193,4 @@ def write_solution(path, mesh, **fields):
             pd[k] = v[:mesh.nv]      # degree-2 nodal array: the vertex values (the mesh written is first order)
         else:
             raise ValueError(f"{k}: {v.shape[0]} rows match neither the vertices nor the cells")
-    return write_xdmf(path, mesh.cell_type, mesh.x, mesh.cells, pd, cd)
+    return write_xdmf(path, mesh.cell_type, mesh.x, mesh.cells, pd, cd, heavy=heavy)

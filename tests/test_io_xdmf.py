@@ -1,7 +1,10 @@
 """XDMF I/O (phifem_amd/io.py; the reference's XDMFFile.write_mesh / write_function / read_mesh,
 demo/weak-dirichlet/flower/main.py:193-195, tests/test_compute_meshtags.py:136-137) without an HDF5 library:
-write -> read round trips bit for bit in both heavy-data formats, for the three cell types."""
+write -> read round trips bit for bit in the three heavy-data formats, for the three cell types; the package's own
+HDF5 writer / reader (phifem_amd/_h5lite.py) is checked against the `h5dump` tool when one is present."""
 import os
+import shutil
+import subprocess
 import xml.etree.ElementTree as ET
 
 import numpy as np
@@ -23,7 +26,10 @@ def meshes():
     return [("triangle", xt, ct), ("tetrahedron", x3, c3), ("quadrilateral", xq, cq)]
 
 
-@pytest.mark.parametrize("heavy", ["binary", "xml"])
+H5DUMP = shutil.which("h5dump") or next((p for p in ("/opt/conda/bin/h5dump", "/usr/bin/h5dump") if os.path.exists(p)), None)
+
+
+@pytest.mark.parametrize("heavy", ["binary", "xml", "hdf"])
 @pytest.mark.parametrize("k", [0, 1, 2])
 def test_round_trip(tmp_path, heavy, k):
     ctype, x, cells = meshes()[k]
@@ -44,6 +50,55 @@ def test_round_trip(tmp_path, heavy, k):
     assert np.array_equal(got["cell_data"]["cell_tags"], tags)
     if heavy == "binary":
         assert os.path.exists(str(tmp_path / "solution_geometry.bin"))
+    if heavy == "hdf":
+        # the layout dolfinx's XDMFFile writes (demo/weak-dirichlet/flower/main.py:193-195)
+        from phifem_amd._h5lite import list_h5
+        assert list_h5(str(tmp_path / "solution.h5")) == ["/Function/cell_tags/0", "/Function/u/0", "/Function/y/0",
+                                                          "/Mesh/mesh/geometry", "/Mesh/mesh/topology"]
+        assert root.find(".//Geometry/DataItem").text == "solution.h5:/Mesh/mesh/geometry"
+
+
+@pytest.mark.skipif(H5DUMP is None, reason="no h5dump tool to cross-check the writer with")
+def test_hdf5_files_are_read_by_the_hdf5_tools(tmp_path):
+    """What `write_h5` writes is a valid HDF5 file for libhdf5: h5dump lists the same tree and returns the same bytes
+    (f64 / f32 / i64 / i32 / u8, rank 1-3, an empty dataset, a group with more links than one symbol-table node)."""
+    from phifem_amd._h5lite import list_h5, read_h5, write_h5
+    rng = np.random.default_rng(3)
+    d = {"/Mesh/mesh/geometry": rng.random((7, 3)), "/Mesh/mesh/topology": rng.integers(0, 7, (5, 4)),
+         "/Function/u/0": rng.random((7, 1)), "/flags": np.arange(5, dtype=np.uint8),
+         "/f32": rng.random((2, 3, 2)).astype(np.float32), "/empty": np.zeros((0, 3))}
+    for i in range(70):
+        d[f"/many/d{i:03d}"] = np.full((2,), i - 35, dtype=np.int32)
+    fn = str(tmp_path / "t.h5")
+    write_h5(fn, d)
+    assert list_h5(fn) == sorted(d)
+    hdr = subprocess.run([H5DUMP, "-H", fn], check=True, capture_output=True, text=True).stdout
+    assert hdr.count("DATASET") == len(d) and "H5T_IEEE_F32LE" in hdr and "H5T_STD_U8LE" in hdr
+    for k, v in d.items():
+        mine = read_h5(fn, k)
+        assert mine.dtype == v.dtype and mine.shape == v.shape and np.array_equal(mine, v)
+        if v.size:
+            out = str(tmp_path / "d.bin")
+            subprocess.run([H5DUMP, "-d", k, "-b", "LE", "-o", out, fn], check=True, capture_output=True)
+            assert np.array_equal(np.fromfile(out, dtype=v.dtype).reshape(v.shape), v), k
+
+
+def test_hdf5_reader_rejects_what_it_does_not_understand(tmp_path):
+    from phifem_amd._h5lite import H5Unsupported, read_h5, write_h5
+    fn = str(tmp_path / "t.h5")
+    write_h5(fn, {"/a/b": np.arange(3.0)})
+    with pytest.raises(KeyError):
+        read_h5(fn, "/a/c")
+    raw = bytearray(open(fn, "rb").read())
+    raw[8] = 2                                   # a version-2 superblock: not this reader's subset
+    open(fn, "wb").write(raw)
+    with pytest.raises(H5Unsupported):
+        read_h5(fn, "/a/b")
+    open(fn, "wb").write(b"not hdf5 at all")
+    with pytest.raises(ValueError):
+        read_h5(fn, "/a/b")
+    with pytest.raises(NotImplementedError):
+        write_h5(fn, {"/c": np.zeros(2, dtype=np.complex128)})
 
 
 def test_quadrilaterals_are_written_cyclic(tmp_path):
@@ -75,10 +130,8 @@ def test_errors(tmp_path):
                     reason="the reference's test data is only present in the build container")
 def test_reads_the_references_xdmf_hdf5_meshes():
     """XDMFFile.read_mesh (tests/test_compute_meshtags.py:136-137) on the reference's own mesh files: HDF5 heavy data
-    through h5py or the h5dump tool; same cells as the committed fixture (converted from the same files), coordinates
-    equal to the fixture's 6-digit text export."""
-    if not (XIO.shutil.which("h5dump") or os.path.exists("/opt/conda/bin/h5dump")):
-        pytest.skip("no h5dump")
+    through the package's own reader (dolfinx's contiguous files and meshio's chunked + deflate one); same cells as
+    the committed fixture (converted from the same files), coordinates equal to the fixture's."""
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meshes.npz"))
     for name in ("disk", "square_tri", "square_quad", "coarse_square"):
         d = XIO.read_xdmf(f"/root/reference/tests/tests_data/{name}.xdmf")
