@@ -56,6 +56,16 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def hbm_in_use_gb():
+    """Device memory in use on this rank's GPU when the line is written (whole device: systems, pool, torch)."""
+    try:
+        import torch
+        free, total = torch.cuda.mem_get_info()
+        return round((total - free) / 2 ** 30, 2)
+    except Exception:
+        return None
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -347,7 +357,9 @@ def main(argv=None):
                 "krylov": ("BiCGStab (f64), right-preconditioned: lattice Laplacian of a box around the active "
                            f"vertices inverted by f{8 * res.get('precond_value_bytes', 8)} sine transforms (u), "
                            "Jacobi (p)") if res.get("precond") == "box-dst"
-                else "BiCGStab + Jacobi (right)",
+                else ("BiCGStab (f64), right-preconditioned: the dense 27 x 27 block of the DoFs of each vertex, "
+                      "inverted once per system (vertex-block Jacobi)")
+                if res.get("precond") == "vertex-block-jacobi" else "BiCGStab + Jacobi (right)",
                 "rtol": args.rtol, "iterations": res["iterations"], "relres": res["relres"],
                 "converged": converged,
                 "stage_ms": {k: 1e3 * v for k, v in res["stage_s"].items()},
@@ -356,6 +368,7 @@ def main(argv=None):
                 "dist_loop": getattr(getattr(prob, "dk", None), "path", "native-single"),
                 "system": res.get("system"),
                 "deterministic": bool(getattr(prob.solver, "deterministic", False)),
+                "hbm_in_use_gb": hbm_in_use_gb(),
             },
             "roofline": dominant,
         }

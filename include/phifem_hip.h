@@ -339,7 +339,8 @@ int phx_precond_dist_info(const phx_system *s, int64_t *out4);
  * all-reduces scal[8 + 4 .. 8 + 5] (SUM) after phase 0 and, when the vetoes add up to > 0, calls this on
  * every rank before the first iteration: Jacobi everywhere, same vectors exchanged, same check cadence. */
 int phx_krylov_precond_disable(phx_system *s);
-/* After a solve: out[8] = {preconditioner active (0/1), transform lengths L0, L1, L2, lattice points of
+/* After a solve: out[8] = {preconditioner (0: Jacobi, 1: lattice solve, 2: vertex-block Jacobi of the
+ * elasticity system), transform lengths L0, L1, L2, lattice points of
  * the box, sampled average seconds of one y-pass launch of the sine transforms (PHX_OPT_PROFILE_SPMV),
  * launches sampled, bytes per lattice value (4: f32 transforms, 8: f64)}. */
 int phx_precond_info(phx_system *s, double *out);

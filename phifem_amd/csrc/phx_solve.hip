@@ -1843,10 +1843,11 @@ extern "C" int phx_krylov_profile(phx_system *s, int reset, double *avg_seconds,
   return PHX_OK;
 }
 
-// out[8] = {preconditioner active (0/1), transform lengths L0, L1, L2, stored lattice points of the box,
+// out[8] = {preconditioner (0 Jacobi, 1 lattice solve, 2 vertex-block Jacobi), transform lengths L0, L1, L2, stored lattice points of the box,
 //           sampled average seconds of a y-pass launch, launches sampled, bytes per lattice value (4 / 8)}
 extern "C" int phx_precond_info(phx_system *s, double *out) {
   for (int i = 0; i < 8; ++i) out[i] = 0.0;
+  if (s->bj) out[0] = 2.0;   // dense vertex blocks (interface elasticity)
   if (s->precond_state != 1) return PHX_OK;
   const BoxGrid &g = s->precond->g;
   out[0] = 1.0;

@@ -213,7 +213,7 @@ class PhiFEMSolver:
         """State of the fictitious-domain preconditioner after a solve (phx_precond_info)."""
         o = (C.c_double * 8)()
         L.check(L.lib.phx_precond_info(self._sys, o))
-        return {"precond": "box-dst" if o[0] else "jacobi", "precond_L": [int(o[1]), int(o[2]), int(o[3])],
+        return {"precond": {1: "box-dst", 2: "vertex-block-jacobi"}.get(int(o[0]), "jacobi"), "precond_L": [int(o[1]), int(o[2]), int(o[3])],
                 "precond_points": int(o[4]), "dst_avg_s": o[5], "dst_timed": int(o[6]),
                 "precond_value_bytes": int(o[7])}
 
