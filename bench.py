@@ -359,7 +359,10 @@ def main(argv=None):
                            "Jacobi (p)") if res.get("precond") == "box-dst"
                 else ("BiCGStab (f64), right-preconditioned: the dense 27 x 27 block of the DoFs of each vertex, "
                       "inverted once per system (vertex-block Jacobi)")
-                if res.get("precond") == "vertex-block-jacobi" else "BiCGStab + Jacobi (right)",
+                + ("" if res.get("precond") == "vertex-block-jacobi" else
+                   f" + Galerkin coarse correction on trilinear functions of spacing {res['precond_L'][0]} h per "
+                   f"displacement block ({res.get('precond_points')} coarse DoFs, dense inverse)")
+                if str(res.get("precond", "")).startswith("vertex-block-jacobi") else "BiCGStab + Jacobi (right)",
                 "rtol": args.rtol, "iterations": res["iterations"], "relres": res["relres"],
                 "converged": converged,
                 "stage_ms": {k: 1e3 * v for k, v in res["stage_s"].items()},

@@ -171,6 +171,13 @@ enum phx_option {
                                summed in a fixed order.  Costs one more pass of the element kernels and 12 bytes
                                per row slot while assembling (skipped beyond PHX_DET_LIMIT_GB, default 48).
                                Default 0: f64 atomics in arrival order (results equal to round-off)           */
+  PHX_OPT_EL_COARSE = 10, /* coarse-space correction of the interface-elasticity solve on generated boxes (one rank):
+                               Galerkin problem on trilinear functions of spacing H = value * h per displacement
+                               block, added to the vertex-block Jacobi (the iteration count then follows H / h
+                               instead of growing with the box).  -1 (default): on from 80 cubes per axis with
+                               H ~ n / 8 (H = 16 h beyond 128 cubes); 0: off; >= 5: this ratio.  Needs
+                               librocsolver for the dense inverse of the coarse matrix (loaded on first use;
+                               without it the solve keeps the vertex blocks alone)                              */
   PHX_OPT_ALLOW_EMPTY = 6, /* 1: phx_assemble_poisson_wd returns an EMPTY system (n_active = 0) when no cell
                                is tagged 1 / 2 instead of PHX_ERR_VALUE: a slab of a partitioned box that
                                does not touch the domain still joins every collective of the solve          */

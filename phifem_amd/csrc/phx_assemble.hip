@@ -1202,6 +1202,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
   }
   phx_box_precond_destroy(s->precond);
   phx_blockjac_destroy(s->bj);
+  phx_coarse_destroy(s->cc);
   delete s;
   return PHX_OK;
 }

@@ -65,11 +65,13 @@ k_bj_build(int64_t nvert, int nblk, const int32_t *__restrict__ dofmap, const in
   for (int e = lane; e < k * 2 * k; e += 64) { const int i = e / (2 * k), j = e % (2 * k); A[i][j] = j - k == i ? 1.0 : 0.0; }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (lane < k) {
-    const int32_t r = rows[lane];
-    for (int64_t q = rowptr[r]; q < rowptr[r + 1]; ++q) {
+  // the 64 lanes walk each row of the vertex together (a lane per row chained 45-250 dependent look-ups: 288 ms at 256^3)
+  for (int j = 0; j < k; ++j) {
+    const int32_t r = rows[j];
+    for (int64_t q = rowptr[r] + lane; q < rowptr[r + 1]; q += 64) {
       const int64_t f = full_of_active[col[q]];
-      if (f % nvert == v) A[lane][lidx[f / nvert]] = val[q];
+      const int64_t blk = f / nvert;
+      if (f - blk * nvert == v) A[j][lidx[blk]] = val[q];
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

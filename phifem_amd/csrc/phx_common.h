@@ -17,7 +17,7 @@ void phx_set_error(const char *fmt, ...);
 // buffers on every pass; hipMalloc/hipFree of such blocks costs hundreds of milliseconds at
 // BASELINE scale (0.8 s per pass on the 1024x1024x128 slab).  Released blocks are kept per device and
 // handed back on an exact-size match; everything cached is returned to the driver when a real
-// allocation fails or the cache exceeds PHX_POOL_LIMIT_GB (default 96).
+// allocation fails or the cache exceeds PHX_POOL_LIMIT_GB (default: 60 % of the device memory).
 hipError_t phx_pool_malloc(void **p, size_t bytes);
 hipError_t phx_pool_free(void *p);
 void phx_pool_trim(void);
@@ -137,6 +137,7 @@ struct phx_mesh {
   int export_csr = 0;              // PHX_OPT_EXPORT_CSR: assembly also builds the CSR copy phx_system_export reads
   int structured = 1;              // PHX_OPT_STRUCTURED: stencil-coded interior rows on Kuhn boxes (P1 weak Dirichlet)
   int allow_empty = 0;             // PHX_OPT_ALLOW_EMPTY: assembly returns an EMPTY system when no cell is tagged 1 / 2
+  int el_coarse = -1;              // PHX_OPT_EL_COARSE
   int deterministic = 0;           // PHX_OPT_DETERMINISTIC: bit-reproducible P2 / elasticity assembly and Krylov dot products
   // A caller-supplied mesh that IS a Kuhn box in some vertex / cell order (what dolfinx's create_box / create_rectangle
   // hand over, demo/weak-dirichlet/flower/main.py:45-46): `inner` is the generated box with the same lattice, the maps
@@ -270,6 +271,7 @@ struct phx_system {
   int el_nblk = 0;                 // > 0: block-major system with this many blocks of nv entries (27 / 14)
   struct phx_blockjac *bj = nullptr;
   bool bj_tried = false;
+  struct phx_coarse *cc = nullptr; // coarse correction on top of the vertex blocks (phx_coarse.inc.hip), single rank
   // PHX_OPT_DETERMINISTIC: every block of a dot-product kernel leaves its partial sum in its own entry of `dpart`
   // ([2][dpart_cap]) instead of adding it to a slot atomically; k_fold_partials sums them in a fixed order
   double *dpart = nullptr;
@@ -309,3 +311,5 @@ struct phx_box_precond;
 void phx_box_precond_destroy(phx_box_precond *bp);  // phx_solve.hip
 struct phx_blockjac;
 void phx_blockjac_destroy(phx_blockjac *b);         // phx_solve.hip
+struct phx_coarse;
+void phx_coarse_destroy(phx_coarse *c);             // phx_solve.hip

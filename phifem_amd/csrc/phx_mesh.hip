@@ -30,12 +30,21 @@ struct Pool {
   std::multimap<std::pair<int, size_t>, void *> free_blocks;   // (device, bytes) -> ptr
   std::unordered_map<void *, std::pair<int, size_t>> live;      // ptr -> (device, bytes)
   size_t cached = 0;
+  size_t live_bytes = 0;        // handed out and not yet released
+  size_t device_total = 0;      // of the device the limit was derived from
 };
 Pool &pool() { static Pool p; return p; }
 size_t pool_limit() {
   static size_t lim = [] {
     const char *e = getenv("PHX_POOL_LIMIT_GB");
-    return (size_t)((e ? atof(e) : 96.0) * (double)(1ull << 30));
+    if (e) return (size_t)(atof(e) * (double)(1ull << 30));
+    // default: 60 % of the device (173 GB of 288) -- the transient buffers of one 256^3 elasticity pass add up to
+    // ~110 GB, and with the former 96 GB every pass gave the largest ones back and paid hipMalloc for them again
+    // (assembly 0.52 -> 2.5 s).  A failing allocation still empties the cache and retries.
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) { (void)hipGetLastError(); return (size_t)96 << 30; }
+    pool().device_total = tot;
+    return (size_t)(0.6 * (double)tot);
   }();
   return lim;
 }
@@ -46,8 +55,20 @@ void trim_locked(Pool &P) {
 }
 }  // namespace
 
+// Size classes of the cached blocks: 32 per octave (at most 3 % larger than asked).  Many sizes here depend on the data
+// in their last digits -- the value-indexed slices of a matrix assembled with atomics, selections, coarse spaces --
+// and with exact-size matching such a block was never found again: the cache filled up with near-duplicates and every
+// pass paid hipMalloc / hipFree for its largest buffers (256^3 elasticity: assembly 0.5 -> 2.1 s after a few passes).
+static inline size_t pool_size_class(size_t bytes) {
+  if (bytes < (1u << 20)) return bytes;
+  int lg = 63 - __builtin_clzll((unsigned long long)bytes);
+  const size_t gran = (size_t)1 << (lg - 5);
+  return (bytes + gran - 1) / gran * gran;
+}
+
 hipError_t phx_pool_malloc(void **p, size_t bytes) {
   if (bytes == 0) bytes = 16;
+  bytes = pool_size_class(bytes);
   int dev = 0;
   (void)hipGetDevice(&dev);
   Pool &P = pool();
@@ -58,6 +79,7 @@ hipError_t phx_pool_malloc(void **p, size_t bytes) {
     P.free_blocks.erase(it);
     P.cached -= bytes;
     P.live[*p] = {dev, bytes};
+    P.live_bytes += bytes;
     return hipSuccess;
   }
   hipError_t e = hipMalloc(p, bytes);
@@ -66,7 +88,7 @@ hipError_t phx_pool_malloc(void **p, size_t bytes) {
     trim_locked(P);
     e = hipMalloc(p, bytes);
   }
-  if (e == hipSuccess) P.live[*p] = {dev, bytes};
+  if (e == hipSuccess) { P.live[*p] = {dev, bytes}; P.live_bytes += bytes; }
   return e;
 }
 
@@ -78,7 +100,14 @@ hipError_t phx_pool_free(void *p) {
   if (it == P.live.end()) return hipFree(p);  // not ours (allocated before the pool existed)
   const auto key = it->second;
   P.live.erase(it);
+  P.live_bytes -= std::min(P.live_bytes, key.second);
   if (key.second < (1u << 20) || P.cached + key.second > pool_limit()) return hipFree(p);
+  // Large problems (this library's blocks, handed out or cached, beyond half of the device): other allocators of the
+  // process (torch's) cannot ask this cache to shrink, so it keeps a tenth of the device free for them
+  if (P.device_total > 0 && 2 * (P.live_bytes + P.cached + key.second) > P.device_total) {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && 10 * fr < tot) return hipFree(p);
+  }
   // hipFree would have synchronised the device; a cached block may be handed to another stream
   (void)hipDeviceSynchronize();
   P.free_blocks.insert({key, p});
@@ -1034,6 +1063,10 @@ extern "C" int phx_set_option(phx_mesh *m, int option, int64_t value) {
     case PHX_OPT_EXPORT_CSR: m->export_csr = value != 0; return PHX_OK;
     case PHX_OPT_STRUCTURED: m->structured = value != 0; return PHX_OK;
     case PHX_OPT_DETERMINISTIC: m->deterministic = value != 0; return PHX_OK;
+    case PHX_OPT_EL_COARSE:
+      PHX_REQUIRE(value == -1 || value == 0 || (value >= 5 && value <= 4096), PHX_ERR_VALUE, "coarse ratio %lld: -1, 0 or >= 5", (long long)value);
+      m->el_coarse = (int)value;
+      return PHX_OK;
     case PHX_OPT_PRECOND:
       PHX_REQUIRE(value >= 0 && value <= 2, PHX_ERR_VALUE, "unknown preconditioner %lld", (long long)value);
       m->precond = (int)value;

@@ -1555,6 +1555,7 @@ static int prof_collect(phx_system *s, double *avg_s, int *count, int c = 0) {
 
 #include "phx_precond.inc.hip"
 #include "phx_blockjac.inc.hip"
+#include "phx_coarse.inc.hip"
 void phx_blockjac_destroy(phx_blockjac *b) { blockjac_free(b); }
 
 // restart threshold of the native loop: ratio of |r| since the last restart below which BiCGStab restarts from r
@@ -1639,6 +1640,8 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
     if (s->el_nblk > 0 && !s->bj && !s->bj_tried && m->precond != 0 && s->rowptr && n > 0) {
       s->bj_tried = true;
       PHX_CHECK(blockjac_build(s, s->el_nblk, &s->bj));   // nullptr when a vertex block is singular: scalar Jacobi then
+      // coarse correction on top of the vertex blocks (one rank; a partitioned box keeps the blocks alone)
+      if (s->bj && !s->own && !s->kr_work) PHX_CHECK(coarse_build(s, s->el_nblk, &s->cc));
     }
     if ((s->precond_state == 1 || s->u_unscaled || s->bj) && n > 0 && !s->kr_work) {
       // phat / shat: rows the preconditioner never writes (u rows another rank owns) stay zero
@@ -1697,12 +1700,12 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       break;
     case 7:  // phat = P p   (before the halo exchange of phat and phase 2)
       if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.p, V.phat, s->precond->dist ? 1 : 0));
-      else if (s->bj) PHX_CHECK(blockjac_apply(s, s->bj, V.p, V.phat));
+      else if (s->bj) { PHX_CHECK(blockjac_apply(s, s->bj, V.p, V.phat)); PHX_CHECK(coarse_apply_add(s, s->cc, V.p, V.phat)); }
       else if (s->u_unscaled && n > 0) k_jacobi_u<<<vec_grid(n), block, 0, st>>>(n, s->nu, s->perm, s->diag, V.p, V.phat);
       break;
     case 8:  // shat = P s   (before the halo exchange of shat and phase 4)
       if (s->precond_state == 1) PHX_CHECK(box_precond_apply(s, V.sv, V.shat, s->precond->dist ? 1 : 0));
-      else if (s->bj) PHX_CHECK(blockjac_apply(s, s->bj, V.sv, V.shat));
+      else if (s->bj) { PHX_CHECK(blockjac_apply(s, s->bj, V.sv, V.shat)); PHX_CHECK(coarse_apply_add(s, s->cc, V.sv, V.shat)); }
       else if (s->u_unscaled && n > 0) k_jacobi_u<<<vec_grid(n), block, 0, st>>>(n, s->nu, s->perm, s->diag, V.sv, V.shat);
       break;
     // --- multi-GPU overlap: phases 2 / 4 in two launches (rows that read no halo entry | the rows that do)
@@ -1847,7 +1850,8 @@ extern "C" int phx_krylov_profile(phx_system *s, int reset, double *avg_seconds,
 //           sampled average seconds of a y-pass launch, launches sampled, bytes per lattice value (4 / 8)}
 extern "C" int phx_precond_info(phx_system *s, double *out) {
   for (int i = 0; i < 8; ++i) out[i] = 0.0;
-  if (s->bj) out[0] = 2.0;   // dense vertex blocks (interface elasticity)
+  if (s->bj) out[0] = s->cc ? 3.0 : 2.0;   // dense vertex blocks (interface elasticity), 3: with the coarse correction
+  if (s->cc) { out[1] = (double)s->cc->ratio; out[4] = (double)s->cc->nc; }
   if (s->precond_state != 1) return PHX_OK;
   const BoxGrid &g = s->precond->g;
   out[0] = 1.0;

@@ -118,7 +118,7 @@ class SlabProblem:
             "system": {k: info[k] for k in ("n_active", "n_active_u", "stencil_rows", "stencil_runs", "n_slices",
                                             "sell_nnz", "sell_padded_nnz", "slot_capacity")},
             # sine-transform y pass of the preconditioner: reads and writes every lattice point once
-            "precond": pc["precond"], "precond_L": pc["precond_L"],
+            "precond": pc["precond"], "precond_L": pc["precond_L"], "precond_points": pc["precond_points"],
             "dst_avg_s": pc["dst_avg_s"], "dst_count": pc["dst_timed"],
             "dst_algorithmic_bytes": 2.0 * pc["precond_value_bytes"] * pc["precond_points"],
             "precond_value_bytes": pc["precond_value_bytes"],

@@ -55,6 +55,8 @@ class PhiFEMSolver:
 
     def _apply_options(self):
         L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_DETERMINISTIC, int(getattr(self, "deterministic", False))))
+        if hasattr(self, "coarse"):
+            L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_EL_COARSE, self.coarse))
 
     def __del__(self):
         self._free()
@@ -213,7 +215,7 @@ class PhiFEMSolver:
         """State of the fictitious-domain preconditioner after a solve (phx_precond_info)."""
         o = (C.c_double * 8)()
         L.check(L.lib.phx_precond_info(self._sys, o))
-        return {"precond": {1: "box-dst", 2: "vertex-block-jacobi"}.get(int(o[0]), "jacobi"), "precond_L": [int(o[1]), int(o[2]), int(o[3])],
+        return {"precond": {1: "box-dst", 2: "vertex-block-jacobi", 3: "vertex-block-jacobi+coarse"}.get(int(o[0]), "jacobi"), "precond_L": [int(o[1]), int(o[2]), int(o[3])],
                 "precond_points": int(o[4]), "dst_avg_s": o[5], "dst_timed": int(o[6]),
                 "precond_value_bytes": int(o[7])}
 
@@ -327,9 +329,12 @@ class InterfaceElasticitySolver(PhiFEMSolver):
     blocks of nv entries, see `blocks()`."""
 
     def __init__(self, mesh, E_in=1.0, nu_in=0.3, E_out=1.0e-3, nu_out=0.3,
-                 penalization_coefficient=1.0, stabilization_coefficient=1.0, deterministic=False):
+                 penalization_coefficient=1.0, stabilization_coefficient=1.0, deterministic=False, coarse=-1):
+        """coarse (PHX_OPT_EL_COARSE): spacing H / h of the coarse-space correction of the solve on generated boxes;
+        -1 automatic (on from 80 cubes per axis), 0 off."""
         # material parameters demo/interface-elasticity/data.py:14-22, coefficients param1.yaml:16-17
         super().__init__(mesh, deterministic=deterministic)
+        self.coarse = int(coarse)
         self.params = np.array([E_in, nu_in, E_out, nu_out, penalization_coefficient,
                                 stabilization_coefficient], dtype=np.float64)
 
