@@ -373,6 +373,10 @@ int phx_system_get_perm(phx_system *s, int32_t *perm, int32_t *dof_u, int32_t *d
  * three all-reduces of 1, 2, 2 doubles per iteration.  Convergence checks are scheduled as in phx_solve; relres /
  * converged refer to the TRUE residual (one more halo exchange + SpMV + all-reduce, restart when it misses rtol).
  * Every host wait is bounded by PHX_DIST_TIMEOUT_S (default 300 s) -> PHX_ERR_TIMEOUT.
+ * Interface-elasticity systems (PHX_OPT_EL_COARSE): the coarse correction is built collectively before the first
+ * iteration (all-reduces of the used-node flags, of a veto and of the coarse matrix: every rank restricts the rows it
+ * owns), and every application adds one all-reduce of the coarse right-hand side (phases 30 / 32 restrict p / s,
+ * 31 / 33 add the prolonged correction to phat / shat).  The phase API alone keeps the vertex blocks.
  * Buffers attached with phx_krylov_attach.
  *   peers[npeers]; counts[2*npeers] = {n_send, n_recv}; idx[2*npeers] = device int64 arrays
  *   {send positions, recv positions} in solver order. */

@@ -15,12 +15,18 @@
 //     (getrf + getri, loaded with dlopen: a plain dense LAPACK call, not a kernel of the path) and applied as a
 //     matrix-vector product;
 //   * R^T and R run as three 1-D passes over lattice lines (no atomics: bit-reproducible).
-// Single-rank systems only (a partitioned box keeps the vertex blocks alone).
+// Partitioned boxes (native RCCL loop, phx_dist.inc.hip): the coarse lattice is the one of the GLOBAL box; every rank
+// restricts its owned rows, the coarse right-hand side is all-reduced (a few thousand doubles per application), every
+// rank holds Ac^-1 (its own rows' share of Ac summed over the ranks once per system) and prolongs onto its owned rows.
 #include <dlfcn.h>
+
+#include <functional>
 
 struct phx_coarse {
   int d = 3, nblk_u = 6, ratio = 16;
-  int64_t nf[3] = {1, 1, 1};   // fine vertices per axis
+  bool dist = false;           // partitioned box: restriction and prolongation are two phases with an all-reduce between
+  int off[3] = {0, 0, 0};      // lattice offset of this rank's vertices in the global box
+  int64_t nf[3] = {1, 1, 1};   // fine vertices per axis (this rank)
   int m[3] = {1, 1, 1};        // coarse nodes per axis
   int64_t M = 1;               // coarse nodes per block
   int nc = 0;                  // compact coarse DoFs
@@ -78,11 +84,13 @@ RocSolver &rocsolver() {
 // unit row `1 * u = u_D`: a single entry on the diagonal)
 __global__ void k_cc_positions(int64_t n, int64_t nv, int nblk_u, int d, const int64_t *__restrict__ full_of_active,
                                const int64_t *__restrict__ rowptr, const int32_t *__restrict__ iperm,
-                               const double *__restrict__ diag, int32_t *__restrict__ cpos, double *__restrict__ dpos) {
+                               const double *__restrict__ diag, const uint8_t *__restrict__ own, int32_t *__restrict__ cpos,
+                               double *__restrict__ dpos) {
   const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (r >= n) return;
   const int32_t pos = iperm[r];
   dpos[pos] = diag[r];
+  if (own && !own[pos]) return;   // a row another rank owns
   const int64_t f = full_of_active[r];
   const int blk = (int)(f / nv);
   if (blk >= nblk_u) return;
@@ -95,6 +103,7 @@ struct CcDims {
   int m[3];
   int ratio;
   int64_t M;
+  int off[3];
 };
 // coarse node and weight of the two hat functions that cover fine index i along an axis with `m` coarse nodes
 __device__ __forceinline__ void cc_axis(int64_t i, int ratio, int m, int c[2], double w[2]) {
@@ -113,7 +122,7 @@ __global__ void k_cc_used(int64_t total, int64_t nv, CcDims g, const int32_t *__
   const int64_t i[3] = {v % g.nf[0], (v / g.nf[0]) % g.nf[1], v / (g.nf[0] * g.nf[1])};
   int c[3][2];
   double w[3][2];
-  for (int a = 0; a < 3; ++a) cc_axis(i[a], g.ratio, g.m[a], c[a], w[a]);
+  for (int a = 0; a < 3; ++a) cc_axis(i[a] + g.off[a], g.ratio, g.m[a], c[a], w[a]);
   for (int q = 0; q < 8; ++q) {
     const double ww = w[0][q & 1] * w[1][(q >> 1) & 1] * w[2][q >> 2];
     if (ww > 0.0) used[blk * g.M + c[0][q & 1] + (int64_t)g.m[0] * (c[1][(q >> 1) & 1] + (int64_t)g.m[1] * c[2][q >> 2])] = 1;
@@ -133,7 +142,7 @@ __global__ void k_cc_probe(int64_t nv, int blk, int col3, CcDims g, const int32_
   for (int a = 0; a < 3; ++a) {
     int c[2];
     double w[2];
-    cc_axis(i[a], g.ratio, g.m[a], c, w);
+    cc_axis(i[a] + g.off[a], g.ratio, g.m[a], c, w);
     s[a] = (c[0] % 3 == cc[a] ? w[0] : 0.0) + ((c[1] != c[0] && c[1] % 3 == cc[a]) ? w[1] : 0.0);
   }
   wvec[pos] = dpos[pos] * s[0] * s[1] * s[2];
@@ -165,13 +174,13 @@ k_cc_restrict_x(int64_t nlines, CcDims g, int colour, const int32_t *__restrict_
   const int nf0 = (int)g.nf[0];
   for (int ci = lane; ci < g.m[0]; ci += 64) {
     // the hat of node ci: 1 - |i - ci H| / H on (ci - 1) H < i < (ci + 1) H
-    const int centre = ci * g.ratio;
+    const int centre = ci * g.ratio - g.off[0];   // in this rank's indices
     const int lo = centre - g.ratio + 1 > 0 ? centre - g.ratio + 1 : 0;
     const int hi = centre + g.ratio - 1 < nf0 - 1 ? centre + g.ratio - 1 : nf0 - 1;
     double acc[2] = {0.0, 0.0};
     for (int i = lo; i <= hi; ++i) {
       const double wt = 1.0 - fabs((double)(i - centre)) * inv_h;
-      acc[SPLIT ? cc_part(i, ci, colour, g.ratio) : 0] += wt * xs[i];
+      acc[SPLIT ? cc_part(i + g.off[0], ci, colour, g.ratio) : 0] += wt * xs[i];
     }
     if (SPLIT) { X1[2 * (line * g.m[0] + ci)] = acc[0]; X1[2 * (line * g.m[0] + ci) + 1] = acc[1]; }
     else X1[line * g.m[0] + ci] = acc[0];
@@ -179,12 +188,12 @@ k_cc_restrict_x(int64_t nlines, CcDims g, int colour, const int32_t *__restrict_
 }
 // generic middle pass: out[o][co][in] = sum_f w(f, co) in[o][f][in]   (axis of fine length nfa -> ma coarse nodes)
 __global__ void __launch_bounds__(256)
-k_cc_restrict_axis(int64_t total, int64_t inner, int64_t nfa, int ma, int ratio, const double *__restrict__ in,
+k_cc_restrict_axis(int64_t total, int64_t inner, int64_t nfa, int ma, int ratio, int off, const double *__restrict__ in,
                    double *__restrict__ out) {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int64_t q = t % inner, o = t / (inner * ma);
-  const int co = (int)((t / inner) % ma), centre = co * ratio;
+  const int co = (int)((t / inner) % ma), centre = co * ratio - off;
   const int lo = centre - ratio + 1 > 0 ? centre - ratio + 1 : 0;
   const int hi = centre + ratio - 1 < (int)nfa - 1 ? centre + ratio - 1 : (int)nfa - 1;
   const double inv_h = 1.0 / (double)ratio;
@@ -202,14 +211,14 @@ __global__ void k_cc_expand(int64_t total, const int32_t *__restrict__ cmap, con
 }
 // middle pass of R: out[o][f][in] = sum_{two co} w(f, co) in[o][co][in]
 __global__ void __launch_bounds__(256)
-k_cc_prolong_axis(int64_t total, int64_t inner, int64_t nfa, int ma, int ratio, const double *__restrict__ in,
+k_cc_prolong_axis(int64_t total, int64_t inner, int64_t nfa, int ma, int ratio, int off, const double *__restrict__ in,
                   double *__restrict__ out) {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int64_t q = t % inner, f = (t / inner) % nfa, o = t / (inner * nfa);
   int c[2];
   double w[2];
-  cc_axis(f, ratio, ma, c, w);
+  cc_axis(f + off, ratio, ma, c, w);
   out[t] = w[0] * in[(o * ma + c[0]) * inner + q] + w[1] * in[(o * ma + c[1]) * inner + q];
 }
 // last pass of R, fused with the scaling and the sum: vout[pos] += D[pos] * sum_{two ci} w X1[blk][k][j][ci]
@@ -223,7 +232,7 @@ k_cc_prolong_x_add(int64_t total, CcDims g, const int32_t *__restrict__ cpos, co
   const int64_t i = f % g.nf[0], line = f / g.nf[0];
   int c[2];
   double w[2];
-  cc_axis(i, g.ratio, g.m[0], c, w);
+  cc_axis(i + g.off[0], g.ratio, g.m[0], c, w);
   vout[p] += dpos[p] * (w[0] * X1[line * g.m[0] + c[0]] + w[1] * X1[line * g.m[0] + c[1]]);
 }
 
@@ -256,9 +265,10 @@ k_cc_probe_rows(int64_t n, int64_t nv, int bj, int nblk_u, CcDims g, int cz, con
     double sw[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      int c0 = idx[a] / g.ratio;
+      const int gi = idx[a] + g.off[a];
+      int c0 = gi / g.ratio;
       if (c0 > g.m[a] - 2) c0 = g.m[a] - 2 > 0 ? g.m[a] - 2 : 0;
-      const double t = (double)(idx[a] - c0 * g.ratio) * inv_h;
+      const double t = (double)(gi - c0 * g.ratio) * inv_h;
       const int k0 = c0 % 3, k1 = (c0 + 1) % 3;
       const double w1 = c0 + 1 < g.m[a] ? t : 0.0;
       sw[a][0] = (k0 == 0 ? 1.0 - t : 0.0) + (k1 == 0 ? w1 : 0.0);
@@ -307,18 +317,18 @@ __device__ __forceinline__ int cc_part_target(int co, int colour, int part) {
 }
 // out[((o ma + co) inner + q) 2 + part] = sum_f [part(f) == part] w(f, co) in[(o nfa + f) inner + q]
 __global__ void __launch_bounds__(256)
-k_cc_restrict_axis_split(int64_t total, int64_t inner, int64_t nfa, int ma, int ratio, int colour, const double *__restrict__ in,
-                         double *__restrict__ out) {
+k_cc_restrict_axis_split(int64_t total, int64_t inner, int64_t nfa, int ma, int ratio, int off, int colour,
+                         const double *__restrict__ in, double *__restrict__ out) {
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= total) return;
   const int64_t q = t % inner, o = t / (inner * ma);
-  const int co = (int)((t / inner) % ma), centre = co * ratio;
+  const int co = (int)((t / inner) % ma), centre = co * ratio - off;
   const int lo = centre - ratio + 1 > 0 ? centre - ratio + 1 : 0;
   const int hi = centre + ratio - 1 < (int)nfa - 1 ? centre + ratio - 1 : (int)nfa - 1;
   const double inv_h = 1.0 / (double)ratio;
   double acc[2] = {0.0, 0.0};
   for (int f = lo; f <= hi; ++f)
-    acc[cc_part(f, co, colour, ratio)] += (1.0 - fabs((double)(f - centre)) * inv_h) * in[(o * nfa + f) * inner + q];
+    acc[cc_part(f + off, co, colour, ratio)] += (1.0 - fabs((double)(f - centre)) * inv_h) * in[(o * nfa + f) * inner + q];
   out[2 * t] = acc[0];
   out[2 * t + 1] = acc[1];
 }
@@ -382,14 +392,15 @@ static inline dim3 cc_grid(int64_t n) { return dim3((unsigned)phx_div_up(std::ma
 // gc = R^T vin (compact coarse vector)
 static int coarse_restrict(phx_system *s, phx_coarse *c, const double *vin) {
   hipStream_t st = s->mesh->stream;
-  const CcDims g{{c->nf[0], c->nf[1], c->nf[2]}, {c->m[0], c->m[1], c->m[2]}, c->ratio, c->M};
+  if (s->n == 0) { PHX_HIP(hipMemsetAsync(c->gc, 0, sizeof(double) * (size_t)c->nc, st)); return PHX_OK; }
+  const CcDims g{{c->nf[0], c->nf[1], c->nf[2]}, {c->m[0], c->m[1], c->m[2]}, c->ratio, c->M, {c->off[0], c->off[1], c->off[2]}};
   const int64_t nb = c->nblk_u;
   const int64_t nl = nb * c->nf[2] * c->nf[1];
   k_cc_restrict_x<false, false><<<dim3((unsigned)phx_div_up(nl, 4)), dim3(256), sizeof(double) * 4 * (size_t)c->nf[0], st>>>(nl, g, 0, c->cpos, vin, c->X1);
   const int64_t t2 = nb * c->nf[2] * c->m[1] * c->m[0];
-  k_cc_restrict_axis<<<cc_grid(t2), dim3(256), 0, st>>>(t2, c->m[0], c->nf[1], c->m[1], c->ratio, c->X1, c->X2);
+  k_cc_restrict_axis<<<cc_grid(t2), dim3(256), 0, st>>>(t2, c->m[0], c->nf[1], c->m[1], c->ratio, c->off[1], c->X1, c->X2);
   const int64_t t3 = nb * c->M;
-  k_cc_restrict_axis<<<cc_grid(t3), dim3(256), 0, st>>>(t3, (int64_t)c->m[0] * c->m[1], c->nf[2], c->m[2], c->ratio, c->X2, c->X3);
+  k_cc_restrict_axis<<<cc_grid(t3), dim3(256), 0, st>>>(t3, (int64_t)c->m[0] * c->m[1], c->nf[2], c->m[2], c->ratio, c->off[2], c->X2, c->X3);
   k_cc_compact<<<cc_grid(c->nc), dim3(256), 0, st>>>(c->nc, c->node_of, c->X3, c->gc);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
@@ -399,52 +410,70 @@ static int coarse_restrict(phx_system *s, phx_coarse *c, const double *vin) {
 static int coarse_restrict_split(phx_system *s, phx_coarse *c, int col3, const double *vin, bool direct, double *X1s, double *X2s,
                                  double *X3s) {
   hipStream_t st = s->mesh->stream;
-  const CcDims g{{c->nf[0], c->nf[1], c->nf[2]}, {c->m[0], c->m[1], c->m[2]}, c->ratio, c->M};
+  const CcDims g{{c->nf[0], c->nf[1], c->nf[2]}, {c->m[0], c->m[1], c->m[2]}, c->ratio, c->M, {c->off[0], c->off[1], c->off[2]}};
   const int64_t nb = c->nblk_u;
   const int64_t nl = nb * c->nf[2] * c->nf[1];
   if (direct) k_cc_restrict_x<true, true><<<dim3((unsigned)phx_div_up(nl, 4)), dim3(256), sizeof(double) * 4 * (size_t)c->nf[0], st>>>(nl, g, col3 % 3, c->cpos, vin, X1s);
   else k_cc_restrict_x<true, false><<<dim3((unsigned)phx_div_up(nl, 4)), dim3(256), sizeof(double) * 4 * (size_t)c->nf[0], st>>>(nl, g, col3 % 3, c->cpos, vin, X1s);
   const int64_t t2 = nb * c->nf[2] * c->m[1] * c->m[0] * 2;
-  k_cc_restrict_axis_split<<<cc_grid(t2), dim3(256), 0, st>>>(t2, (int64_t)c->m[0] * 2, c->nf[1], c->m[1], c->ratio, (col3 / 3) % 3, X1s, X2s);
+  k_cc_restrict_axis_split<<<cc_grid(t2), dim3(256), 0, st>>>(t2, (int64_t)c->m[0] * 2, c->nf[1], c->m[1], c->ratio, c->off[1], (col3 / 3) % 3, X1s, X2s);
   const int64_t t3 = nb * c->M * 4;
-  k_cc_restrict_axis_split<<<cc_grid(t3), dim3(256), 0, st>>>(t3, (int64_t)c->m[0] * c->m[1] * 4, c->nf[2], c->m[2], c->ratio, col3 / 9, X2s, X3s);
+  k_cc_restrict_axis_split<<<cc_grid(t3), dim3(256), 0, st>>>(t3, (int64_t)c->m[0] * c->m[1] * 4, c->nf[2], c->m[2], c->ratio, c->off[2], col3 / 9, X2s, X3s);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
 }
 
-// vout += D R Ac^-1 R^T vin
-static int coarse_apply_add(phx_system *s, phx_coarse *c, const double *vin, double *vout) {
-  if (!c || c->nc == 0 || s->n == 0) return PHX_OK;
+// vout += D R zc,  zc = Ac^-1 gc  (gc: the restricted vector, all-reduced by the driver on a partitioned box)
+static int coarse_apply_end(phx_system *s, phx_coarse *c, double *vout) {
+  if (!c || c->nc == 0) return PHX_OK;
   hipStream_t st = s->mesh->stream;
-  PHX_CHECK(coarse_restrict(s, c, vin));
+  if (s->n == 0) return PHX_OK;   // a slab outside the domain: nothing to prolong onto
   k_cc_gemv<<<dim3((unsigned)phx_div_up(c->nc, 4)), dim3(256), 0, st>>>(c->nc, c->Ainv, c->gc, c->zc);
-  const CcDims g{{c->nf[0], c->nf[1], c->nf[2]}, {c->m[0], c->m[1], c->m[2]}, c->ratio, c->M};
+  const CcDims g{{c->nf[0], c->nf[1], c->nf[2]}, {c->m[0], c->m[1], c->m[2]}, c->ratio, c->M, {c->off[0], c->off[1], c->off[2]}};
   const int64_t nb = c->nblk_u;
   const int64_t t3 = nb * c->M;
   k_cc_expand<<<cc_grid(t3), dim3(256), 0, st>>>(t3, c->cmap, c->zc, c->X3);
   const int64_t t2 = nb * c->nf[2] * c->m[1] * c->m[0];
-  k_cc_prolong_axis<<<cc_grid(t2), dim3(256), 0, st>>>(t2, (int64_t)c->m[0] * c->m[1], c->nf[2], c->m[2], c->ratio, c->X3, c->X2);
+  k_cc_prolong_axis<<<cc_grid(t2), dim3(256), 0, st>>>(t2, (int64_t)c->m[0] * c->m[1], c->nf[2], c->m[2], c->ratio, c->off[2], c->X3, c->X2);
   const int64_t t1 = nb * c->nf[2] * c->nf[1] * c->m[0];
-  k_cc_prolong_axis<<<cc_grid(t1), dim3(256), 0, st>>>(t1, c->m[0], c->nf[1], c->m[1], c->ratio, c->X2, c->X1);
+  k_cc_prolong_axis<<<cc_grid(t1), dim3(256), 0, st>>>(t1, c->m[0], c->nf[1], c->m[1], c->ratio, c->off[1], c->X2, c->X1);
   const int64_t tf = nb * s->mesh->nv;
   k_cc_prolong_x_add<<<cc_grid(tf), dim3(256), 0, st>>>(tf, g, c->cpos, c->dpos, c->X1, vout);
   PHX_HIP(hipGetLastError());
   return PHX_OK;
 }
+// vout += D R Ac^-1 R^T vin on one rank
+static int coarse_apply_add(phx_system *s, phx_coarse *c, const double *vin, double *vout) {
+  if (!c || c->nc == 0 || s->n == 0 || c->dist) return PHX_OK;
+  PHX_CHECK(coarse_restrict(s, c, vin));
+  return coarse_apply_end(s, c, vout);
+}
+
+__global__ void k_cc_flags_to_f64(int64_t n, const uint8_t *__restrict__ f, double *__restrict__ d) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) d[i] = f[i] ? 1.0 : 0.0;
+}
 
 // Builds the coarse correction of `s` (*out = nullptr when it does not apply: not a generated box, rocSOLVER missing,
-// a singular coarse matrix, PHX_EL_COARSE=0).
-static int coarse_build(phx_system *s, int nblk, phx_coarse **out) {
+// a singular coarse matrix, PHX_OPT_EL_COARSE = 0).  `reduce` (partitioned boxes): in-place sum of a device buffer of
+// doubles over the ranks, enqueued on the solver stream -- EVERY rank then walks the same sequence of reductions
+// (a veto of one rank switches the correction off on all of them).
+typedef std::function<int(double *, size_t)> CcReduce;
+static int coarse_build(phx_system *s, int nblk, phx_coarse **out, const CcReduce *reduce = nullptr) {
   *out = nullptr;
   phx_mesh *m = s->mesh;
   hipStream_t st = m->stream;
   static const int env_req = getenv("PHX_EL_COARSE") ? atoi(getenv("PHX_EL_COARSE")) : -2;   // A/B aid: overrides the option
   const int req = env_req != -2 ? env_req : m->el_coarse;   // -1: automatic, 0: off, > 0: the ratio H / h
-  if (req == 0 || !m->is_box || m->is_submesh || !s->rowptr || s->n == 0) return PHX_OK;
+  // decided from numbers every rank shares
+  if (req == 0 || !m->is_box || m->is_submesh) return PHX_OK;
+  if (!reduce && (!s->rowptr || s->n == 0)) return PHX_OK;
   const int d = m->gdim;
-  const int64_t nmax = std::max(m->box_n[0], std::max(m->box_n[1], d == 3 ? m->box_n[2] : (int64_t)1));
-  // automatic: the 162 (2-D: 36) probing products and the inverse cost about 100 iterations of the plain loop, which
-  // is what the correction saves from ~64 cubes per axis on (48^3: 176 -> 88 iterations but 52 -> 73 ms)
+  int64_t nglob[3];
+  for (int a = 0; a < 3; ++a) nglob[a] = a < d ? (m->box_nglob[a] > 0 ? m->box_nglob[a] : m->box_n[a]) : 1;
+  const int64_t nmax = std::max(nglob[0], std::max(nglob[1], nglob[2]));
+  // automatic: the probing passes and the inverse cost about as much as 50-100 iterations of the plain loop, which is
+  // what the correction saves from ~64 cubes per axis on (48^3: 176 -> 88 iterations but 52 -> 73 ms)
   if (req < 0 && nmax < 80) return PHX_OK;
   // coarse cells per axis: 8 up to 128 cubes (~3 000 coarse DoFs: the dense inverse takes 30 ms), growing to 13 at 256
   // (~10 000: 0.25 s) -- measured at 256^3: H = 16 h 104 iterations / 2.9 s, 20 h 112 / 2.3 s, 24 h 152 / 2.7 s
@@ -452,82 +481,106 @@ static int coarse_build(phx_system *s, int nblk, phx_coarse **out) {
   int ratio = req > 0 ? req : (int)ceil((double)nmax / cells);
   if (ratio < 5) ratio = 5;   // the split of the probing passes needs H > 4 h
   if (nmax < 2 * ratio) return PHX_OK;   // nothing coarser than the mesh itself
+  // from here on a partitioned box must reach the veto reduction on every rank
+  bool veto = false;
   RocSolver &rs = rocsolver();
   if (!rs.ok) {
     static bool warned = false;
     if (!warned) fprintf(stderr, "phifem_hip: librocsolver / librocblas not loadable: elasticity solves run without the coarse correction\n");
     warned = true;
-    return PHX_OK;
+    if (!reduce) return PHX_OK;
+    veto = true;
   }
   phx_coarse *c = new phx_coarse();
   auto fail = [&](int code) { coarse_free(c); return code; };
-  c->d = d; c->nblk_u = 2 * d; c->ratio = ratio;
+  c->d = d; c->nblk_u = 2 * d; c->ratio = ratio; c->dist = reduce != nullptr;
   c->M = 1;
   for (int a = 0; a < 3; ++a) {
     c->nf[a] = a < d ? m->box_n[a] + 1 : 1;
-    c->m[a] = a < d ? (int)phx_div_up(m->box_n[a], ratio) + 1 : 1;
+    c->off[a] = a < d ? (int)m->box_off[a] : 0;
+    c->m[a] = a < d ? (int)phx_div_up(nglob[a], ratio) + 1 : 1;
     c->M *= c->m[a];
   }
-  const CcDims g{{c->nf[0], c->nf[1], c->nf[2]}, {c->m[0], c->m[1], c->m[2]}, c->ratio, c->M};
+  const CcDims g{{c->nf[0], c->nf[1], c->nf[2]}, {c->m[0], c->m[1], c->m[2]}, c->ratio, c->M, {c->off[0], c->off[1], c->off[2]}};
   const int64_t nv = m->nv, n = s->n, nb = c->nblk_u, tf = nb * nv;
-  if (phx_malloc(&c->cpos, sizeof(int32_t) * (size_t)tf) != hipSuccess || phx_malloc(&c->dpos, sizeof(double) * (size_t)n) != hipSuccess ||
+  const bool rows = n > 0 && s->rowptr;   // false: a slab outside the domain, it only joins the reductions
+  if (n > 0 && (!s->rowptr || !s->bj)) veto = true;   // without the vertex blocks phat aliases p: nothing to add a correction to
+  if (phx_malloc(&c->cpos, sizeof(int32_t) * (size_t)tf) != hipSuccess || phx_malloc(&c->dpos, sizeof(double) * (size_t)std::max<int64_t>(n, 1)) != hipSuccess ||
       phx_malloc(&c->cmap, sizeof(int32_t) * (size_t)(nb * c->M)) != hipSuccess)
     return fail(PHX_ERR_HIP);
   PHX_HIP(hipMemsetAsync(c->cpos, 0xff, sizeof(int32_t) * (size_t)tf, st));
-  k_cc_positions<<<cc_grid(n), dim3(256), 0, st>>>(n, nv, c->nblk_u, d, s->full_of_active, s->rowptr, s->iperm, s->diag, c->cpos, c->dpos);
+  if (rows) k_cc_positions<<<cc_grid(n), dim3(256), 0, st>>>(n, nv, c->nblk_u, d, s->full_of_active, s->rowptr, s->iperm, s->diag, s->own, c->cpos, c->dpos);
   uint8_t *used = nullptr;
-  if (phx_malloc(&used, (size_t)(nb * c->M)) != hipSuccess) return fail(PHX_ERR_HIP);
+  double *usedf = nullptr;
+  if (phx_malloc(&used, (size_t)(nb * c->M)) != hipSuccess || phx_malloc(&usedf, sizeof(double) * (size_t)(nb * c->M)) != hipSuccess) {
+    (void)phx_free(used); (void)phx_free(usedf);
+    return fail(PHX_ERR_HIP);
+  }
   PHX_HIP(hipMemsetAsync(used, 0, (size_t)(nb * c->M), st));
   k_cc_used<<<cc_grid(tf), dim3(256), 0, st>>>(tf, nv, g, c->cpos, used);
-  std::vector<uint8_t> hused((size_t)(nb * c->M));
-  PHX_HIP(hipMemcpyAsync(hused.data(), used, hused.size(), hipMemcpyDeviceToHost, st));
-  PHX_HIP(hipStreamSynchronize(st));
-  PHX_HIP(phx_free(used));
+  k_cc_flags_to_f64<<<cc_grid(nb * c->M), dim3(256), 0, st>>>(nb * c->M, used, usedf);
+  int rrc = reduce ? (*reduce)(usedf, (size_t)(nb * c->M)) : PHX_OK;
+  std::vector<double> hused((size_t)(nb * c->M));
+  if (rrc == PHX_OK && hipMemcpyAsync(hused.data(), usedf, sizeof(double) * hused.size(), hipMemcpyDeviceToHost, st) != hipSuccess) rrc = PHX_ERR_HIP;
+  if (rrc == PHX_OK && hipStreamSynchronize(st) != hipSuccess) rrc = PHX_ERR_HIP;
+  (void)phx_free(used); (void)phx_free(usedf);
+  if (rrc != PHX_OK) return fail(rrc);
   std::vector<int32_t> hmap(hused.size(), -1), hnode;
   for (size_t q = 0; q < hused.size(); ++q)
-    if (hused[q]) { hmap[q] = (int32_t)hnode.size(); hnode.push_back((int32_t)q); }
+    if (hused[q] > 0.0) { hmap[q] = (int32_t)hnode.size(); hnode.push_back((int32_t)q); }
   c->nc = (int)hnode.size();
   static const int nc_max = getenv("PHX_EL_COARSE_MAX") ? atoi(getenv("PHX_EL_COARSE_MAX")) : 24000;
-  if (c->nc == 0 || c->nc > nc_max) { coarse_free(c); return PHX_OK; }
+  if (c->nc == 0 || c->nc > nc_max) { coarse_free(c); return PHX_OK; }   // the same numbers on every rank
   const int nc = c->nc;
   const int64_t t1 = nb * c->nf[2] * c->nf[1] * c->m[0], t2 = nb * c->nf[2] * c->m[1] * c->m[0], t3 = nb * c->M;
-  if (phx_malloc(&c->node_of, sizeof(int32_t) * (size_t)nc) != hipSuccess || phx_malloc(&c->Ainv, sizeof(double) * (size_t)nc * nc) != hipSuccess ||
-      phx_malloc(&c->X1, sizeof(double) * (size_t)t1) != hipSuccess || phx_malloc(&c->X2, sizeof(double) * (size_t)t2) != hipSuccess ||
-      phx_malloc(&c->X3, sizeof(double) * (size_t)t3) != hipSuccess || phx_malloc(&c->gc, sizeof(double) * (size_t)nc) != hipSuccess ||
-      phx_malloc(&c->zc, sizeof(double) * (size_t)nc) != hipSuccess)
-    return fail(PHX_ERR_HIP);
-  PHX_HIP(hipMemcpyAsync(c->cmap, hmap.data(), sizeof(int32_t) * hmap.size(), hipMemcpyHostToDevice, st));
-  PHX_HIP(hipMemcpyAsync(c->node_of, hnode.data(), sizeof(int32_t) * hnode.size(), hipMemcpyHostToDevice, st));
-  PHX_HIP(hipMemsetAsync(c->Ainv, 0, sizeof(double) * (size_t)nc * nc, st));
-  // ---- Ac by probing with the solver's operator (A D^-1 in solver order)
-  double *wv = nullptr, *tv = nullptr;
-  if (phx_malloc(&wv, sizeof(double) * (size_t)n) != hipSuccess || phx_malloc(&tv, sizeof(double) * (size_t)n) != hipSuccess) {
-    (void)phx_free(wv); (void)phx_free(tv);
-    return fail(PHX_ERR_HIP);
-  }
-  const int ncol = d == 3 ? 27 : 9;
-  int rc = PHX_OK;
-  static const bool lumped = getenv("PHX_EL_COARSE_LUMPED") && atoi(getenv("PHX_EL_COARSE_LUMPED")) != 0;
-  double *X1s = nullptr, *X2s = nullptr, *X3s = nullptr;
-  if (!lumped && (phx_malloc(&X1s, sizeof(double) * (size_t)t1 * 2) != hipSuccess || phx_malloc(&X2s, sizeof(double) * (size_t)t2 * 4) != hipSuccess ||
-                  phx_malloc(&X3s, sizeof(double) * (size_t)t3 * 8) != hipSuccess)) {
-    (void)phx_free(wv); (void)phx_free(tv); (void)phx_free(X1s); (void)phx_free(X2s); (void)phx_free(X3s);
-    return fail(PHX_ERR_HIP);
-  }
-  // nine colours of a block from one pass over the CSR copy when their images fit (nine vectors in full lattice order:
-  // 7 GB at 256^3), else one product with the solver's SpMV per (block, colour)
-  double *T = nullptr;
+  double *wv = nullptr, *tv = nullptr, *X1s = nullptr, *X2s = nullptr, *X3s = nullptr, *T = nullptr, *vflag = nullptr;
   int32_t *f32 = nullptr;
-  static const bool by_spmv = getenv("PHX_EL_COARSE_SPMV") && atoi(getenv("PHX_EL_COARSE_SPMV")) != 0;   // A/B aid
-  if (!lumped && !by_spmv && (int64_t)c->nblk_u * nv < INT32_MAX && s->nent < INT32_MAX) {
+  auto drop_scratch = [&]() {
+    (void)phx_free(wv); (void)phx_free(tv); (void)phx_free(X1s); (void)phx_free(X2s); (void)phx_free(X3s); (void)phx_free(T);
+    (void)phx_free(f32); (void)phx_free(vflag);
+  };
+  static const bool lumped = getenv("PHX_EL_COARSE_LUMPED") && atoi(getenv("PHX_EL_COARSE_LUMPED")) != 0;   // A/B aids, one rank
+  static const bool by_spmv = getenv("PHX_EL_COARSE_SPMV") && atoi(getenv("PHX_EL_COARSE_SPMV")) != 0;
+  bool mem_ok = phx_malloc(&c->node_of, sizeof(int32_t) * (size_t)nc) == hipSuccess && phx_malloc(&c->Ainv, sizeof(double) * (size_t)nc * nc) == hipSuccess &&
+                phx_malloc(&c->X1, sizeof(double) * (size_t)t1) == hipSuccess && phx_malloc(&c->X2, sizeof(double) * (size_t)t2) == hipSuccess &&
+                phx_malloc(&c->X3, sizeof(double) * (size_t)t3) == hipSuccess && phx_malloc(&c->gc, sizeof(double) * (size_t)nc) == hipSuccess &&
+                phx_malloc(&c->zc, sizeof(double) * (size_t)nc) == hipSuccess && phx_malloc(&vflag, sizeof(double)) == hipSuccess &&
+                phx_malloc(&X1s, sizeof(double) * (size_t)t1 * 2) == hipSuccess && phx_malloc(&X2s, sizeof(double) * (size_t)t2 * 4) == hipSuccess &&
+                phx_malloc(&X3s, sizeof(double) * (size_t)t3 * 8) == hipSuccess;
+  // nine colours of a block from one pass over the CSR copy when their images fit (nine vectors in full lattice order:
+  // 7 GB at 256^3), else -- one rank only -- one product with the solver's SpMV per (block, colour)
+  if (mem_ok && rows && !(lumped && !reduce) && !(by_spmv && !reduce) && (int64_t)c->nblk_u * nv < INT32_MAX && s->nent < INT32_MAX) {
     size_t fr = 0, tot = 0;
     (void)hipMemGetInfo(&fr, &tot);
     const size_t need = sizeof(double) * 9 * (size_t)tf + sizeof(int32_t) * (size_t)n;
-    if (need + (size_t(4) << 30) < fr + 0 && phx_malloc(&f32, sizeof(int32_t) * (size_t)n) == hipSuccess) {
+    if (need + (size_t(4) << 30) < fr && phx_malloc(&f32, sizeof(int32_t) * (size_t)n) == hipSuccess) {
       if (phx_malloc(&T, sizeof(double) * 9 * (size_t)tf) != hipSuccess) { (void)hipGetLastError(); (void)phx_free(f32); f32 = nullptr; T = nullptr; }
     }
   }
-  if (T) {
+  if (mem_ok && rows && !T) {
+    if (reduce) veto = true;   // the SpMV probes would need the halo of every probing vector
+    else mem_ok = phx_malloc(&wv, sizeof(double) * (size_t)n) == hipSuccess && phx_malloc(&tv, sizeof(double) * (size_t)n) == hipSuccess;
+  }
+  if (!mem_ok) { (void)hipGetLastError(); if (!reduce) { drop_scratch(); return fail(PHX_ERR_HIP); } veto = true; }
+  if (reduce) {   // one veto and nobody corrects
+    const double v = veto ? 1.0 : 0.0;
+    double hv = 0.0;
+    int rc2 = vflag ? PHX_OK : PHX_ERR_HIP;
+    if (rc2 == PHX_OK && hipMemcpyAsync(vflag, &v, sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) rc2 = PHX_ERR_HIP;
+    if (rc2 == PHX_OK) rc2 = (*reduce)(vflag, 1);
+    if (rc2 == PHX_OK && hipMemcpyAsync(&hv, vflag, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) rc2 = PHX_ERR_HIP;
+    if (rc2 == PHX_OK && hipStreamSynchronize(st) != hipSuccess) rc2 = PHX_ERR_HIP;
+    if (rc2 != PHX_OK) { drop_scratch(); return fail(rc2); }
+    if (hv > 0.0) { drop_scratch(); coarse_free(c); return PHX_OK; }
+  }
+  int rc = PHX_OK;
+  if (hipMemcpyAsync(c->cmap, hmap.data(), sizeof(int32_t) * hmap.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(c->node_of, hnode.data(), sizeof(int32_t) * hnode.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemsetAsync(c->Ainv, 0, sizeof(double) * (size_t)nc * nc, st) != hipSuccess)
+    rc = PHX_ERR_HIP;
+  // ---- Ac (this rank's rows' share of it) by probing
+  const int ncol = d == 3 ? 27 : 9;
+  if (T && rc == PHX_OK) {
     k_cc_f32<<<cc_grid(n), dim3(256), 0, st>>>(n, s->full_of_active, f32);
     for (int bj = 0; bj < c->nblk_u && rc == PHX_OK; ++bj) {
       for (int cz = 0; cz < 3 && cz < c->m[2] && rc == PHX_OK; ++cz) {
@@ -540,10 +593,8 @@ static int coarse_build(phx_system *s, int nblk, phx_coarse **out) {
         }
       }
     }
-    if (rc == PHX_OK && hipStreamSynchronize(st) != hipSuccess) rc = PHX_ERR_HIP;
-    (void)phx_free(T); (void)phx_free(f32);
   }
-  for (int bj = 0; bj < c->nblk_u && rc == PHX_OK && !T; ++bj) {
+  for (int bj = 0; bj < c->nblk_u && rc == PHX_OK && !T && rows; ++bj) {
     for (int col = 0; col < ncol && rc == PHX_OK; ++col) {
       // a colour no node of the lattice carries probes nothing
       bool any = true;
@@ -563,10 +614,11 @@ static int coarse_build(phx_system *s, int nblk, phx_coarse **out) {
     }
   }
   if (rc == PHX_OK && hipGetLastError() != hipSuccess) rc = PHX_ERR_HIP;
+  if (rc == PHX_OK && reduce) rc = (*reduce)(c->Ainv, (size_t)nc * nc);
   if (rc == PHX_OK && hipStreamSynchronize(st) != hipSuccess) rc = PHX_ERR_HIP;
-  (void)phx_free(wv); (void)phx_free(tv); (void)phx_free(X1s); (void)phx_free(X2s); (void)phx_free(X3s);
+  drop_scratch();
   if (rc != PHX_OK) return fail(rc);
-  // ---- dense inverse
+  // ---- dense inverse (every rank inverts the same matrix)
   int *ipiv = nullptr, *info = nullptr, hinfo[2] = {0, 0};
   if (phx_malloc(&ipiv, sizeof(int) * (size_t)nc) != hipSuccess || phx_malloc(&info, sizeof(int) * 2) != hipSuccess) {
     (void)phx_free(ipiv); (void)phx_free(info);
@@ -578,7 +630,7 @@ static int coarse_build(phx_system *s, int nblk, phx_coarse **out) {
   good = good && hipMemcpyAsync(hinfo, info, sizeof(hinfo), hipMemcpyDeviceToHost, st) == hipSuccess;
   good = good && hipStreamSynchronize(st) == hipSuccess;
   (void)phx_free(ipiv); (void)phx_free(info);
-  if (!good || hinfo[0] != 0 || hinfo[1] != 0) { coarse_free(c); return PHX_OK; }   // singular coarse matrix: the vertex blocks alone
+  if (!good || hinfo[0] != 0 || hinfo[1] != 0) { coarse_free(c); return PHX_OK; }   // singular coarse matrix (the same on every rank): the vertex blocks alone
   *out = c;
   return PHX_OK;
 }

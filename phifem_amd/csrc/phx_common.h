@@ -101,6 +101,7 @@ struct phx_mesh {
   int64_t box_n[3] = {0, 0, 0};
   double box_h[3] = {0.0, 0.0, 0.0};  // exact lattice spacing (hi - lo) / n_global per axis
   int64_t box_off[3] = {0, 0, 0};     // cube offset of this (slab of a) box in the global box
+  int64_t box_nglob[3] = {0, 0, 0};   // cubes per axis of the global box
   int64_t *v2c_ptr = nullptr;  // [nv+1]
   int32_t *v2c_idx = nullptr;  // [nc*nvpc]
   bool is_box = false;
@@ -271,7 +272,8 @@ struct phx_system {
   int el_nblk = 0;                 // > 0: block-major system with this many blocks of nv entries (27 / 14)
   struct phx_blockjac *bj = nullptr;
   bool bj_tried = false;
-  struct phx_coarse *cc = nullptr; // coarse correction on top of the vertex blocks (phx_coarse.inc.hip), single rank
+  struct phx_coarse *cc = nullptr; // coarse correction on top of the vertex blocks (phx_coarse.inc.hip)
+  bool cc_tried = false;
   // PHX_OPT_DETERMINISTIC: every block of a dot-product kernel leaves its partial sum in its own entry of `dpart`
   // ([2][dpart_cap]) instead of adding it to a slot atomically; k_fold_partials sums them in a fixed order
   double *dpart = nullptr;

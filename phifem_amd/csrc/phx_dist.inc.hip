@@ -264,6 +264,23 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
     // ranks exchange the same vectors and test convergence at the same iterations
     const bool pc_all = s->scal_h[R_OFF + R_RR] == 0.0;
     if (!pc_all) PHX_CHECK(phx_krylov_precond_disable(s));
+    // interface elasticity: the coarse correction on top of the vertex blocks, built collectively (phx_coarse.inc.hip);
+    // a rank without rows of its own still joins the reductions
+    if (s->el_nblk > 0 && m->precond != 0 && !s->cc && !s->cc_tried) {
+      s->cc_tried = true;
+      const CcReduce red = [&](double *buf, size_t count) -> int {
+        if (c->nranks == 1) return PHX_OK;
+        PHX_NCCL(g_nccl.AllReduce(buf, buf, count, PHX_NCCL_FLOAT64, PHX_NCCL_SUM, c->comm, st));
+        return PHX_OK;
+      };
+      PHX_CHECK(coarse_build(s, s->el_nblk, &s->cc, &red));
+    }
+    const bool coarse = s->cc != nullptr && s->cc->dist;
+    auto coarse_step = [&](int ph_restrict, int ph_add) -> int {
+      PHX_CHECK(phx_krylov_phase(s, ph_restrict));
+      if (c->nranks > 1) PHX_NCCL(g_nccl.AllReduce(s->cc->gc, s->cc->gc, (size_t)s->cc->nc, PHX_NCCL_FLOAT64, PHX_NCCL_SUM, c->comm, st));
+      return phx_krylov_phase(s, ph_add);
+    };
     const KrVecs V = kr_vecs(s);  // after the vote: the preconditioner decides where phat / shat live
     const bool exact = s->precond_state == 1 && s->precond->dist;   // the same on every rank (set up from all-reduced numbers)
     const double bb = s->scal_h[S_BB];
@@ -276,6 +293,7 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
       while (bb != 0.0 && it < max_iter) {
         PHX_CHECK(phx_krylov_phase(s, 7));
         if (exact) { PHX_CHECK(allgather_carries(s, c)); PHX_CHECK(phx_krylov_phase(s, 9)); }
+        if (coarse) PHX_CHECK(coarse_step(30, 31));
         if (overlap) {
           PHX_CHECK(halo_begin(s, c, H, V.phat, true));
           PHX_CHECK(phx_krylov_phase(s, 20));
@@ -289,6 +307,7 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
         PHX_CHECK(phx_krylov_phase(s, 3));
         PHX_CHECK(phx_krylov_phase(s, 8));
         if (exact) { PHX_CHECK(allgather_carries(s, c)); PHX_CHECK(phx_krylov_phase(s, 10)); }
+        if (coarse) PHX_CHECK(coarse_step(32, 33));
         if (overlap) {
           PHX_CHECK(halo_begin(s, c, H, V.shat, true));
           PHX_CHECK(phx_krylov_phase(s, 40));

@@ -826,6 +826,7 @@ extern "C" int phx_mesh_create_box(int gdim, const double *lo, const double *hi,
   m->box_nlast = b.n[gdim - 1];
   for (int a = 0; a < 3; ++a) m->box_n[a] = a < gdim ? b.n[a] : 1;
   for (int a = 0; a < 3; ++a) m->box_off[a] = a < gdim ? b.off[a] : 0;
+  for (int a = 0; a < 3; ++a) m->box_nglob[a] = a < gdim ? b.nglob[a] : 1;
   for (int a = 0; a < gdim; ++a) m->box_h[a] = (b.hi[a] - b.lo[a]) / (double)b.nglob[a];
   PHX_HIP(phx_malloc(&m->x, sizeof(double) * (size_t)nv * gdim));
   PHX_HIP(phx_malloc(&m->cells, sizeof(int32_t) * (size_t)nc * (gdim + 1)));

@@ -1641,7 +1641,7 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       s->bj_tried = true;
       PHX_CHECK(blockjac_build(s, s->el_nblk, &s->bj));   // nullptr when a vertex block is singular: scalar Jacobi then
       // coarse correction on top of the vertex blocks (one rank; a partitioned box keeps the blocks alone)
-      if (s->bj && !s->own && !s->kr_work) PHX_CHECK(coarse_build(s, s->el_nblk, &s->cc));
+      if (s->bj && !s->own && !s->kr_work && !s->cc_tried) { s->cc_tried = true; PHX_CHECK(coarse_build(s, s->el_nblk, &s->cc)); }
     }
     if ((s->precond_state == 1 || s->u_unscaled || s->bj) && n > 0 && !s->kr_work) {
       // phat / shat: rows the preconditioner never writes (u rows another rank owns) stay zero
@@ -1708,6 +1708,12 @@ static int kr_phase(phx_system *s, int phase, int mode, int par) {
       else if (s->bj) { PHX_CHECK(blockjac_apply(s, s->bj, V.sv, V.shat)); PHX_CHECK(coarse_apply_add(s, s->cc, V.sv, V.shat)); }
       else if (s->u_unscaled && n > 0) k_jacobi_u<<<vec_grid(n), block, 0, st>>>(n, s->nu, s->perm, s->diag, V.sv, V.shat);
       break;
+    // --- coarse correction of a partitioned elasticity system: 30 / 32 restrict p / s (the driver all-reduces the coarse
+    // vector), 31 / 33 add the prolonged correction to phat / shat
+    case 30: if (s->cc) PHX_CHECK(coarse_restrict(s, s->cc, V.p)); break;
+    case 31: if (s->cc) PHX_CHECK(coarse_apply_end(s, s->cc, V.phat)); break;
+    case 32: if (s->cc) PHX_CHECK(coarse_restrict(s, s->cc, V.sv)); break;
+    case 33: if (s->cc) PHX_CHECK(coarse_apply_end(s, s->cc, V.shat)); break;
     // --- multi-GPU overlap: phases 2 / 4 in two launches (rows that read no halo entry | the rows that do)
     case 20:
       PHX_CHECK(prof_begin(s));

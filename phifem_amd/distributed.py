@@ -131,10 +131,11 @@ class ElasticitySlabProblem(SlabProblem):
     on an n x n x (nz_per_rank * world) Kuhn box of [-1.5,1.5]^3, slab-partitioned.  Tags without the
     single-layer rule and u_in = u_D on the box boundary, as in the demo (main.py:115-117,158-177)."""
 
-    def __init__(self, nxy, nz_per_rank, rank=0, world=1, device=0, rtol=1e-8, max_iter=200000):
+    def __init__(self, nxy, nz_per_rank, rank=0, world=1, device=0, rtol=1e-8, max_iter=200000, coarse=-1):
         super().__init__(nz_per_rank, rank=rank, world=world, device=device, rtol=rtol,
                          max_iter=max_iter, nxy=nxy)
         self.n_blocks = 27
+        self.coarse = coarse      # PHX_OPT_EL_COARSE: -1 automatic (on from 80 cubes per axis of the global box)
 
     def setup(self):
         import torch
@@ -162,7 +163,7 @@ class ElasticitySlabProblem(SlabProblem):
         torch.cuda.synchronize()
         # bit-reproducible assembly and dot products: the iteration count of this ill-conditioned system is then the
         # same on every run (it moved between 712 and 912 with atomics in arrival order)
-        self.solver = InterfaceElasticitySolver(self.mesh, deterministic=True)
+        self.solver = InterfaceElasticitySolver(self.mesh, deterministic=True, coarse=self.coarse)
         if self.world > 1:
             from .dist_solver import DistributedKrylov
             self.dk = DistributedKrylov(self)

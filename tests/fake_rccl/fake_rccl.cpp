@@ -139,14 +139,30 @@ static void host_fn(void *arg) {
   } else if (x->kind == 2) {
     const double *mine = (const double *)x->in;
     double *out = (double *)x->out;
-    for (size_t i = 0; i < x->count; ++i) s->red[c->rank][i] = mine[i];
-    barrier(c);
-    for (size_t i = 0; i < x->count; ++i) {
-      double sum = 0.0;
-      for (int r = 0; r < c->nranks; ++r) sum += s->red[r][i];   // rank order: every rank obtains the same bits
-      out[i] = sum;
+    if (x->count <= RED_MAX) {
+      for (size_t i = 0; i < x->count; ++i) s->red[c->rank][i] = mine[i];
+      barrier(c);
+      for (size_t i = 0; i < x->count; ++i) {
+        double sum = 0.0;
+        for (int r = 0; r < c->nranks; ++r) sum += s->red[r][i];   // rank order: every rank obtains the same bits
+        out[i] = sum;
+      }
+      barrier(c);   // nobody overwrites its deposit before everyone has read it
+    } else {
+      // long vectors (the coarse matrix of the elasticity solve): through the rank's own mailbox, a chunk at a time
+      const size_t chunk = MBOX_BYTES / sizeof(double);
+      for (size_t o = 0; o < x->count; o += chunk) {
+        const size_t k = x->count - o < chunk ? x->count - o : chunk;
+        memcpy(s->mbox[c->rank][c->rank], mine + o, k * sizeof(double));
+        barrier(c);
+        for (size_t i = 0; i < k; ++i) {
+          double sum = 0.0;
+          for (int r = 0; r < c->nranks; ++r) sum += ((const double *)s->mbox[r][r])[i];
+          out[o + i] = sum;
+        }
+        barrier(c);
+      }
     }
-    barrier(c);   // nobody overwrites its deposit before everyone has read it
   } else {
     memcpy(s->mbox[c->rank][c->rank], x->in, x->bytes);
     barrier(c);
@@ -260,7 +276,7 @@ int ncclRecv(void *buf, size_t count, int dtype, int peer, void *comm, hipStream
 
 // f64 SUM only (what the solver uses)
 int ncclAllReduce(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t st) {
-  if (dtype != 8 || op != 0 || count > RED_MAX) return fail("all-reduce: only f64 SUM of <= 64 values");
+  if (dtype != 8 || op != 0) return fail("all-reduce: only f64 SUM");
   Ctx *x = new Ctx{2, (FakeComm *)comm, -1, count * 8, count, nullptr, nullptr};
   return enqueue(x, send, recv, count * 8, count * 8, st);
 }

@@ -86,15 +86,18 @@ def test_slabs_on_one_gpu_match_single_mesh(world, tmp_path):
     assert np.abs(p - wref[nvg:]).max() <= 1e-7 * scale
 
 
-def _worker_el(rank, world, nxy, nzr, port, outdir):
+def _worker_el(rank, world, nxy, nzr, port, outdir, native=None, coarse=-1):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if native is not None:
+        os.environ["PHIFEM_NATIVE_LOOP"] = "1" if native else "0"
+        os.environ["PHX_RCCL_LIB"] = _FAKE
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from phifem_amd.distributed import ElasticitySlabProblem
-        prob = ElasticitySlabProblem(nxy, nzr, rank=rank, world=world, device=0, rtol=1e-11)
+        prob = ElasticitySlabProblem(nxy, nzr, rank=rank, world=world, device=0, rtol=1e-11, coarse=coarse)
         prob.setup()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -107,7 +110,8 @@ def _worker_el(rank, world, nxy, nzr, port, outdir):
         owned = (vplane >= lay["P0"]) & (vplane < lay["P1"])
         gid = np.arange(nv) + lay["k0"] * plane
         np.savez(os.path.join(outdir, f"e{rank}.npz"), gid=gid[owned], w=w[:, owned],
-                 relres=res["relres"], n_owned=res["n_active_owned"])
+                 relres=res["relres"], n_owned=res["n_active_owned"], it=res["iterations"], precond=res["precond"],
+                 path=prob.dk.path)
     finally:
         dist.destroy_process_group()
 
@@ -247,6 +251,47 @@ def test_native_loop_multi_rank_matches_single_mesh(world, native, exact, tmp_pa
     scale = np.abs(wref).max()
     assert np.abs(u - wref[:mesh.nv]).max() <= 1e-7 * scale
     assert np.abs(p - wref[mesh.nv:]).max() <= 1e-7 * scale
+
+
+@pytest.mark.skipif(not os.path.exists(_FAKE), reason="tests/fake_rccl/libfake_rccl.so not built (build())")
+@pytest.mark.parametrize("world", [2, 3])
+def test_elasticity_coarse_correction_across_slabs(world, tmp_path):
+    """The coarse correction of the elasticity solve on a partitioned box (native loop): the coarse lattice is the one
+    of the global box, the coarse matrix and every coarse right-hand side are summed over the ranks -- the SAME
+    preconditioner as on the single mesh, so the same solution in (about) the same number of iterations."""
+    import torch.multiprocessing as mp
+    import phifem_amd as P
+    from phifem_amd.mesh_scripts import NodalFunction
+    nxy, nzr, ratio = 24, 24 // world, 6
+    mp.spawn(_worker_el, args=(world, nxy, nzr, _free_port(), str(tmp_path), True, ratio), nprocs=world, join=True)
+    mesh = P.create_box([-1.5] * 3, [1.5] * 3, [nxy, nxy, nzr * world])
+    x = mesh.x
+    phi = 1.0 - (x ** 2).sum(axis=1)
+    f = np.stack([np.sin(x[:, 0]) + 0.2, np.cos(x[:, 1]), 0.5 * x[:, 2]], axis=1)
+    uD = 0.1 * np.stack([x[:, 0] * x[:, 1], np.sin(x[:, 2]), x[:, 0] - x[:, 1]], axis=1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        P.compute_tags_measures(mesh, NodalFunction(phi), 1, box_mode=True)
+    n1 = nxy + 1
+    v = np.arange(mesh.nv)
+    i, j, k = v % n1, (v // n1) % n1, v // (n1 * n1)
+    bcv = np.flatnonzero((i == 0) | (i == nxy) | (j == 0) | (j == nxy) | (k == 0) | (k == nzr * world))
+    s = P.InterfaceElasticitySolver(mesh, deterministic=True, coarse=ratio)
+    info = s.assemble(phi, f, uD, bcv)
+    wref = s.solve(rtol=1e-11, max_iter=200000).reshape(27, mesh.nv)
+    assert s.stats["precond"] == "vertex-block-jacobi+coarse"
+    got = np.full((27, mesh.nv), np.nan)
+    rows = []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"e{r}.npz"))
+        got[:, d["gid"]] = d["w"]
+        rows.append(d)
+        assert d["relres"] <= 1e-11 and str(d["path"]) == "native" and str(d["precond"]) == "vertex-block-jacobi+coarse", (d["path"], d["precond"])
+    assert not np.any(np.isnan(got)) and sum(int(d["n_owned"]) for d in rows) == info["n_active"]
+    assert np.abs(got - wref).max() <= 1e-6 * np.abs(wref).max()
+    its = {int(d["it"]) for d in rows}
+    print(f"world {world}: {its} iterations across the slabs, {s.stats['iterations']} on the single mesh")
+    assert len(its) == 1 and abs(its.pop() - s.stats["iterations"]) <= max(8, s.stats["iterations"] // 8)
 
 
 @pytest.mark.skipif(not os.path.exists(_FAKE), reason="tests/fake_rccl/libfake_rccl.so not built (build())")
