@@ -123,6 +123,78 @@ def main(n):
         print(f"   {name:20s} {it:5d} it  res {np.linalg.norm(Aa @ xs - ba) / np.linalg.norm(ba):.1e}  {time.time() - t0:.0f} s", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and os.environ.get("P2_COARSE") != "1":
     for n in [int(a) for a in sys.argv[1:]] or [6, 8]:
         main(n)
+
+
+def coarse_variants(n, ratios=(2, 4)):
+    """Galerkin coarse corrections on top of the shipped preconditioner: trilinear functions of spacing ratio * h
+    (a) on every u and p DoF, (b) on the band DoFs only (u and p of the cut cells), one set per field."""
+    t0 = time.time()
+    x, topo, cv, V, pts, A, b, act = problem(n)
+    nd = V.ndofs
+    idx = np.flatnonzero(act)
+    Aa = A[idx][:, idx].tocsr(); ba = b[idx]
+    nu = int((idx < nd).sum())
+    dg = Aa.diagonal()
+    h2 = 1.5 / n
+    ijk = np.rint((pts[idx[:nu]] + 1.5) / h2).astype(np.int64)
+    lo = ijk.min(0) - 5; m = ijk.max(0) + 5 - lo + 1
+    T = lambda k: sp.diags([-np.ones(k - 1), 2 * np.ones(k), -np.ones(k - 1)], [-1, 0, 1])
+    I = [sp.identity(k) for k in m]
+    K = h2 * (sp.kron(I[2], sp.kron(I[1], T(m[0]))) + sp.kron(I[2], sp.kron(T(m[1]), I[0])) + sp.kron(T(m[2]), sp.kron(I[1], I[0])))
+    pos = (ijk[:, 0] - lo[0]) + m[0] * ((ijk[:, 1] - lo[1]) + m[1] * (ijk[:, 2] - lo[2]))
+    Klu = spla.splu(K.tocsc())
+
+    def ML(r):
+        g = np.zeros(K.shape[0]); g[pos] = r[:nu]
+        return np.concatenate([Klu.solve(g)[pos], r[nu:] / dg[nu:]])
+
+    loc = -np.ones(2 * nd, dtype=np.int64); loc[idx] = np.arange(idx.size)
+    cut = np.flatnonzero(cv == 2)
+    band = np.zeros(idx.size, dtype=bool)
+    cd = V.cell_dofs[cut].ravel()
+    for off in (0, nd):
+        g = loc[cd + off]; band[g[g >= 0]] = True
+    allp = pts[np.where(idx < nd, idx, idx - nd)]          # position of every active DoF
+    fld = (idx >= nd).astype(int)
+    print(f"n={n}: {idx.size} DoFs, band {int(band.sum())}, set-up {time.time() - t0:.0f} s", flush=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xs, it = bicgstab(Aa, ba, ML, rtol=1e-8, maxit=5000)
+    print(f"   L                          {it:5d} it", flush=True)
+    for ratio in ratios:
+        H = ratio * 3.0 / n
+        mc = int(np.ceil(3.0 / H)) + 1
+        for name, sel in (("all", np.ones(idx.size, dtype=bool)),):
+            rows, cols, vals = [], [], []
+            for f in (0, 1):
+                s_ = np.flatnonzero(sel & (fld == f))
+                t = (allp[s_] + 1.5) / H
+                c0 = np.minimum(np.floor(t).astype(int), mc - 2)
+                for d in range(8):
+                    dd = np.array([d & 1, (d >> 1) & 1, d >> 2])
+                    cc = c0 + dd
+                    w = np.prod(1.0 - np.abs(t - cc), axis=1)
+                    keep = w > 1e-14
+                    rows.append(s_[keep]); cols.append(f * mc ** 3 + cc[keep, 0] + mc * (cc[keep, 1] + mc * cc[keep, 2])); vals.append(w[keep])
+            R = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(idx.size, 2 * mc ** 3))
+            used = np.flatnonzero(np.asarray(abs(R).sum(axis=0)).ravel() > 0)
+            R = R[:, used].tocsr()
+            Ac = (R.T @ Aa @ R).tocsc()
+            try:
+                Aclu = spla.splu(Ac)
+            except RuntimeError:
+                print(f"   L + C({name}, H={ratio}h): singular coarse matrix"); continue
+            M = lambda r: ML(r) + R @ Aclu.solve(R.T @ r)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                xs, it = bicgstab(Aa, ba, M, rtol=1e-8, maxit=5000)
+            print(f"   L + C({name:4s}, H={ratio}h, {used.size:5d}) {it:5d} it  res {np.linalg.norm(Aa @ xs - ba) / np.linalg.norm(ba):.1e}", flush=True)
+
+
+if __name__ == "__main__" and os.environ.get("P2_COARSE") == "1":
+    rat = tuple(int(a) for a in os.environ.get("RATIOS", "2,4").split(","))
+    for n in [int(a) for a in sys.argv[1:]] or [12]:
+        coarse_variants(n, rat)
