@@ -169,7 +169,7 @@ enum phx_option {
                                interface elasticity) and the Krylov solve: the element kernels run twice and
                                accumulate exactly (per-slot exponent, two accumulators), the dot products are
                                summed in a fixed order.  Costs one more pass of the element kernels and 12 bytes
-                               per row slot while assembling (skipped beyond PHX_DET_LIMIT_GB, default 48).
+                               per row slot while assembling (skipped beyond PHX_DET_LIMIT_GB, default a fifth of the device memory).
                                Default 0: f64 atomics in arrival order (results equal to round-off)           */
   PHX_OPT_EL_COARSE = 10, /* coarse-space correction of the interface-elasticity solve on generated boxes (one rank):
                                Galerkin problem on trilinear functions of spacing H = value * h per displacement

@@ -923,7 +923,13 @@ __global__ void k_det_finalize(int64_t n, double *__restrict__ acc, const double
 static int det_alloc(phx_mesh *m, Slots &sl, int64_t nslots, int64_t nrows, bool *on) {
   *on = false;
   if (!m->deterministic) return PHX_OK;
-  static const double limit_gb = getenv("PHX_DET_LIMIT_GB") ? atof(getenv("PHX_DET_LIMIT_GB")) : 48.0;
+  // default: a fifth of the device (57.6 GB of 288: the 256^3 elasticity system needs 52 GB, the 512^3 P2 system more)
+  static const double limit_gb = [] {
+    if (const char *e = getenv("PHX_DET_LIMIT_GB")) return atof(e);
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) { (void)hipGetLastError(); return 48.0; }
+    return 0.2 * (double)tot / 1073741824.0;
+  }();
   if (12.0 * (double)nslots > limit_gb * 1073741824.0) return PHX_OK;
   PHX_HIP(phx_malloc(&sl.emax, sizeof(int32_t) * (size_t)nslots));
   PHX_HIP(phx_malloc(&sl.lo, sizeof(double) * (size_t)nslots));

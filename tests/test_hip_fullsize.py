@@ -235,7 +235,7 @@ def test_p2_512_at_full_size():
 
 def test_elasticity_256_at_full_size():
     """BASELINE configs[3] AT ITS STATED SIZE on one GPU: the 5-field interface-elasticity system on the 256^3 box
-    (100 663 296 tetrahedra, 27 components per vertex, 5.6e7 active rows, 2.3e9 stored non-zeros, ~155 GB).
+    (100 663 296 tetrahedra, 27 components per vertex, 5.6e7 active rows, 2.3e9 stored non-zeros, ~220 GB with the exact assembly pass).
     Size-independent properties, evaluated on the device: the solve converges (true residual, verified inside
     phx_solve), the returned solution satisfies the system through the library's own operator, inactive DoFs are zero,
     u_in carries u_D on the faces of the box (demo/interface-elasticity/main.py:158-177)."""

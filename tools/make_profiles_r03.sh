@@ -33,7 +33,7 @@ timeout -k 10 500 python bench.py --config5 --steps 3 --warmup 1 --no-cpu-baseli
 timeout -k 10 600 python bench.py --config3 --cubes 256 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_config3_p2_256_n1.json 2> $O/bench_config3_256.err; echo "c3-256 rc=$?"
 timeout -k 10 900 python bench.py --config3 --cubes 512 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_config3_p2_512_n1.json 2> $O/bench_config3_512.err; echo "c3-512 rc=$?"
 timeout -k 10 600 python bench.py --config4 --cubes 96 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_config4_el_96_n1.json 2> $O/bench_config4.err; echo "c4 rc=$?"
-timeout -k 10 600 python bench.py --config4 --cubes 256 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_config4_el_256_n1.json 2> $O/bench_config4_256.err; echo "c4-256 rc=$?"
+timeout -k 10 600 python bench.py --config4 --cubes 256 --steps 2 --warmup 2 --no-cpu-baseline > $O/bench_config4_el_256_n1.json 2> $O/bench_config4_256.err; echo "c4-256 rc=$?"
 timeout -k 10 300 python tools/caller_lattice_step.py 128 > $O/caller_lattice_step_128.txt 2>&1; tail -1 $O/caller_lattice_step_128.txt
 rm -f $O/*.log
 ls -la $O; python3 - <<PY
