@@ -220,7 +220,9 @@ __device__ __forceinline__ void fft_stage(C2<T> *z, int nb, int tp, int t, int p
 #pragma unroll
       for (int q = 0; q < R; ++q) {
         C2<T> w = *zr;
-        if (q > 0 && k > 0) w = cmul(w, *twq);
+        // every stage behind the first multiplies unconditionally (tw[0] = 1 exactly): a per-lane `k > 0` test put each
+        // of the R - 1 twiddle reads behind its own branch and its own LDS wait
+        if (q > 0 && p > 1) w = cmul(w, *twq);
         u[b][q] = w;
         zr += nbp;
         twq += step;
@@ -660,6 +662,9 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G, const int2 *__restrict__ row_an
   }
 }
 
+constexpr bool dst_wave_f64(int L) { return L / 8 == 32 || L / 8 == 64 || L / 8 == 24; }
+#include "phx_dst_wave.inc.hip"
+
 // --------------------------------------------------------------------------------------------------
 struct phx_box_precond {
   BoxGrid g;
@@ -670,6 +675,7 @@ struct phx_box_precond {
   double *dscale = nullptr;  // [n] diag of A in solver order (weighted systems: sqrt(diag A * diag K_box))
   double *iscale = nullptr;  // [n] weighted systems only: sqrt(diag K_box / diag A), applied to the input
   const uint8_t *own_ptr = nullptr;  // ownership mask the maps were built for
+  int64_t nvec = 0;          // entries of the Krylov vectors the x passes gather from / scatter to
   double *lam[3] = {nullptr, nullptr, nullptr};
   int lo[3] = {0, 0, 0};     // lattice index of the lower Dirichlet face
   // slab-exact mode (multi-GPU): this rank holds `g.m[2]` planes of a GLOBAL column of zN planes starting at the
@@ -710,7 +716,6 @@ static int dst_allow_lds_t() {
 }
 // f64 kernels specialised for the transform length, in the synchronisation mode dst_get_plan picks for it
 #define PHX_DST_LENGTHS(X) X(64) X(128) X(192) X(256) X(384) X(512) X(768) X(1024)
-constexpr bool dst_wave_f64(int L) { return L / 8 == 32 || L / 8 == 64 || L / 8 == 24; }
 template <int LL>
 static int dst_allow_lds_len() {
   const int bytes = 160 * 1024;
@@ -726,6 +731,9 @@ static int dst_allow_lds() {
   if (done) return PHX_OK;
 #define X(L_) PHX_CHECK((dst_allow_lds_len<L_>()));
   PHX_DST_LENGTHS(X)
+#undef X
+#define X(L_) PHX_CHECK((dst_wave_allow_lds<L_>()));
+  PHX_DST_WAVE_LENGTHS(X)
 #undef X
   PHX_CHECK((dst_allow_lds_t<double, true>()));
   PHX_CHECK((dst_allow_lds_t<double, false>()));
@@ -812,7 +820,18 @@ static int box_pass_y_t(phx_box_precond *bp, hipStream_t st, phx_system *prof, i
   if (prof) PHX_CHECK(prof_begin(prof, 1));
   bool done = false;
   if constexpr (sizeof(T) == 8) {
-    if (!getenv("PHX_DST_GENERIC")) {
+    if (dst_wave_fast(g, py, 0)) {
+      const dim3 g2((unsigned)ncb, (unsigned)g.m[2]);
+      switch (py.L) {
+#define X(L_) case L_: k_dst_yw<L_><<<g2, block, (size_t)py.lds_elems * el, st>>>(g, py, G, ra, dir); done = true; break;
+        PHX_DST_WAVE_LENGTHS(X)
+#undef X
+        default: break;
+      }
+    }
+  }
+  if constexpr (sizeof(T) == 8) {
+    if (!done && !getenv("PHX_DST_GENERIC")) {
       switch (py.L) {
 #define X(L_) case L_: if ((py.wave != 0) == dst_wave_f64(L_)) { \
           k_dst_s<double, 1, false, dst_wave_f64(L_), L_><<<grid, block, (size_t)py.lds_elems * el, st>>>(g, py, G, ra, dir); done = true; } break;
@@ -878,7 +897,22 @@ static int box_pass_x_t(phx_box_precond *bp, hipStream_t st, const double *vin, 
   const double *sc = IO == 1 ? bp->iscale : bp->dscale;
   bool done = false;
   if constexpr (sizeof(T) == 8) {
-    if (!getenv("PHX_DST_GENERIC")) {
+    if (dst_wave_fast(g, px, bp->nvec)) {
+      const uint32_t vb = (uint32_t)(bp->nvec * 8);
+      double *Gd = static_cast<double *>(bp->G);
+      switch (px.L) {
+#define X(L_) case L_: \
+          if (sc) k_dst_xw<L_, IO, IO != 0><<<grid, block, lds, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb); \
+          else k_dst_xw<L_, IO, false><<<grid, block, lds, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb); \
+          done = true; break;
+        PHX_DST_WAVE_LENGTHS(X)
+#undef X
+        default: break;
+      }
+    }
+  }
+  if constexpr (sizeof(T) == 8) {
+    if (!done && !getenv("PHX_DST_GENERIC")) {
       switch (px.L) {
 #define X(L_) case L_: if ((px.wave != 0) == dst_wave_f64(L_)) { \
           k_dst_x<double, IO, dst_wave_f64(L_), L_><<<grid, block, lds, st>>>(g, px, static_cast<double *>(bp->G), bp->gmap, vin, vout, sc, bp->line_any); \
@@ -1154,6 +1188,7 @@ static int box_precond_build(phx_system *s, bool p2, const int L[3], const int l
   }
   if (hipGetLastError() != hipSuccess) { box_precond_free(bp); return PHX_ERR_HIP; }
   bp->own_ptr = s->own;
+  bp->nvec = s->n;
   *out = bp;
   return PHX_OK;
 }

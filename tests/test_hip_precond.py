@@ -29,7 +29,9 @@ def scipy_box_solve(f, L, h):
 @pytest.mark.parametrize("L", [(64, 64, 64), (128, 64, 192), (192, 128, 64), (256, 128, 64), (64, 384, 128),
                                (512, 64, 64), (64, 64, 768), (1024, 64, 64), (768, 64, 40), (64, 768, 20), (384, 192, 30),
                                # z is solved as a tridiagonal system: any column length, no transform
-                               (64, 64, 180), (128, 64, 38), (64, 128, 2), (64, 64, 3), (64, 64, 1025)])
+                               (64, 64, 180), (128, 64, 38), (64, 128, 2), (64, 64, 3), (64, 64, 1025),
+                               # lengths served by the wave-mode kernels (phx_dst_wave.inc.hip) in x AND in y, odd plane counts
+                               (192, 192, 21), (256, 512, 4), (512, 256, 7), (192, 256, 2)])
 @pytest.mark.parametrize("f32", [0, 1])
 def test_box_poisson_solve_matches_scipy(P, L, f32):
     from phifem_amd import _lib as L_
