@@ -288,6 +288,8 @@ struct phx_system {
 int phx_mesh_alloc_common(phx_mesh *m);
 int phx_begin_timing(phx_mesh *m);
 int phx_end_timing(phx_mesh *m, int slot);
+int phx_end_timing_mark(phx_mesh *m);
+int phx_end_timing_read(phx_mesh *m, int slot);
 int phx_mesh_build_edges(phx_mesh *m);
 int phx_mesh_create_from(int gdim, int cell_type, int64_t nv, const double *coords, int64_t nc,
                          const int32_t *cells, int loc, int device, phx_mesh **out);

@@ -41,23 +41,45 @@ template <int LL> struct WaveShape {
   static_assert(dst_wave_f64(LL) && RSTEP % 8 == 0 && TP % 8 == 0 && H % RSTEP == 0, "shape");
 };
 
-template <int LL>
-__device__ __forceinline__ void stage_tables_w(C2<double> *zs, const DstPlan &P, const C2<double> **tw, const double **sn) {
+// The twiddle and sine tables of the plan go to LDS behind the padded pair arrays (the stage loops read them with LDS
+// latency).  Two halves: the global loads are ISSUED behind the tile loads of the block and the LDS writes follow the
+// tile's own -- staging them first (as k_dst_x / k_dst_s do) put a full global round trip in front of the tile loads.
+template <int LL> struct WaveTables {
   using S = WaveShape<LL>;
-  C2<double> *ltw = zs + S::PAIRS * S::ZL;   // = P.tab_off (no scan scratch in wave mode)
-  double *lsn = reinterpret_cast<double *>(ltw + LL);
-  const C2<double> *gtw = PlanTab<double>::tw(P);
-  const double *gsn = P.sintab;
+  static constexpr int NTW = (LL + S::NTHR - 1) / S::NTHR, NSN = (LL / 2 + 1 + S::NTHR - 1) / S::NTHR;
+  C2<double> tw[NTW];
+  double sn[NSN];
+  __device__ __forceinline__ void load(const DstPlan &P) {
+    const C2<double> *gtw = PlanTab<double>::tw(P);
+    const double *gsn = P.sintab;
 #pragma unroll
-  for (int j0 = 0; j0 < LL; j0 += S::NTHR) {
-    const int j = j0 + (int)threadIdx.x;
-    if (j < LL) ltw[j] = gtw[j];
+    for (int q = 0; q < NTW; ++q) {
+      const int j = q * S::NTHR + (int)threadIdx.x;
+      tw[q] = gtw[min(j, LL - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < NSN; ++q) {
+      const int j = q * S::NTHR + (int)threadIdx.x;
+      sn[q] = gsn[min(j, LL / 2)];
+    }
   }
-  if ((int)threadIdx.x <= LL / 2 && (int)threadIdx.x < S::NTHR) lsn[threadIdx.x] = gsn[threadIdx.x];
-  if (LL / 2 >= S::NTHR && (int)threadIdx.x + S::NTHR <= LL / 2) lsn[threadIdx.x + S::NTHR] = gsn[threadIdx.x + S::NTHR];
-  *tw = ltw;
-  *sn = lsn;
-}
+  __device__ __forceinline__ void store(C2<double> *zs, const C2<double> **twp, const double **snp) const {
+    C2<double> *ltw = zs + S::PAIRS * S::ZL;   // = P.tab_off (no scan scratch in wave mode)
+    double *lsn = reinterpret_cast<double *>(ltw + LL);
+#pragma unroll
+    for (int q = 0; q < NTW; ++q) {
+      const int j = q * S::NTHR + (int)threadIdx.x;
+      if (j < LL) ltw[j] = tw[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NSN; ++q) {
+      const int j = q * S::NTHR + (int)threadIdx.x;
+      if (j <= LL / 2) lsn[j] = sn[q];
+    }
+    *twp = ltw;
+    *snp = lsn;
+  }
+};
 
 // ---- y pass: a block transforms the W columns [col0, col0 + W) of plane `outer` (grid: column blocks x planes).
 // row_any / dir as in k_dst_s: rows outside the plane's interval are taken as zero (dir = 1) / not stored (dir = 2).
@@ -77,7 +99,7 @@ k_dst_yw(BoxGrid g, DstPlan P, double *__restrict__ G, const int2 *__restrict__ 
       buf_rsrc(G + ((int64_t)outer * g.plane + col0), (uint32_t)((len - 1) * pitch8 + ncols * 8));
   const C2<double> *tw;
   const double *sn;
-  stage_tables_w<LL>(zs, P, &tw, &sn);
+  WaveTables<LL> tab;
   const int tcol = tid % S::W, row0 = tid / S::W;
   const bool colok = tcol < ncols;
   double *wcol = reinterpret_cast<double *>(zs + (tcol >> 1) * S::ZL) + (tcol & 1);
@@ -111,6 +133,7 @@ k_dst_yw(BoxGrid g, DstPlan P, double *__restrict__ G, const int2 *__restrict__ 
       vb[i] = buf_ld_f64(rs, okb ? offb - (uint32_t)i * dstep : PHX_BUF_OOB);
       sj[i] = sng[1 + row0 + i * S::RSTEP];
     }
+    tab.load(P);
     const int zpa = ZP(1 + row0), zpb = ZP(LL - 1 - row0);
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -119,6 +142,7 @@ k_dst_yw(BoxGrid g, DstPlan P, double *__restrict__ G, const int2 *__restrict__ 
       wcol[2 * (zpb - i * ZS)] = e - o;
     }
     if (row0 == 0) wcol[0] = 0.0;
+    tab.store(zs, &tw, &sn);
   }
   __syncthreads();
   {
@@ -159,18 +183,18 @@ k_dst_xw(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict
   const int pr = tid / S::SLOT, t = tid % S::SLOT;
   const int nlines = g.m[1] * g.m[2];
   if (IO != 0 && line_any) {
-    // a block whose lines hold no mapped point: forward, the y pass takes its rows as zero; backward, nothing to scatter
-    const int l0 = (int)blockIdx.x * S::PAIRS * 2, l1 = min(l0 + 2 * S::PAIRS, nlines);
-    bool any = false;
-    for (int l = l0; l < l1; ++l) any |= line_any[l] != 0;
-    if (!any) return;
+    // a block whose lines hold no mapped point: forward, the y pass takes its rows as zero; backward, nothing to scatter.
+    // Every wave looks at the 2 PAIRS flags of the block with its first lanes (one load, one ballot).
+    const int lane = tid & 63, l = (int)blockIdx.x * S::PAIRS * 2 + lane;
+    const bool mine = lane < 2 * S::PAIRS && l < nlines && line_any[l] != 0;
+    if (__ballot(mine) == 0) return;
   }
   const int line0 = ((int)blockIdx.x * S::PAIRS + pr) * 2;
   const bool live = line0 < nlines && t < TP;
   C2<double> *w = zs + pr * S::ZL;
   const C2<double> *tw;
   const double *sn;
-  stage_tables_w<LL>(zs, P, &tw, &sn);
+  WaveTables<LL> tab;
   const uint32_t lat = (uint32_t)nlines * (uint32_t)g.pitch;   // lattice elements
   const __amdgpu_buffer_rsrc_t rsG = buf_rsrc(G, lat * 8u);
   const __amdgpu_buffer_rsrc_t rsM = buf_rsrc(gmap, IO != 0 ? lat * 4u : 0u);
@@ -178,6 +202,7 @@ k_dst_xw(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict
   const __amdgpu_buffer_rsrc_t rsS = buf_rsrc(dscale, SC ? vec_bytes : 0u);
   bool has[2] = {false, false};
   uint32_t base[2] = {0, 0};
+  double va[4], vb[4], ua[4], ub[4], sj[4];   // line a / b at j (v) and at L - j (u)
   if (live) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -188,7 +213,6 @@ k_dst_xw(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict
     // the lane takes the pairs (j, L - j), j = 1 + t + i TP (j = 1 .. L / 2) of both lines; j = L / 2 pairs an element
     // with itself (see k_dst_yw)
     const double *sng = P.sintab;
-    double va[4], vb[4], ua[4], ub[4], sj[4];   // line a / b at j (v) and at L - j (u)
     const uint32_t ea = base[0] + (uint32_t)t, eb = base[1] + (uint32_t)t;                         // element of j = 1 + t
     const uint32_t fa = base[0] + (uint32_t)(LL - 2 - t), fb = base[1] + (uint32_t)(LL - 2 - t);   // element of L - j
     if (IO == 1) {
@@ -223,6 +247,9 @@ k_dst_xw(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict
         sj[i] = sng[1 + t + i * TP];
       }
     }
+  }
+  tab.load(P);   // every lane of the block, behind the lattice loads
+  if (live) {
     const int zpa = ZP(1 + t), zpb = ZP(LL - 1 - t);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -233,6 +260,7 @@ k_dst_xw(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict
     }
     if (t == 0) w[0] = mk<double>(0.0, 0.0);
   }
+  tab.store(zs, &tw, &sn);
   __syncthreads();   // the tables; the pair's own elements are wave-local
   if (!live) return;
   dst_core<double, true, LL, false>(w, nullptr, P, t, true, tw, sn);

@@ -330,6 +330,19 @@ int phx_end_timing(phx_mesh *m, int slot) {
   m->timings[slot] = (double)ms * 1e-3;
   return PHX_OK;
 }
+// the same in two halves, for callers that synchronise the stream anyway a few launches later: mark the end now,
+// read the interval after that synchronisation (one host round trip instead of two)
+int phx_end_timing_mark(phx_mesh *m) {
+  PHX_HIP(hipEventRecord(m->ev1, m->stream));
+  return PHX_OK;
+}
+int phx_end_timing_read(phx_mesh *m, int slot) {
+  PHX_HIP(hipEventSynchronize(m->ev1));
+  float ms = 0.f;
+  PHX_HIP(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+  m->timings[slot] = (double)ms * 1e-3;
+  return PHX_OK;
+}
 
 static int mesh_init_device(phx_mesh *m, int device) {
   int ndev = 0;

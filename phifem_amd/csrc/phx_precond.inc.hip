@@ -296,6 +296,16 @@ __device__ __forceinline__ void fft_pairs(C2<T> *z, const DstPlan &P, int t, boo
   }
 }
 
+// DPP move of a complex double: lane l reads the value of the lane CTRL selects (0x110 + n: row_shr n, 0x138: wave_shr 1,
+// 0x142 / 0x143: row_bcast 15 / 31), 0 where there is none or where ROWS masks the row out
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ C2<double> dpp_c2(C2<double> v) {
+  int w[4] = {__double2loint(v.x), __double2hiint(v.x), __double2loint(v.y), __double2hiint(v.y)};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = __builtin_amdgcn_update_dpp(0, w[q], CTRL, ROWS, 0xf, true);
+  return mk<double>(__hiloint2double(w[1], w[0]), __hiloint2double(w[3], w[2]));
+}
+
 // In:  w[ZP(j)] = (a_j, b_j), j = 1 .. L-1 (w[0] arbitrary).   Out: w[ZP(k)] = (F^a_k, F^b_k), k = 1 .. L-1,
 // F_k = sum_j x_j sin(pi j k / L).  `scr`: tp + tp/8 + 1 complex values of scan scratch of this pair.
 // Block-wide barriers inside: every thread of the block calls it.
@@ -359,14 +369,20 @@ __device__ __forceinline__ void dst_core(C2<T> *w, C2<T> *scr, const DstPlan &P,
   if constexpr (WAVE) {
     // the pair sits inside one wavefront: prefix sum of the per-thread totals by shuffles -- no scratch in LDS
     // (which lets a fifth block fit a CU at L = 192), no synchronisation.  Idle lanes carry zeros.
+    // Data-parallel-primitive moves instead of ds_bpermute: a VALU move with a lane-shifted source, no LDS round trip,
+    // and lanes without a source read 0 (bound_ctrl), which spares the `t >= d` selects.  Inclusive scan inside each
+    // row of 16 lanes (row_shr 1, 2, 4, 8), then the row totals cross the rows (row_bcast15 into rows 1 and 3,
+    // row_bcast31 into rows 2 and 3 when the pair fills the wave).
     C2<double> inc = run;
-    for (int d = 1; d < slot; d <<= 1) {
-      const double ux = __shfl_up(inc.x, d, slot), uy = __shfl_up(inc.y, d, slot);
-      if (t >= d) { inc.x += ux; inc.y += uy; }
-    }
+    inc = cadd(inc, dpp_c2<0x111>(inc));
+    inc = cadd(inc, dpp_c2<0x112>(inc));
+    inc = cadd(inc, dpp_c2<0x114>(inc));
+    inc = cadd(inc, dpp_c2<0x118>(inc));
+    inc = cadd(inc, dpp_c2<0x142, 0xa>(inc));
+    if (slot == 64) inc = cadd(inc, dpp_c2<0x143, 0xc>(inc));
     // exclusive prefix = the inclusive one of the lane below (no subtraction: that would cost the low bits)
-    const double ex = __shfl_up(inc.x, 1, slot), ey = __shfl_up(inc.y, 1, slot);
-    E = t == 0 ? mk<double>(0.0, 0.0) : mk<double>(ex, ey);
+    const C2<double> ex = dpp_c2<0x138>(inc);   // wave_shr:1
+    E = t == 0 ? mk<double>(0.0, 0.0) : ex;
   } else {
     C2<double> *tot = reinterpret_cast<C2<double> *>(scr), *gt = tot + tp;
     if (live) tot[t] = run;

@@ -7,6 +7,7 @@
 #pragma once
 #include "phx_prim.h"
 #include <utility>
+#include <vector>
 
 #include "phx_common.h"
 
@@ -68,8 +69,11 @@ k_select_chunks(int64_t n, Pred pred, int32_t *__restrict__ chunk_counts,
 }
 
 // Allocates *list with exactly the kept count (at least one entry) and returns the count.
+// later (nullable): the caller synchronises `stream` before it frees what is pushed here -- the fill pass is then only
+// enqueued (one host round trip per selection instead of two).
 template <typename Pred>
-static int phx_select_indices(hipStream_t stream, int64_t n, Pred pred, int32_t **list, int64_t *count) {
+static int phx_select_indices(hipStream_t stream, int64_t n, Pred pred, int32_t **list, int64_t *count,
+                              std::vector<void *> *later = nullptr) {
   *list = nullptr;
   *count = 0;
   const int64_t nchunks = phx_div_up(n > 0 ? n : 1, (int64_t)PHX_SEL_CHUNK);
@@ -90,8 +94,12 @@ static int phx_select_indices(hipStream_t stream, int64_t n, Pred pred, int32_t 
   PHX_HIP(phx_malloc(list, sizeof(int32_t) * (size_t)(total > 0 ? total : 1)));
   if (total > 0) k_select_chunks<Pred, true><<<grid, block, 0, stream>>>(n, pred, nullptr, off, *list);
   PHX_HIP(hipGetLastError());
-  PHX_HIP(hipStreamSynchronize(stream));
-  PHX_HIP(phx_free(tmp)); PHX_HIP(phx_free(cnt)); PHX_HIP(phx_free(off));
+  if (later) {
+    later->push_back(tmp); later->push_back(cnt); later->push_back(off);
+  } else {
+    PHX_HIP(hipStreamSynchronize(stream));
+    PHX_HIP(phx_free(tmp)); PHX_HIP(phx_free(cnt)); PHX_HIP(phx_free(off));
+  }
   *count = total;
   return PHX_OK;
 }

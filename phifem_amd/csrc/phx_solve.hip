@@ -580,6 +580,29 @@ static int scan_u8(hipStream_t st, const uint8_t *flags, int32_t *out, int64_t n
   return PHX_OK;
 }
 
+static int scan_u8_pair(hipStream_t st, const uint8_t *fa, int32_t *oa, int32_t *ta, const uint8_t *fb, int32_t *ob,
+                        int32_t *tb, int64_t n) {
+  auto ia = rocprim::make_transform_iterator(fa, U8AsI32());
+  auto ib = rocprim::make_transform_iterator(fb, U8AsI32());
+  size_t bytes = 0;
+  PHX_HIP(phx_exclusive_sum(nullptr, bytes, ia, oa, (size_t)(n), st));
+  void *tmp = nullptr;
+  PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(phx_exclusive_sum(tmp, bytes, ia, oa, (size_t)(n), st));
+  PHX_HIP(phx_exclusive_sum(tmp, bytes, ib, ob, (size_t)(n), st));
+  int32_t last[2] = {0, 0};
+  uint8_t lastf[2] = {0, 0};
+  PHX_HIP(hipMemcpyAsync(&last[0], oa + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  PHX_HIP(hipMemcpyAsync(&lastf[0], fa + (n - 1), 1, hipMemcpyDeviceToHost, st));
+  PHX_HIP(hipMemcpyAsync(&last[1], ob + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  PHX_HIP(hipMemcpyAsync(&lastf[1], fb + (n - 1), 1, hipMemcpyDeviceToHost, st));
+  PHX_HIP(hipStreamSynchronize(st));
+  PHX_HIP(phx_free(tmp));
+  *ta = last[0] + (int32_t)lastf[0];
+  *tb = last[1] + (int32_t)lastf[1];
+  return PHX_OK;
+}
+
 int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t nent) {
   phx_mesh *m = s->mesh;
   hipStream_t st = m->stream;
@@ -603,8 +626,9 @@ int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t 
   // ---- stored rows (everything the stencil does not apply): kept entries, diagonal
   int32_t *list = nullptr;
   int64_t ns = 0;
-  PHX_CHECK(phx_select_indices(st, n, SelStored{c0i}, &list, &ns));   // synchronises
-  PHX_HIP(phx_free(rank));
+  std::vector<void *> later;   // temporaries whose last kernel is only enqueued: freed behind the last synchronisation
+  PHX_CHECK(phx_select_indices(st, n, SelStored{c0i}, &list, &ns, &later));   // one host round trip (the count)
+  later.push_back(rank);
   int32_t *len = nullptr, *nstruct = nullptr;
   unsigned long long *dtot = nullptr, htot[2] = {0, 0};
   PHX_HIP(phx_malloc(&len, sizeof(int32_t) * (size_t)std::max<int64_t>(ns, 1)));
@@ -689,8 +713,7 @@ int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t 
     // the stored rows (near Gamma_h) hold few repeated values: no dictionary coding here
     s->sell_stream_bytes = 12 * s->sell_nnz + 8 * s->nslices + 4 * s->nslices * SELL_S;
   }
-  PHX_HIP(hipStreamSynchronize(st));
-  PHX_HIP(phx_free(len)); PHX_HIP(phx_free(list)); PHX_HIP(phx_free(rows_active));
+  later.push_back(len); later.push_back(list); later.push_back(rows_active);
   // ---- stencil runs over the positions of the C0 rows
   s->nseg = 0;
   s->nstencil_pos = nc0all;
@@ -703,8 +726,7 @@ int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t 
     const dim3 gq((unsigned)phx_div_up(nq, 256));
     k_seg_flags<<<gq, block, 0, st>>>(nq, s->perm, c0i, s->full_of_active, fs, fe);
     int32_t nstart = 0, nend = 0;
-    PHX_CHECK(scan_u8(st, fs, is, nq, &nstart));
-    PHX_CHECK(scan_u8(st, fe, ie, nq, &nend));
+    PHX_CHECK(scan_u8_pair(st, fs, is, &nstart, fe, ie, &nend, nq));   // one host round trip for both totals
     PHX_REQUIRE(nstart == nend, PHX_ERR_HIP, "stencil runs: %d starts, %d ends", nstart, nend);
     s->nseg = nstart;
     PHX_HIP(phx_malloc(&s->seg, sizeof(int32_t) * 6 * (size_t)std::max(nstart, 1)));
@@ -714,12 +736,12 @@ int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t 
     PHX_HIP(phx_malloc(&s->slice_seg, sizeof(int32_t) * 16 * (size_t)nw));
     k_slice_seg<<<dim3((unsigned)phx_div_up(nw, 256)), block, 0, st>>>(nw, s->nseg, s->seg, s->slice_seg);
     PHX_HIP(hipGetLastError());
-    PHX_HIP(hipStreamSynchronize(st));
-    PHX_HIP(phx_free(fs)); PHX_HIP(phx_free(fe)); PHX_HIP(phx_free(is)); PHX_HIP(phx_free(ie));
+    later.push_back(fs); later.push_back(fe); later.push_back(is); later.push_back(ie);
     s->sell_stream_bytes += 24 * (int64_t)s->nseg + 64 * nw;
   }
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(st));
+  for (void *q : later) PHX_HIP(phx_free(q));
   PHX_HIP(phx_free(c0i));
   // solver workspace: 9 vectors + scalars
   PHX_HIP(phx_malloc(&s->work, sizeof(double) * (size_t)n * 9));
@@ -797,7 +819,10 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
   // its L2; inside every run of 8*G consecutive block ids XCD k is handed G CONSECUTIVE slice groups,
   // so the x entries its rows gather stay in one L2.  Speed only: any placement is correct.
   int64_t bid = blockIdx.x;
-  if (xcd_group > 0) {
+  if (xcd_group < 0) {
+    // contiguous eighths (structured systems: nb_sell is a multiple of 8): XCD k walks the k-th eighth of the stored rows
+    if (bid < nb_sell) bid = (bid & 7) * (nb_sell >> 3) + (bid >> 3);
+  } else if (xcd_group > 0) {
     const int64_t super = 8 * (int64_t)xcd_group, sg = bid / super;
     if ((sg + 1) * super <= nb_sell) {
       const int64_t rem = bid - sg * super;
@@ -1419,6 +1444,7 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   static const int part = getenv("PHX_SPMV_PART") ? atoi(getenv("PHX_SPMV_PART")) : 0;  // timing aid: 1 SELL only, 2 stencil only
   if (part == 2) nb_sell = 0;
   int64_t nb = nb_sell;
+  static const int sell_xcd = getenv("PHX_SELL_XCD") ? atoi(getenv("PHX_SELL_XCD")) : 0;   // experiment: 1 = contiguous eighths
   if (s->structured && s->nseg > 0 && part != 1) {
     // the stencil blocks start at a multiple of 8 so that blockIdx % 8 (the XCD a block lands on) is theirs to
     // use: XCD k walks the k-th contiguous eighth of the rows, whose x entries then stay in ITS 4 MiB L2
@@ -1428,16 +1454,17 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
     sa = StencilArgs{s->nstencil_pos, s->seg, s->nseg, s->slice_seg, s->stencil, (nbst + 7) / 8};
     nb = nb_sell + 8 * sa.chunk;
   }
+  const int xg2 = (sell_xcd == 1 && s->structured && nb_sell % 8 == 0 && nb_sell > 0) ? -1 : xg;
   if (nb == 0 && !s->p2s) return PHX_OK;
   const dim3 g2((unsigned)std::max<int64_t>(nb, 1));
   if (dots > 0 && nb > 0) PHX_CHECK(det_part(s, nb, &dp));
   if (nb == 0) {}
   else if (dots == 0)
-    k_spmv_sell<0><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd, dp);
+    k_spmv_sell<0><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg2, kinds, rows, nb_sell, sa, bnd, dp);
   else if (dots == 1)
-    k_spmv_sell<1><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd, dp);
+    k_spmv_sell<1><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg2, kinds, rows, nb_sell, sa, bnd, dp);
   else
-    k_spmv_sell<2><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg, kinds, rows, nb_sell, sa, bnd, dp);
+    k_spmv_sell<2><<<g2, block, 0, st>>>(s->n, s->nslices, s->slice_ptr, s->sell_col, vals, x, y, own, d0, o0, o1, xg2, kinds, rows, nb_sell, sa, bnd, dp);
   PHX_HIP(hipGetLastError());
   if (s->p2s && s->p2s->nrun > 0 && part_of == 0 && part != 1) {
     // structured P2: the interior rows from the eight class stencils, one wavefront per run

@@ -372,7 +372,9 @@ static int64_t cell_points_count(const phx_mesh *m, int degree) {
   return t.npts;
 }
 
-static int read_hist(phx_mesh *m, const int8_t *tags, int64_t n, int nbins, int64_t *out) {
+// extra (nullable): `extra_bytes` more device bytes fetched with the same host round trip (flags of the tagging kernels)
+static int read_hist(phx_mesh *m, const int8_t *tags, int64_t n, int nbins, int64_t *out, const void *extra = nullptr,
+                     size_t extra_bytes = 0, void *extra_host = nullptr) {
   unsigned long long *d = nullptr;
   PHX_HIP(phx_malloc(&d, sizeof(unsigned long long) * 8));
   PHX_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long) * 8, m->stream));
@@ -380,6 +382,7 @@ static int read_hist(phx_mesh *m, const int8_t *tags, int64_t n, int nbins, int6
   k_tag_hist<<<dim3(blocks), dim3(256), 0, m->stream>>>(n, tags, nbins, d);
   unsigned long long h[8];
   PHX_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, m->stream));
+  if (extra) PHX_HIP(hipMemcpyAsync(extra_host, extra, extra_bytes, hipMemcpyDeviceToHost, m->stream));
   PHX_HIP(hipStreamSynchronize(m->stream));
   PHX_HIP(phx_free(d));
   for (int i = 0; i < nbins; ++i) out[i] = (int64_t)h[i];
@@ -419,8 +422,8 @@ extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int l
   if (phi_kind == PHX_PHI_NODAL_P1) PHX_CHECK(launch_tag_cells<PHX_PHI_NODAL_P1>(m, tab, dphi, quad, dwarn));
   else if (phi_kind == PHX_PHI_POINTS) PHX_CHECK(launch_tag_cells<PHX_PHI_POINTS>(m, tab, dphi, quad, dwarn));
   else PHX_CHECK(launch_tag_cells<PHX_PHI_QUADRIC>(m, tab, dphi, quad, dwarn));
+  uint8_t *touched = nullptr;
   if (single_layer_cut) {
-    uint8_t *touched = nullptr;
     PHX_HIP(phx_malloc(&touched, (size_t)m->nv));
     PHX_HIP(hipMemsetAsync(touched, 0, (size_t)m->nv, m->stream));
     const dim3 grid((unsigned)phx_div_up(phx_div_up(m->nc, 4), 256)), block(256);   // four cells per thread
@@ -432,17 +435,19 @@ extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int l
       k_demote_isolated_cut<4><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
     }
     PHX_HIP(hipGetLastError());
-    PHX_CHECK(phx_end_timing(m, 0));
-    PHX_HIP(phx_free(touched));
+    PHX_CHECK(phx_end_timing_mark(m));
   } else {
-    PHX_CHECK(phx_end_timing(m, 0));
+    touched = nullptr;
+    PHX_CHECK(phx_end_timing_mark(m));
   }
+  // one host round trip for the histogram, the warning flag and the timing events
   int hwarn = 0;
-  PHX_HIP(hipMemcpy(&hwarn, dwarn, sizeof(int), hipMemcpyDeviceToHost));
+  PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist, dwarn, sizeof(int), &hwarn));
+  PHX_CHECK(phx_end_timing_read(m, 0));
+  if (touched) PHX_HIP(phx_free(touched));
   PHX_HIP(phx_free(dwarn));
   if (owned) PHX_HIP(phx_free(owned));
   if (warn_zero_denominator) *warn_zero_denominator = hwarn;
-  PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist));
   m->have_cell_tags = true;
   m->have_facet_tags = false;
   m->have_entities = false;
@@ -481,11 +486,11 @@ static int run_facet_rule(phx_mesh *m) {
       m->has_exterior_override >= 0 ? (m->has_exterior_override ? 0 : 1) : (m->tag_hist[3] == 0 ? 1 : 0),
       m->facet_exempt, m->facet_tags, dbad);
   PHX_HIP(hipGetLastError());
-  PHX_CHECK(phx_end_timing(m, 1));
+  PHX_CHECK(phx_end_timing_mark(m));
   unsigned long long bad = 0;
-  PHX_HIP(hipMemcpy(&bad, dbad, sizeof(bad), hipMemcpyDeviceToHost));
+  PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist, dbad, sizeof(bad), &bad));
+  PHX_CHECK(phx_end_timing_read(m, 1));
   PHX_HIP(phx_free(dbad));
-  PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist));
   m->have_facet_tags = true;
   m->have_entities = false;
   PHX_REQUIRE(bad == 0, PHX_ERR_PARTITION,
@@ -620,9 +625,10 @@ int phx_collect_entities(phx_mesh *m) {
     return PHX_OK;
   }
   int32_t *list = nullptr, *cnt = nullptr, *off = nullptr;
+  std::vector<void *> later;   // freed behind the synchronisation at the end
   {
     int64_t nsel = 0;
-    PHX_CHECK(phx_select_indices(st, m->nf, SelTag34{m->facet_tags}, &list, &nsel));
+    PHX_CHECK(phx_select_indices(st, m->nf, SelTag34{m->facet_tags}, &list, &nsel, &later));
     PHX_REQUIRE(nsel == nmax, PHX_ERR_VALUE, "facet tag histogram and selection disagree");
   }
   PHX_HIP(phx_malloc(&cnt, sizeof(int32_t) * 2 * (size_t)(nmax + 1)));
@@ -632,25 +638,31 @@ int phx_collect_entities(phx_mesh *m) {
   const dim3 grid((unsigned)phx_div_up(nmax, 256)), block(256);
   k_entities<false><<<grid, block, 0, st>>>(nmax, list, m->f2c, m->c2f, m->ci.nfpc, m->cell_tags,
                                             m->facet_tags, cnt0, cnt1, nullptr, nullptr, nullptr, nullptr);
-  for (int w = 0; w < 2; ++w) {
+  {
+    // both scans, then ONE host round trip for the two totals
+    int32_t tot[2] = {0, 0};
     size_t bytes = 0;
-    int32_t *ci = w == 0 ? cnt0 : cnt1, *oi = w == 0 ? off0 : off1;
-    PHX_HIP(phx_exclusive_sum(nullptr, bytes, ci, oi, (size_t)(nmax + 1), st));
+    PHX_HIP(phx_exclusive_sum(nullptr, bytes, cnt0, off0, (size_t)(nmax + 1), st));
     void *tmp = nullptr;
     PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-    PHX_HIP(phx_exclusive_sum(tmp, bytes, ci, oi, (size_t)(nmax + 1), st));
-    int32_t tot = 0;
-    PHX_HIP(hipMemcpyAsync(&tot, oi + nmax, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    for (int w = 0; w < 2; ++w) {
+      int32_t *ci = w == 0 ? cnt0 : cnt1, *oi = w == 0 ? off0 : off1;
+      PHX_HIP(phx_exclusive_sum(tmp, bytes, ci, oi, (size_t)(nmax + 1), st));
+      PHX_HIP(hipMemcpyAsync(&tot[w], oi + nmax, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
     PHX_HIP(hipStreamSynchronize(st));
     PHX_HIP(phx_free(tmp));
-    m->ent_count[w] = tot;
-    PHX_HIP(phx_malloc(&m->ent_buf[w], sizeof(int64_t) * 2 * (size_t)(tot > 0 ? tot : 1)));
+    for (int w = 0; w < 2; ++w) {
+      m->ent_count[w] = tot[w];
+      PHX_HIP(phx_malloc(&m->ent_buf[w], sizeof(int64_t) * 2 * (size_t)(tot[w] > 0 ? tot[w] : 1)));
+    }
   }
   k_entities<true><<<grid, block, 0, st>>>(nmax, list, m->f2c, m->c2f, m->ci.nfpc, m->cell_tags,
                                            m->facet_tags, nullptr, nullptr, off0, off1,
                                            m->ent_buf[0], m->ent_buf[1]);
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(st));
+  for (void *q : later) PHX_HIP(phx_free(q));
   PHX_HIP(phx_free(list)); PHX_HIP(phx_free(cnt)); PHX_HIP(phx_free(off));
   m->have_entities = true;
   return PHX_OK;
