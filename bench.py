@@ -313,10 +313,14 @@ def main(argv=None):
         dst_roof = None
         if dst_s > 0:
             a2 = res["dst_algorithmic_bytes"] / dst_s / 1e9
-            tr2, src2 = pmc_traffic("k_dst_s_y", res["dst_algorithmic_bytes"])
+            # f64 lattices of a wave-mode length run the shape-specialised kernel (phx_dst_wave.inc.hip)
+            wave = res["precond_value_bytes"] == 8 and res["precond_L"][1] in (192, 256, 512)
+            kname = (f"k_dst_yw<{res['precond_L'][1]}>" if wave else
+                     f"k_dst_s<{'float' if res['precond_value_bytes'] == 4 else 'double'},1,false>")
+            tr2, src2 = pmc_traffic("k_dst_yw" if wave else "k_dst_s_y", res["dst_algorithmic_bytes"])
             dst_roof = {
                 "bound": "hbm",
-                "kernel": f"k_dst_s<{'float' if res['precond_value_bytes'] == 4 else 'double'},1,false> (type-I sine "
+                "kernel": f"{kname} (type-I sine "
                           f"transform along y of the preconditioner lattice, "
                           f"f{8 * res['precond_value_bytes']}, one read + one write of every lattice point)",
                 "achieved": a2, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a2 / HBM_PEAK_GBS,

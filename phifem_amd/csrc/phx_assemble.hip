@@ -56,6 +56,21 @@ __global__ void k_finish_numbering(int64_t nv, const uint8_t *__restrict__ fu,
   du[v] = a;
   dp[v] = b;
 }
+// sup[v]: ranks of vertex v among the flagged u (low word) and p (high word) vertices -- ONE 64-bit scan of both flags
+__global__ void k_finish_numbering_packed(int64_t nv, const uint8_t *__restrict__ fu,
+                                   const uint8_t *__restrict__ fp,
+                                   const unsigned long long *__restrict__ sup,
+                                   int32_t nu, int32_t *__restrict__ du, int32_t *__restrict__ dp,
+                                   int64_t *__restrict__ full_of_active) {
+  const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  int32_t a = -1, b = -1;
+  const unsigned long long r = sup[v];
+  if (fu[v]) { a = (int32_t)(r & 0xffffffffull); full_of_active[a] = v; }
+  if (fp[v]) { b = nu + (int32_t)(r >> 32); full_of_active[b] = nv + v; }
+  du[v] = a;
+  dp[v] = b;
+}
 
 // ---------------------------------------------------------------------------------------------
 // row slots: a small open-addressing table of W (col,val) pairs per row.  A column claims a free
@@ -913,99 +928,6 @@ __global__ void __launch_bounds__(256) k_assemble_facets(int64_t nlist, const in
     for (int b = 0; b < M; ++b) slot_add(A.slots, rows[a], vd[b], w * Jd[a] * Jd[b]);
 }
 
-// ---- ghost penalty on a generated Kuhn box: the macro-element of an interior facet is one of 3 (2-D) / 12 (3-D)
-// translates, by facet class (phx_mesh.hip: facet id = base[class] + index of its anchor cube inside the class
-// extent).  k_facet_classes evaluates facet_macro ONCE per class on the facet anchored at cube (1, 1, 1); the assembly
-// kernel then needs nothing of the mesh but the facet id: class and anchor from the id, the D + 2 vertices as
-// anchor vertex + class offsets, the tensor w Jd Jd^T from the table -- no f2c / cells / c2f / coordinate loads and no
-// simplex geometry per facet (two cells x (4 vertex ids + 12 coordinates + 4 facet ids) and ~250 flops before).
-// The table entries equal the per-facet values up to the rounding of the vertex coordinates (lo + (hi - lo) t).
-struct BoxFacetIndex {
-  int ntypes;
-  int32_t base[13];
-  int32_t ext0[12], ext1[12];
-  int32_t vs1, vs2;       // vertex id strides of the y and z axes
-};
-struct FacetClassTab {
-  int32_t off[12][5];     // vertex ids of the macro-element minus the id of the anchor's lattice vertex
-  double J[12][5];
-  double w[12];
-};
-
-template <int D>
-__global__ void k_facet_classes(AsmArgs A, BoxFacetIndex bi, FacetClassTab *tab) {
-  const int t = threadIdx.x;
-  if (t >= bi.ntypes) return;
-  constexpr int M = D + 2;
-  const int64_t f = (int64_t)bi.base[t] + 1 + (int64_t)bi.ext0[t] * (1 + (D == 3 ? (int64_t)bi.ext1[t] : 0));
-  int32_t vd[M];
-  double Jd[M], w;
-  facet_macro<D>(A, f, vd, Jd, &w);
-  const int32_t va = 1 + bi.vs1 + (D == 3 ? bi.vs2 : 0);
-  for (int a = 0; a < M; ++a) { tab->off[t][a] = vd[a] - va; tab->J[t][a] = Jd[a]; }
-  tab->w[t] = w;
-}
-
-template <int D>
-__global__ void __launch_bounds__(256)
-k_assemble_facets_box(int64_t nlist, const int32_t *__restrict__ list, AsmArgs A, BoxFacetIndex bi,
-                      const FacetClassTab *__restrict__ tab) {
-  constexpr int M = D + 2;
-  __shared__ FacetClassTab T;
-  __shared__ int32_t e0s[12], e1s[12], bs[12];
-  for (int i = threadIdx.x; i < (int)(sizeof(FacetClassTab) / 4); i += blockDim.x)
-    reinterpret_cast<int32_t *>(&T)[i] = reinterpret_cast<const int32_t *>(tab)[i];
-  if (threadIdx.x < 12) { e0s[threadIdx.x] = bi.ext0[threadIdx.x]; e1s[threadIdx.x] = bi.ext1[threadIdx.x]; bs[threadIdx.x] = bi.base[threadIdx.x]; }
-  __syncthreads();
-  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (e >= nlist) return;
-  const int32_t f = list[e];
-  int type = 0;
-#pragma unroll
-  for (int t = 1; t < 12; ++t) type += (t < bi.ntypes && f >= bi.base[t]) ? 1 : 0;
-  const uint32_t r = (uint32_t)(f - bs[type]);
-  const uint32_t e0 = (uint32_t)e0s[type], e1 = (uint32_t)e1s[type];
-  const uint32_t q = r / e0, o0 = r - q * e0;
-  const uint32_t o2 = D == 3 ? q / e1 : 0u, o1 = D == 3 ? q - o2 * e1 : q;
-  const int32_t va = (int32_t)(o0 + (uint32_t)bi.vs1 * o1 + (uint32_t)bi.vs2 * o2);
-  int32_t vd[M], rows[M];
-  double Jd[M];
-#pragma unroll
-  for (int a = 0; a < M; ++a) { vd[a] = va + T.off[type][a]; Jd[a] = T.J[type][a]; }
-  const double w = T.w[type];
-#pragma unroll
-  for (int a = 0; a < M; ++a) rows[a] = A.du[vd[a]];
-#pragma unroll
-  for (int a = 0; a < M; ++a)
-#pragma unroll
-    for (int b = 0; b < M; ++b) slot_add(A.slots, rows[a], vd[b], w * Jd[a] * Jd[b]);
-}
-
-// facet index of a generated box (the numbers phx_mesh_create_box derives its connectivities from); false when a
-// class has no facet anchored at cube (1, 1, 1) with two cells (fewer than two cubes along an axis)
-static bool box_facet_index(const phx_mesh *m, BoxFacetIndex *bi) {
-  const int D = m->gdim;
-  memset(bi, 0, sizeof(*bi));
-  for (int a = 0; a < D; ++a) if (m->box_n[a] < 2) return false;
-  bi->ntypes = D == 3 ? 12 : 3;
-  int64_t base = 0;
-  for (int t = 0; t < bi->ntypes; ++t) {
-    int64_t ext[3];
-    for (int a = 0; a < 3; ++a) ext[a] = a < D ? m->box_n[a] : 1;
-    if (D == 3 && t < 6) ext[t / 2] += 1;
-    if (D == 2 && t < 2) ext[t] += 1;
-    bi->base[t] = (int32_t)base;
-    bi->ext0[t] = (int32_t)ext[0];
-    bi->ext1[t] = (int32_t)ext[1];
-    base += ext[0] * ext[1] * ext[2];
-  }
-  bi->base[bi->ntypes] = (int32_t)base;
-  if (base != m->nf) return false;
-  bi->vs1 = (int32_t)(m->box_n[0] + 1);
-  bi->vs2 = D == 3 ? (int32_t)((m->box_n[0] + 1) * (m->box_n[1] + 1)) : 0;
-  return true;
-}
-
 // deterministic accumulation: value = hi + lo
 __global__ void k_det_finalize(int64_t n, double *__restrict__ acc, const double *__restrict__ lo) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1048,8 +970,8 @@ static int det_finish(phx_mesh *m, Slots &sl, int64_t nslots, int64_t nrows, dou
 
 template <typename Pred>
 static int build_list(phx_mesh *m, int64_t n, Pred pred, int32_t **list, int64_t *count,
-                      std::vector<void *> *later = nullptr) {
-  return phx_select_indices(m->stream, n, pred, list, count, later);
+                      std::vector<void *> *later = nullptr, const int32_t *known_counts = nullptr) {
+  return phx_select_indices(m->stream, n, pred, list, count, later, known_counts);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1277,11 +1199,36 @@ static int scan_flags(phx_mesh *m, const uint8_t *flags, int32_t *out, int64_t n
   PHX_HIP(phx_exclusive_sum(tmp, bytes, it, out, (size_t)(n), m->stream));
   int32_t last = 0;
   uint8_t lastf = 0;
-  PHX_HIP(hipMemcpyAsync(&last, out + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
-  PHX_HIP(hipMemcpyAsync(&lastf, flags + (n - 1), 1, hipMemcpyDeviceToHost, m->stream));
-  PHX_HIP(hipStreamSynchronize(m->stream));
+  const phx_rb_item rb[2] = {{out + (n - 1), 4, &last}, {flags + (n - 1), 1, &lastf}};
+  PHX_CHECK(phx_read_back(m->stream, rb, 2));
   PHX_HIP(phx_free(tmp));
   *total = last + (int32_t)lastf;
+  return PHX_OK;
+}
+
+// two flag arrays of the same entities as ONE scan of 64-bit words (low word: a, high word: b; the totals stay below
+// 2^31), both totals with one host round trip
+struct PackFlags2 {
+  const uint8_t *fa, *fb;
+  __host__ __device__ unsigned long long operator()(const int64_t &i) const {
+    return (unsigned long long)fa[i] | ((unsigned long long)fb[i] << 32);
+  }
+};
+static int scan_flags_packed(phx_mesh *m, const uint8_t *fa, const uint8_t *fb, unsigned long long *out, int32_t *ta,
+                             int32_t *tb, int64_t n) {
+  auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), PackFlags2{fa, fb});
+  size_t bytes = 0;
+  PHX_HIP(phx_exclusive_sum(nullptr, bytes, it, out, (size_t)(n), m->stream));
+  void *tmp = nullptr;
+  PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(phx_exclusive_sum(tmp, bytes, it, out, (size_t)(n), m->stream));
+  unsigned long long last = 0;
+  uint8_t la = 0, lb = 0;
+  const phx_rb_item rb[3] = {{out + (n - 1), 8, &last}, {fa + (n - 1), 1, &la}, {fb + (n - 1), 1, &lb}};
+  PHX_CHECK(phx_read_back(m->stream, rb, 3));
+  PHX_HIP(phx_free(tmp));
+  *ta = (int32_t)(last & 0xffffffffull) + (int32_t)la;
+  *tb = (int32_t)(last >> 32) + (int32_t)lb;
   return PHX_OK;
 }
 
@@ -1298,11 +1245,9 @@ static int scan_flags2(phx_mesh *m, const uint8_t *fa, int32_t *oa, int32_t *ta,
   PHX_HIP(phx_exclusive_sum(tmp, bytes, ib, ob, (size_t)(n), m->stream));
   int32_t last[2] = {0, 0};
   uint8_t lastf[2] = {0, 0};
-  PHX_HIP(hipMemcpyAsync(&last[0], oa + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
-  PHX_HIP(hipMemcpyAsync(&lastf[0], fa + (n - 1), 1, hipMemcpyDeviceToHost, m->stream));
-  PHX_HIP(hipMemcpyAsync(&last[1], ob + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, m->stream));
-  PHX_HIP(hipMemcpyAsync(&lastf[1], fb + (n - 1), 1, hipMemcpyDeviceToHost, m->stream));
-  PHX_HIP(hipStreamSynchronize(m->stream));
+  const phx_rb_item rb[4] = {{oa + (n - 1), 4, &last[0]}, {fa + (n - 1), 1, &lastf[0]}, {ob + (n - 1), 4, &last[1]},
+                             {fb + (n - 1), 1, &lastf[1]}};
+  PHX_CHECK(phx_read_back(m->stream, rb, 4));
   PHX_HIP(phx_free(tmp));
   *ta = last[0] + (int32_t)lastf[0];
   *tb = last[1] + (int32_t)lastf[1];
@@ -1455,23 +1400,22 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   const dim3 block(256);
   // ---- active numbering
   uint8_t *fu = nullptr, *fp = nullptr;
-  int32_t *su = nullptr, *sp = nullptr;
+  unsigned long long *sup = nullptr;
   PHX_HIP(phx_malloc(&fu, (size_t)m->nv));
   PHX_HIP(phx_malloc(&fp, (size_t)m->nv));
-  PHX_HIP(phx_malloc(&su, sizeof(int32_t) * (size_t)m->nv));
-  PHX_HIP(phx_malloc(&sp, sizeof(int32_t) * (size_t)m->nv));
+  PHX_HIP(phx_malloc(&sup, sizeof(unsigned long long) * (size_t)m->nv));
   PHX_HIP(hipMemsetAsync(fu, 0, (size_t)m->nv, m->stream));
   PHX_HIP(hipMemsetAsync(fp, 0, (size_t)m->nv, m->stream));
   const dim3 gcells((unsigned)phx_div_up(phx_div_up(m->nc, 4), 256));
   if (D == 2) k_mark_active<3><<<gcells, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, fu, fp);
   else k_mark_active<4><<<gcells, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, fu, fp);
   int32_t nu = 0, np = 0;
-  PHX_CHECK(scan_flags2(m, fu, su, &nu, fp, sp, &np, m->nv));
+  PHX_CHECK(scan_flags_packed(m, fu, fp, sup, &nu, &np, m->nv));
   s->nu = nu;
   s->n = (int64_t)nu + np;
   if (s->n == 0) {
     PHX_HIP(hipStreamSynchronize(m->stream));
-    PHX_HIP(phx_free(fu)); PHX_HIP(phx_free(fp)); PHX_HIP(phx_free(su)); PHX_HIP(phx_free(sp));
+    PHX_HIP(phx_free(fu)); PHX_HIP(phx_free(fp)); PHX_HIP(phx_free(sup));
     if (!m->allow_empty) {
       delete s;
       phx_set_error("no active DoF: no cell is tagged 1 or 2");
@@ -1492,15 +1436,17 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   PHX_HIP(phx_malloc(&s->dof_of_vertex_u, sizeof(int32_t) * (size_t)m->nv));
   PHX_HIP(phx_malloc(&s->dof_of_vertex_p, sizeof(int32_t) * (size_t)m->nv));
   PHX_HIP(phx_malloc(&s->full_of_active, sizeof(int64_t) * (size_t)s->n));
-  k_finish_numbering<<<dim3((unsigned)phx_div_up(m->nv, 256)), block, 0, m->stream>>>(
-      m->nv, fu, fp, su, sp, nu, s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active);
+  k_finish_numbering_packed<<<dim3((unsigned)phx_div_up(m->nv, 256)), block, 0, m->stream>>>(
+      m->nv, fu, fp, sup, nu, s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active);
   // temporaries whose last kernel is only enqueued: freed behind the synchronisation in front of finish_*
-  std::vector<void *> later = {fu, fp, su, sp};
+  std::vector<void *> later = {fu, fp, sup};
   // ---- element kernels run over compacted work lists
   int32_t *l_cut = nullptr, *l_fac = nullptr;
   int64_t n_cut = 0, n_fac = 0;
-  PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut, &later));
-  PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac, &later));
+  PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut, &later,
+                       m->sel_cut_valid ? m->sel_counts_cut : nullptr));       // counted by the cell tagging kernel
+  PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac, &later,
+                       m->sel_counts_valid ? m->sel_counts[0] : nullptr));   // counted by the facet tagging kernel
   Slots sl;
   sl.W = W;
   sl.cols = nullptr; sl.vals = nullptr; sl.overflow = nullptr;
@@ -1649,27 +1595,17 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
     }
   }
   PHX_HIP(hipGetLastError());
-  FacetClassTab *ftab = nullptr;
   if (n_fac > 0) {
+    // (Per-class macro-element tables for generated boxes -- vertices as anchor + class offsets, the tensor w Jd Jd^T from
+    // a table, no f2c / cells / c2f / coordinate loads and no simplex geometry per facet -- were measured at 1.46 ms against
+    // 1.49 ms for this kernel at 256^3: the 5e7 hashed f64 atomics are the whole cost.  Not kept.)
     const dim3 g((unsigned)phx_div_up(n_fac, 256));
-    static const bool facet_generic = getenv("PHX_FACET_GENERIC") && atoi(getenv("PHX_FACET_GENERIC")) != 0;   // A/B aid
-    BoxFacetIndex bi;
-    if (m->is_box && !m->is_submesh && !facet_generic && box_facet_index(m, &bi)) {
-      PHX_HIP(phx_malloc(&ftab, sizeof(FacetClassTab)));
-      if (D == 2) {
-        k_facet_classes<2><<<1, 64, 0, m->stream>>>(A, bi, ftab);
-        k_assemble_facets_box<2><<<g, block, 0, m->stream>>>(n_fac, l_fac, A, bi, ftab);
-      } else {
-        k_facet_classes<3><<<1, 64, 0, m->stream>>>(A, bi, ftab);
-        k_assemble_facets_box<3><<<g, block, 0, m->stream>>>(n_fac, l_fac, A, bi, ftab);
-      }
-    } else if (D == 2) k_assemble_facets<2><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
+    if (D == 2) k_assemble_facets<2><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
     else k_assemble_facets<3><<<g, block, 0, m->stream>>>(n_fac, l_fac, A);
   }
   PHX_HIP(hipGetLastError());
   PHX_HIP(hipStreamSynchronize(m->stream));
   for (void *q : later) PHX_HIP(phx_free(q));
-  if (ftab) PHX_HIP(phx_free(ftab));
   PHX_HIP(phx_free(l_cut)); PHX_HIP(phx_free(l_fac));
   if (touched) PHX_HIP(phx_free(touched));
   if (stored_rows) PHX_HIP(phx_free(stored_rows));
@@ -1731,6 +1667,8 @@ static int assemble_poisson_wd_on_inner(phx_mesh *m, double pen_coef, double sta
   k_push_tags<<<dim3((unsigned)phx_div_up(m->nc, 256)), block, 0, st>>>(m->nc, m->in_cmap, m->cell_tags, in->cell_tags);
   k_push_tags<<<dim3((unsigned)phx_div_up(m->nf, 256)), block, 0, st>>>(m->nf, m->in_fmap, m->facet_tags, in->facet_tags);
   in->have_cell_tags = in->have_facet_tags = true;
+  in->sel_counts_valid = false;
+  in->sel_cut_valid = false;
   in->have_entities = false;
   for (int i = 0; i < 4; ++i) in->tag_hist[i] = m->tag_hist[i];
   for (int i = 0; i < 8; ++i) in->ftag_hist[i] = m->ftag_hist[i];

@@ -111,6 +111,13 @@ struct phx_mesh {
   bool have_cell_tags = false, have_facet_tags = false;
   int64_t tag_hist[4] = {0, 0, 0, 0};
   int64_t ftag_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // per-chunk counts (chunks of 2048 facets, phx_select.h) of the two facet selections every assembly starts with,
+  // left behind by the facet tagging kernel: [0] ghost-penalty facets (tag 2 / 3, interior), [1] tags 3 / 4.  Valid
+  // while sel_counts_valid (the facet tags are the ones k_tag_facets wrote).
+  int32_t *sel_counts[2] = {nullptr, nullptr};
+  bool sel_counts_valid = false;
+  int32_t *sel_counts_cut = nullptr;   // the same for the cut cells (tag 2), left behind by the last cell tagging kernel
+  bool sel_cut_valid = false;
   // integration entities of the current tags (device, unordered): (key, cell, lf) triples
   int64_t *ent_buf[2] = {nullptr, nullptr};
   int64_t ent_count[2] = {0, 0};
@@ -294,6 +301,11 @@ int phx_mesh_build_edges(phx_mesh *m);
 int phx_mesh_create_from(int gdim, int cell_type, int64_t nv, const double *coords, int64_t nc,
                          const int32_t *cells, int loc, int device, phx_mesh **out);
 int phx_mesh_pinned_scalars(phx_mesh *m, double **out);
+// Several small device values to the host with ONE round trip on `st`: a one-wave kernel packs them into a staging
+// block, one copy lands in pinned memory.  (Every hipMemcpyAsync into a pageable host variable is a round trip of its
+// own, ~20 us each: the totals of two scans cost four.)  At most 8 items of at most 64 bytes.
+struct phx_rb_item { const void *dev; int bytes; void *host; };
+int phx_read_back(hipStream_t st, const phx_rb_item *items, int n);
 
 int phx_system_build_empty(phx_system *s);  // phx_solve.hip
 // row slots of the assembly as the SELL builder of structured systems reads them (phx_assemble.hip: Slots)

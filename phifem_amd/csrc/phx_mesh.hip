@@ -1030,6 +1030,8 @@ extern "C" int phx_mesh_destroy(phx_mesh *m) {
   if (m->inner) { phx_mesh_destroy(m->inner); m->inner = nullptr; }
   if (m->scal_h) (void)hipHostFree(m->scal_h);
   for (auto &pe : m->prof_ev) for (auto &e : pe) (void)hipEventDestroy(e);
+  for (int w = 0; w < 2; ++w) (void)phx_free(m->sel_counts[w]);
+  (void)phx_free(m->sel_counts_cut);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);
@@ -1040,6 +1042,48 @@ extern "C" int phx_mesh_destroy(phx_mesh *m) {
 extern "C" int phx_mesh_counts(const phx_mesh *m, int64_t *counts) {
   counts[0] = m->gdim; counts[1] = m->cell_type; counts[2] = m->nv;
   counts[3] = m->nc; counts[4] = m->nf; counts[5] = m->nbf;
+  return PHX_OK;
+}
+
+struct RbArgs { const uint8_t *src[8]; int bytes[8], off[8], n; };
+__global__ void k_rb_pack(RbArgs a, uint8_t *__restrict__ out) {
+  for (int i = 0; i < a.n; ++i)
+    for (int b = threadIdx.x; b < a.bytes[i]; b += blockDim.x) out[a.off[i] + b] = a.src[i][b];
+}
+int phx_read_back(hipStream_t st, const phx_rb_item *items, int n) {
+  PHX_REQUIRE(n >= 1 && n <= 8, PHX_ERR_VALUE, "read-back of %d items", n);
+  // staging blocks per (device, stream): a handful per process, alive until it ends
+  struct Stage { uint8_t *dev = nullptr, *pin = nullptr; };
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Stage> stages;
+  int dev = 0;
+  PHX_HIP(hipGetDevice(&dev));
+  Stage sg;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    Stage &ref = stages[{dev, st}];
+    if (!ref.dev) {
+      PHX_HIP(hipMalloc(&ref.dev, 512));
+      PHX_HIP(hipHostMalloc(&ref.pin, 512));
+    }
+    sg = ref;
+  }
+  RbArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n = n;
+  int tot = 0;
+  for (int i = 0; i < n; ++i) {
+    PHX_REQUIRE(items[i].bytes > 0 && items[i].bytes <= 64, PHX_ERR_VALUE, "read-back item of %d bytes", items[i].bytes);
+    a.src[i] = static_cast<const uint8_t *>(items[i].dev);
+    a.bytes[i] = items[i].bytes;
+    a.off[i] = tot;
+    tot += (items[i].bytes + 7) & ~7;
+  }
+  k_rb_pack<<<1, 64, 0, st>>>(a, sg.dev);
+  PHX_HIP(hipGetLastError());
+  PHX_HIP(hipMemcpyAsync(sg.pin, sg.dev, (size_t)tot, hipMemcpyDeviceToHost, st));
+  PHX_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) memcpy(items[i].host, sg.pin + a.off[i], (size_t)items[i].bytes);
   return PHX_OK;
 }
 

@@ -24,6 +24,7 @@
 #include <math.h>
 
 #include <map>
+#include <tuple>
 
 #define PHX_PRECOND_MARGIN 4   // lattice planes between the active vertices and the Dirichlet faces of the box
 
@@ -716,7 +717,7 @@ static void box_precond_free(phx_box_precond *bp) {
   (void)phx_free(bp->G); (void)phx_free(bp->gmap); (void)phx_free(bp->dscale); (void)phx_free(bp->iscale); (void)phx_free(bp->line_any); (void)phx_free(bp->line_iv);
   if (!bp->carry_borrowed) { (void)phx_free(bp->carry_send); (void)phx_free(bp->carry_recv); }
   (void)phx_free(bp->tri_in);
-  for (int a = 0; a < 3; ++a) (void)phx_free(bp->lam[a]);
+  for (int a = 0; a < 3; ++a) if (bp->lam[a]) (void)hipFree(bp->lam[a]);   // only tables the cache did not take
   delete bp;
 }
 
@@ -776,12 +777,26 @@ static int box_grid_setup(phx_box_precond *bp, int device, const int L[3], const
   g.plane = g.pitch * g.m[1];
   g.scale = (2.0 / L[0]) * (2.0 / L[1]) * (2.0 / L[2]);
   for (int a = 0; a < 3; ++a) {
+    // eigenvalue tables: constants of (length, coefficient) like the twiddle tables of a plan -- kept per process (a
+    // step that re-assembles the same box found three blocking uploads and three hipMalloc / hipFree pairs here)
+    static std::map<std::tuple<int, int, uint64_t>, double *> lam_cache;
+    uint64_t cbits;
+    memcpy(&cbits, &c[a], sizeof(cbits));
+    const auto key = std::make_tuple(device, L[a], cbits);
+    auto it = lam_cache.find(key);
+    if (it != lam_cache.end()) {
+      g.lam[a] = it->second;
+      continue;
+    }
     std::vector<double> lam((size_t)L[a]);
     for (int k = 0; k < L[a]; ++k)
       lam[k] = c[a] * (2.0 - 2.0 * cos(3.14159265358979323846 * (double)k / (double)L[a]));
-    PHX_HIP(phx_malloc(&bp->lam[a], sizeof(double) * (size_t)L[a]));
-    PHX_HIP(hipMemcpy(bp->lam[a], lam.data(), sizeof(double) * (size_t)L[a], hipMemcpyHostToDevice));
-    g.lam[a] = bp->lam[a];
+    double *d = nullptr;
+    PHX_HIP(hipMalloc(&d, sizeof(double) * (size_t)L[a]));
+    PHX_HIP(hipMemcpy(d, lam.data(), sizeof(double) * (size_t)L[a], hipMemcpyHostToDevice));
+    if (lam_cache.size() < 256) lam_cache[key] = d;   // beyond that the table lives and dies with this lattice
+    else bp->lam[a] = d;
+    g.lam[a] = d;
   }
   PHX_HIP(phx_malloc(&bp->G, (f32 ? sizeof(float) : sizeof(double)) * (size_t)(g.plane * g.m[2])));
   return PHX_OK;
@@ -1131,6 +1146,7 @@ __global__ void k_dscale_weighted(int64_t n, const int32_t *__restrict__ perm, c
 // solve, any length).
 #define PHX_PRECOND_MARGIN_OPEN 32
 // lattice bounding box of this rank's (owned) active u DoFs in LOCAL lattice coordinates; hbb[3] < 0: none
+__global__ void k_bbox_init(int *bb) { bb[threadIdx.x] = threadIdx.x < 3 ? INT_MAX : -1; }
 static int box_local_bbox(phx_system *s, bool p2, int hbb[6]) {
   phx_mesh *m = s->mesh;
   hipStream_t st = m->stream;
@@ -1139,7 +1155,7 @@ static int box_local_bbox(phx_system *s, bool p2, int hbb[6]) {
   const int init[6] = {INT_MAX, INT_MAX, INT_MAX, -1, -1, -1};
   for (int i = 0; i < 6; ++i) hbb[i] = init[i];
   PHX_HIP(phx_malloc(&dbb, sizeof(init)));
-  PHX_HIP(hipMemcpyAsync(dbb, init, sizeof(init), hipMemcpyHostToDevice, st));
+  k_bbox_init<<<1, 6, 0, st>>>(dbb);   // (an upload from a pageable host array is a host round trip)
   if (p2)
     k_active_bbox_p2<<<dim3((unsigned)std::min<int64_t>(phx_div_up(s->nent, 256), 1024)), dim3(256), 0, st>>>(
         s->nent, m->nv, n0, n1, m->edges, s->dof_of_vertex_u, s->iperm, s->own, dbb);

@@ -71,23 +71,28 @@ k_select_chunks(int64_t n, Pred pred, int32_t *__restrict__ chunk_counts,
 // Allocates *list with exactly the kept count (at least one entry) and returns the count.
 // later (nullable): the caller synchronises `stream` before it frees what is pushed here -- the fill pass is then only
 // enqueued (one host round trip per selection instead of two).
+// known_counts (nullable): the per-chunk counts [nchunks + 1, last entry 0] are already on the device (the kernel that
+// wrote the tags counted) -- the counting pass over the items is skipped.
 template <typename Pred>
 static int phx_select_indices(hipStream_t stream, int64_t n, Pred pred, int32_t **list, int64_t *count,
-                              std::vector<void *> *later = nullptr) {
+                              std::vector<void *> *later = nullptr, const int32_t *known_counts = nullptr) {
   *list = nullptr;
   *count = 0;
   const int64_t nchunks = phx_div_up(n > 0 ? n : 1, (int64_t)PHX_SEL_CHUNK);
   int32_t *cnt = nullptr, *off = nullptr;
-  PHX_HIP(phx_malloc(&cnt, sizeof(int32_t) * (size_t)(nchunks + 1)));
   PHX_HIP(phx_malloc(&off, sizeof(int32_t) * (size_t)(nchunks + 1)));
-  PHX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(nchunks + 1), stream));
   const dim3 block(256), grid((unsigned)phx_div_up(nchunks, 4));
-  if (n > 0) k_select_chunks<Pred, false><<<grid, block, 0, stream>>>(n, pred, cnt, nullptr, nullptr);
+  if (!known_counts) {
+    PHX_HIP(phx_malloc(&cnt, sizeof(int32_t) * (size_t)(nchunks + 1)));
+    PHX_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(nchunks + 1), stream));
+    if (n > 0) k_select_chunks<Pred, false><<<grid, block, 0, stream>>>(n, pred, cnt, nullptr, nullptr);
+    known_counts = cnt;
+  }
   size_t bytes = 0;
-  PHX_HIP(phx_exclusive_sum(nullptr, bytes, cnt, off, (size_t)(nchunks + 1), stream));
+  PHX_HIP(phx_exclusive_sum(nullptr, bytes, known_counts, off, (size_t)(nchunks + 1), stream));
   void *tmp = nullptr;
   PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-  PHX_HIP(phx_exclusive_sum(tmp, bytes, cnt, off, (size_t)(nchunks + 1), stream));
+  PHX_HIP(phx_exclusive_sum(tmp, bytes, known_counts, off, (size_t)(nchunks + 1), stream));
   int32_t total = 0;
   PHX_HIP(hipMemcpyAsync(&total, off + nchunks, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   PHX_HIP(hipStreamSynchronize(stream));
@@ -95,7 +100,8 @@ static int phx_select_indices(hipStream_t stream, int64_t n, Pred pred, int32_t 
   if (total > 0) k_select_chunks<Pred, true><<<grid, block, 0, stream>>>(n, pred, nullptr, off, *list);
   PHX_HIP(hipGetLastError());
   if (later) {
-    later->push_back(tmp); later->push_back(cnt); later->push_back(off);
+    later->push_back(tmp); later->push_back(off);
+    if (cnt) later->push_back(cnt);
   } else {
     PHX_HIP(hipStreamSynchronize(stream));
     PHX_HIP(phx_free(tmp)); PHX_HIP(phx_free(cnt)); PHX_HIP(phx_free(off));

@@ -370,6 +370,80 @@ __global__ void k_stored_keys(int64_t ns, const int32_t *__restrict__ list, cons
   keys[i] = key;
 }
 
+// Stable counting sort of (key, value) pairs with keys < 1024 (the stored rows by length: half a million items, a few
+// dozen distinct keys).  rocPRIM sorts an input of this size with a merge sort: 23 launches of 5-8 us each, more than
+// the SELL fill it feeds.  Here: one wavefront per segment of 256 consecutive items, keys in [klo, klo + nk).  Pass 1 leaves H[key][segment] =
+// items of the segment with that key; an exclusive scan over H in (key, segment) order turns the counts into
+// destinations; pass 2 sends every item to H[key][segment] + its rank among the equal keys of its segment before it
+// (equal keys of one round of 64 items are peeled off with ballots, in lane order).  Four launches.
+#define PHX_CSORT_KEYS 1024
+#define PHX_CSORT_SEG 256
+template <bool SCATTER>
+__global__ void __launch_bounds__(256)
+k_csort(int64_t n, const uint32_t *__restrict__ keys, const int32_t *__restrict__ vals, int64_t nseg, uint32_t klo, int nk,
+        int32_t *__restrict__ H, uint32_t *__restrict__ keys_out, int32_t *__restrict__ vals_out) {
+  __shared__ int32_t cnt[4][PHX_CSORT_KEYS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t seg = blockIdx.x * (int64_t)4 + wv;
+  if (seg >= nseg) return;   // no block-wide synchronisation below: a wave works on its own LDS strip
+  int32_t *c = cnt[wv];
+  for (int i = lane; i < nk; i += 64) c[i] = SCATTER ? H[(int64_t)i * nseg + seg] : 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int64_t base = seg * PHX_CSORT_SEG;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int r = 0; r < PHX_CSORT_SEG / 64; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    const bool ok = i < n;
+    const uint32_t k = ok ? min(max(keys[i], klo) - klo, (uint32_t)(nk - 1)) : 0u;
+    const int32_t v = SCATTER && ok ? vals[i] : 0;
+    unsigned long long todo = __ballot(ok);
+    while (todo) {
+      const int first = __ffsll((long long)todo) - 1;
+      const uint32_t kf = (uint32_t)__shfl((int)k, first);
+      const bool mine = ok && k == kf;
+      const unsigned long long same = __ballot(mine);
+      if (SCATTER && mine) {
+        const int64_t dst = (int64_t)c[kf] + __popcll(same & below);
+        keys_out[dst] = keys[i];
+        vals_out[dst] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == first) c[kf] += __popcll(same);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      todo &= ~same;
+    }
+  }
+  if (!SCATTER)
+    for (int i = lane; i < nk; i += 64) H[(int64_t)i * nseg + seg] = c[i];
+}
+
+// keys_out / vals_out = the pairs sorted by key (< 1024), stable.  `later`: temporaries, freed by the caller behind its
+// next synchronisation.
+static int phx_counting_sort_pairs(hipStream_t st, const uint32_t *keys, uint32_t *keys_out, const int32_t *vals,
+                                   int32_t *vals_out, int64_t n, uint32_t klo, int nk, std::vector<void *> *later) {
+  if (n <= 0) return PHX_OK;
+  PHX_REQUIRE(nk >= 1 && nk <= PHX_CSORT_KEYS, PHX_ERR_VALUE, "counting sort over %d keys", nk);
+  const int64_t nseg = phx_div_up(n, (int64_t)PHX_CSORT_SEG);
+  const size_t nh = (size_t)nk * (size_t)nseg;
+  int32_t *H = nullptr, *H2 = nullptr;
+  PHX_HIP(phx_malloc(&H, sizeof(int32_t) * nh));
+  PHX_HIP(phx_malloc(&H2, sizeof(int32_t) * nh));
+  const dim3 grid((unsigned)phx_div_up(nseg, 4)), block(256);
+  k_csort<false><<<grid, block, 0, st>>>(n, keys, vals, nseg, klo, nk, H, nullptr, nullptr);
+  size_t bytes = 0;
+  PHX_HIP(phx_exclusive_sum(nullptr, bytes, H, H2, nh, st));
+  void *tmp = nullptr;
+  PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
+  PHX_HIP(phx_exclusive_sum(tmp, bytes, H, H2, nh, st));
+  k_csort<true><<<grid, block, 0, st>>>(n, keys, vals, nseg, klo, nk, H2, keys_out, vals_out);
+  PHX_HIP(hipGetLastError());
+  later->push_back(H); later->push_back(H2); later->push_back(tmp);
+  return PHX_OK;
+}
+
 __global__ void k_fill_i32(int64_t n, int32_t *__restrict__ a, int32_t v, int iota) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) a[i] = iota ? (int32_t)i : v;
@@ -572,9 +646,8 @@ static int scan_u8(hipStream_t st, const uint8_t *flags, int32_t *out, int64_t n
   PHX_HIP(phx_exclusive_sum(tmp, bytes, it, out, (size_t)(n), st));
   int32_t last = 0;
   uint8_t lastf = 0;
-  PHX_HIP(hipMemcpyAsync(&last, out + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  PHX_HIP(hipMemcpyAsync(&lastf, flags + (n - 1), 1, hipMemcpyDeviceToHost, st));
-  PHX_HIP(hipStreamSynchronize(st));
+  const phx_rb_item rb[2] = {{out + (n - 1), 4, &last}, {flags + (n - 1), 1, &lastf}};
+  PHX_CHECK(phx_read_back(st, rb, 2));
   PHX_HIP(phx_free(tmp));
   *total = last + (int32_t)lastf;
   return PHX_OK;
@@ -592,11 +665,9 @@ static int scan_u8_pair(hipStream_t st, const uint8_t *fa, int32_t *oa, int32_t 
   PHX_HIP(phx_exclusive_sum(tmp, bytes, ib, ob, (size_t)(n), st));
   int32_t last[2] = {0, 0};
   uint8_t lastf[2] = {0, 0};
-  PHX_HIP(hipMemcpyAsync(&last[0], oa + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  PHX_HIP(hipMemcpyAsync(&lastf[0], fa + (n - 1), 1, hipMemcpyDeviceToHost, st));
-  PHX_HIP(hipMemcpyAsync(&last[1], ob + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  PHX_HIP(hipMemcpyAsync(&lastf[1], fb + (n - 1), 1, hipMemcpyDeviceToHost, st));
-  PHX_HIP(hipStreamSynchronize(st));
+  const phx_rb_item rb[4] = {{oa + (n - 1), 4, &last[0]}, {fa + (n - 1), 1, &lastf[0]}, {ob + (n - 1), 4, &last[1]},
+                             {fb + (n - 1), 1, &lastf[1]}};
+  PHX_CHECK(phx_read_back(st, rb, 4));
   PHX_HIP(phx_free(tmp));
   *ta = last[0] + (int32_t)lastf[0];
   *tb = last[1] + (int32_t)lastf[1];
@@ -673,10 +744,17 @@ int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t 
     k_stored_keys<<<gs, block, 0, st>>>(ns, list, len, keys, s->full_of_active, m->nv, n0, n01, tile, tn[0], tn[1]);
     k_fill_i32<<<dim3((unsigned)phx_div_up(s->nslices * SELL_S, 256)), block, 0, st>>>(s->nslices * SELL_S, rows_active, -1, 0);
     size_t bytes = 0;
-    PHX_HIP(phx_sort_pairs(nullptr, bytes, keys, keys2, list, rows_active, (size_t)ns, 0, key_bits, st));
     void *tmp = nullptr;
-    PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
-    PHX_HIP(phx_sort_pairs(tmp, bytes, keys, keys2, list, rows_active, (size_t)ns, 0, key_bits, st));
+    static const bool sort_rocprim = getenv("PHX_SORT_ROCPRIM") && atoi(getenv("PHX_SORT_ROCPRIM")) != 0;   // A/B aid
+    if (key_bits <= 10 && !sort_rocprim) {
+      // keys = 1023 - row length, and a row holds at most slot-capacity entries
+      const int wmax = std::min(std::max(sv.W, 1), 1023);
+      PHX_CHECK(phx_counting_sort_pairs(st, keys, keys2, list, rows_active, ns, (uint32_t)(1023 - wmax), wmax + 1, &later));
+    } else {
+      PHX_HIP(phx_sort_pairs(nullptr, bytes, keys, keys2, list, rows_active, (size_t)ns, 0, key_bits, st));
+      PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
+      PHX_HIP(phx_sort_pairs(tmp, bytes, keys, keys2, list, rows_active, (size_t)ns, 0, key_bits, st));
+    }
     PHX_HIP(hipMemcpyAsync(s->sell_rows, rows_active, sizeof(int32_t) * (size_t)(s->nslices * SELL_S), hipMemcpyDeviceToDevice, st));
     k_map_i32<<<dim3((unsigned)phx_div_up(s->nslices * SELL_S, 256)), block, 0, st>>>(s->nslices * SELL_S, s->iperm, s->sell_rows);
     int64_t *widths = nullptr;

@@ -115,21 +115,47 @@ __global__ void k_mark_inside_vertices(int64_t nc, const int32_t *__restrict__ c
   }
 }
 
+// The last kernel that writes cell tags also counts them (as k_tag_facets does for the facets): hist_part[bin][block]
+// for the bins 0..3 and, per chunk of PHX_SEL_CHUNK cells, the cut cells (tag 2) the assembly will select.
+// Launched with 256 threads; touched == nullptr: no demotion (single_layer_cut off), counting only.
 template <int NVPC>
-__global__ void k_demote_isolated_cut(int64_t nc, const int32_t *__restrict__ cells,
-                                      int8_t *__restrict__ tags,
-                                      const uint8_t *__restrict__ touched) {
+__global__ void __launch_bounds__(256)
+k_demote_isolated_cut(int64_t nc, const int32_t *__restrict__ cells, int8_t *__restrict__ tags,
+                      const uint8_t *__restrict__ touched, uint32_t *__restrict__ hist_part,
+                      int32_t *__restrict__ sel_cut) {
+  __shared__ uint32_t lh[4][4];
   const int64_t c0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
-  if (c0 >= nc) return;
-  const uint32_t w = phx_tag_word(tags, c0, nc);
+  int tj[4] = {0x7f, 0x7f, 0x7f, 0x7f};
+  if (c0 < nc) {
+    const uint32_t w = phx_tag_word(tags, c0, nc);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (((w >> (8 * j)) & PHX_TAG_MASK) != 2u) continue;
-    const int64_t c = c0 + j;
-    bool keep = false;
-    for (int i = 0; i < NVPC; ++i) keep = keep || touched[cells[c * NVPC + i]];
-    if (!keep) tags[c] = 3;
+    for (int j = 0; j < 4; ++j) {
+      if (c0 + j >= nc) continue;
+      int t = (int)((w >> (8 * j)) & PHX_TAG_MASK);
+      if (t == 2 && touched) {
+        const int64_t c = c0 + j;
+        bool keep = false;
+        for (int i = 0; i < NVPC; ++i) keep = keep || touched[cells[c * NVPC + i]];
+        if (!keep) { tags[c] = 3; t = 3; }
+      }
+      tj[j] = t;
+    }
   }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) cnt[b] += (uint32_t)__popcll(__ballot(tj[j] == b));
+  if (lane == 0) {
+    const int64_t wbase = (blockIdx.x * (int64_t)blockDim.x + (threadIdx.x & ~63)) * 4;
+    if (wbase < nc && cnt[2]) atomicAdd(&sel_cut[wbase / PHX_SEL_CHUNK], (int32_t)cnt[2]);
+    for (int b = 0; b < 4; ++b) lh[wv][b] = cnt[b];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    hist_part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+        lh[0][threadIdx.x] + lh[1][threadIdx.x] + lh[2][threadIdx.x] + lh[3][threadIdx.x];
 }
 
 // Tag histogram: four tag bytes per lane and load, counted with ballots (the counters are
@@ -255,13 +281,20 @@ __device__ __forceinline__ int facet_rule(int2 cc, const int8_t *__restrict__ ct
 
 // four facets per thread: two 16-byte loads of f2c, one 4-byte store of the tags (a byte per lane and store left the
 // kernel at 1.9 TB/s of its 11 B per facet)
+// The kernel that writes the tags also counts them: hist_part[bin][block] (7 bins, summed by k_hist_fold: the separate
+// histogram pass re-read 2e8 tag bytes) and, per chunk of PHX_SEL_CHUNK facets, how many facets the two selections every
+// assembly starts with will keep (sel0: ghost-penalty facets = tag 2 / 3 with two cells; sel1: tags 3 / 4) -- their
+// counting passes re-read the tags (and f2c) as well.  A wavefront covers 256 consecutive facets of ONE chunk.
 __global__ void __launch_bounds__(256)
 k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restrict__ ctags,
              int no_ext, const uint8_t *__restrict__ exempt, int8_t *__restrict__ ftags,
-             unsigned long long *__restrict__ bad) {
+             unsigned long long *__restrict__ bad, uint32_t *__restrict__ hist_part,
+             int32_t *__restrict__ sel0, int32_t *__restrict__ sel1) {
+  __shared__ uint32_t lh[4][8];
   const int64_t f0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
-  if (f0 >= nf) return;
   int nbad = 0;
+  int8_t tj[4] = {0x7f, 0x7f, 0x7f, 0x7f};   // 0x7f: no facet here
+  bool two[4] = {false, false, false, false};
   if (f0 + 3 < nf) {
     const int4 a = *reinterpret_cast<const int4 *>(f2c + 2 * f0), b = *reinterpret_cast<const int4 *>(f2c + 2 * f0 + 4);
     const int2 cc[4] = {make_int2(a.x, a.y), make_int2(a.z, a.w), make_int2(b.x, b.y), make_int2(b.z, b.w)};
@@ -271,16 +304,61 @@ k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restri
       int8_t t = 0;
       if (!(exempt && exempt[f0 + j])) nbad += facet_rule(cc[j], ctags, no_ext, &t) != 1;   // exempt: cut through the global mesh, no tag
       w |= (uint32_t)(uint8_t)t << (8 * j);
+      tj[j] = t;
+      two[j] = cc[j].y >= 0;
     }
     *reinterpret_cast<uint32_t *>(ftags + f0) = w;
   } else {
     for (int64_t f = f0; f < nf; ++f) {
       int8_t t = 0;
-      if (!(exempt && exempt[f])) nbad += facet_rule(*reinterpret_cast<const int2 *>(f2c + 2 * f), ctags, no_ext, &t) != 1;
+      const int2 cc = *reinterpret_cast<const int2 *>(f2c + 2 * f);
+      if (!(exempt && exempt[f])) nbad += facet_rule(cc, ctags, no_ext, &t) != 1;
       ftags[f] = t;
+      tj[f - f0] = t;
+      two[f - f0] = cc.y >= 0;
     }
   }
   if (nbad) atomicAdd(bad, (unsigned long long)nbad);
+  // ---- counts (wave-uniform: every lane of the block takes part in the ballots)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t cnt[7] = {0, 0, 0, 0, 0, 0, 0}, c0 = 0, c1 = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int b = 0; b < 7; ++b) cnt[b] += (uint32_t)__popcll(__ballot(tj[j] == b));
+    c0 += (uint32_t)__popcll(__ballot((tj[j] == 2 || tj[j] == 3) && two[j]));
+    c1 += (uint32_t)__popcll(__ballot(tj[j] == 3 || tj[j] == 4));
+  }
+  if (lane == 0) {
+    const int64_t wbase = (blockIdx.x * (int64_t)blockDim.x + (threadIdx.x & ~63)) * 4;   // first facet of the wave
+    if (wbase < nf) {
+      const int64_t chunk = wbase / PHX_SEL_CHUNK;
+      if (c0) atomicAdd(&sel0[chunk], (int32_t)c0);
+      if (c1) atomicAdd(&sel1[chunk], (int32_t)c1);
+    }
+    for (int b = 0; b < 7; ++b) lh[wv][b] = cnt[b];
+  }
+  __syncthreads();
+  if (threadIdx.x < 7)
+    hist_part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
+        lh[0][threadIdx.x] + lh[1][threadIdx.x] + lh[2][threadIdx.x] + lh[3][threadIdx.x];
+}
+
+// hist[b] += sum over blocks of part[b][.]   (grid: slices x bins; hist zeroed by the caller)
+__global__ void __launch_bounds__(256) k_hist_fold(int64_t nblocks, const uint32_t *__restrict__ part,
+                                                   unsigned long long *__restrict__ hist) {
+  __shared__ unsigned long long red[256];
+  const int b = blockIdx.y;
+  unsigned long long a = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nblocks; i += (int64_t)gridDim.x * blockDim.x)
+    a += part[(size_t)b * nblocks + i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && red[0]) atomicAdd(&hist[b], red[0]);
 }
 
 // --- a6: (facet, cell) incidences of a one-sided measure -------------------------------------
@@ -381,9 +459,8 @@ static int read_hist(phx_mesh *m, const int8_t *tags, int64_t n, int nbins, int6
   const int blocks = (int)std::min<int64_t>(phx_div_up(n, 256), 2048);
   k_tag_hist<<<dim3(blocks), dim3(256), 0, m->stream>>>(n, tags, nbins, d);
   unsigned long long h[8];
-  PHX_HIP(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, m->stream));
-  if (extra) PHX_HIP(hipMemcpyAsync(extra_host, extra, extra_bytes, hipMemcpyDeviceToHost, m->stream));
-  PHX_HIP(hipStreamSynchronize(m->stream));
+  const phx_rb_item rb[2] = {{d, (int)sizeof(h), h}, {extra, (int)extra_bytes, extra_host}};
+  PHX_CHECK(phx_read_back(m->stream, rb, extra ? 2 : 1));
   PHX_HIP(phx_free(d));
   for (int i = 0; i < nbins; ++i) out[i] = (int64_t)h[i];
   return PHX_OK;
@@ -423,33 +500,44 @@ extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int l
   else if (phi_kind == PHX_PHI_POINTS) PHX_CHECK(launch_tag_cells<PHX_PHI_POINTS>(m, tab, dphi, quad, dwarn));
   else PHX_CHECK(launch_tag_cells<PHX_PHI_QUADRIC>(m, tab, dphi, quad, dwarn));
   uint8_t *touched = nullptr;
+  const dim3 grid4((unsigned)phx_div_up(phx_div_up(m->nc, 4), 256)), block4(256);   // four cells per thread
   if (single_layer_cut) {
     PHX_HIP(phx_malloc(&touched, (size_t)m->nv));
     PHX_HIP(hipMemsetAsync(touched, 0, (size_t)m->nv, m->stream));
-    const dim3 grid((unsigned)phx_div_up(phx_div_up(m->nc, 4), 256)), block(256);   // four cells per thread
-    if (m->ci.nvpc == 3) {
-      k_mark_inside_vertices<3><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
-      k_demote_isolated_cut<3><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
-    } else {
-      k_mark_inside_vertices<4><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
-      k_demote_isolated_cut<4><<<grid, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
-    }
-    PHX_HIP(hipGetLastError());
-    PHX_CHECK(phx_end_timing_mark(m));
-  } else {
-    touched = nullptr;
-    PHX_CHECK(phx_end_timing_mark(m));
+    if (m->ci.nvpc == 3) k_mark_inside_vertices<3><<<grid4, block4, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
+    else k_mark_inside_vertices<4><<<grid4, block4, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
   }
+  // demotion of isolated cut cells (if asked for) + histogram + per-chunk counts of the cut cells, in one pass
+  unsigned long long *dres = nullptr;   // [0..3] histogram, [4] warning flag (low word)
+  uint32_t *part = nullptr;
+  const int64_t nchunks = phx_div_up(m->nc > 0 ? m->nc : 1, (int64_t)PHX_SEL_CHUNK);
+  PHX_HIP(phx_malloc(&dres, sizeof(unsigned long long) * 4));
+  PHX_HIP(phx_malloc(&part, sizeof(uint32_t) * 4 * (size_t)grid4.x));
+  PHX_HIP(hipMemsetAsync(dres, 0, sizeof(unsigned long long) * 4, m->stream));
+  if (!m->sel_counts_cut) PHX_HIP(phx_malloc(&m->sel_counts_cut, sizeof(int32_t) * (size_t)(nchunks + 1)));
+  PHX_HIP(hipMemsetAsync(m->sel_counts_cut, 0, sizeof(int32_t) * (size_t)(nchunks + 1), m->stream));
+  if (m->ci.nvpc == 3) k_demote_isolated_cut<3><<<grid4, block4, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched, part, m->sel_counts_cut);
+  else k_demote_isolated_cut<4><<<grid4, block4, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched, part, m->sel_counts_cut);
+  PHX_HIP(hipGetLastError());
+  PHX_CHECK(phx_end_timing_mark(m));
+  k_hist_fold<<<dim3(64, 4), dim3(256), 0, m->stream>>>((int64_t)grid4.x, part, dres);
   // one host round trip for the histogram, the warning flag and the timing events
   int hwarn = 0;
-  PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist, dwarn, sizeof(int), &hwarn));
+  unsigned long long hh[4] = {0, 0, 0, 0};
+  const phx_rb_item rb[2] = {{dres, (int)sizeof(hh), hh}, {dwarn, (int)sizeof(int), &hwarn}};
+  PHX_CHECK(phx_read_back(m->stream, rb, 2));
+  for (int i = 0; i < 4; ++i) m->tag_hist[i] = (int64_t)hh[i];
+  m->sel_cut_valid = true;
   PHX_CHECK(phx_end_timing_read(m, 0));
   if (touched) PHX_HIP(phx_free(touched));
+  PHX_HIP(phx_free(dres));
+  PHX_HIP(phx_free(part));
   PHX_HIP(phx_free(dwarn));
   if (owned) PHX_HIP(phx_free(owned));
   if (warn_zero_denominator) *warn_zero_denominator = hwarn;
   m->have_cell_tags = true;
   m->have_facet_tags = false;
+  m->sel_counts_valid = false;
   m->have_entities = false;
   return PHX_OK;
 }
@@ -478,19 +566,33 @@ __global__ void k_clear_bcut(int64_t n, int8_t *tags) {
 }
 
 static int run_facet_rule(phx_mesh *m) {
-  unsigned long long *dbad = nullptr;
-  PHX_HIP(phx_malloc(&dbad, sizeof(unsigned long long)));
-  PHX_HIP(hipMemsetAsync(dbad, 0, sizeof(unsigned long long), m->stream));
-  k_tag_facets<<<dim3((unsigned)phx_div_up(phx_div_up(m->nf, 4), 256)), dim3(256), 0, m->stream>>>(
+  unsigned long long *dbad = nullptr;   // [0] bad facets, [1..7] the histogram
+  uint32_t *part = nullptr;
+  const int64_t nblocks = phx_div_up(phx_div_up(m->nf, 4), 256);
+  const int64_t nchunks = phx_div_up(m->nf > 0 ? m->nf : 1, (int64_t)PHX_SEL_CHUNK);
+  PHX_HIP(phx_malloc(&dbad, sizeof(unsigned long long) * 8));
+  PHX_HIP(phx_malloc(&part, sizeof(uint32_t) * 7 * (size_t)nblocks));
+  PHX_HIP(hipMemsetAsync(dbad, 0, sizeof(unsigned long long) * 8, m->stream));
+  for (int w = 0; w < 2; ++w) {
+    if (!m->sel_counts[w]) PHX_HIP(phx_malloc(&m->sel_counts[w], sizeof(int32_t) * (size_t)(nchunks + 1)));
+    PHX_HIP(hipMemsetAsync(m->sel_counts[w], 0, sizeof(int32_t) * (size_t)(nchunks + 1), m->stream));
+  }
+  k_tag_facets<<<dim3((unsigned)nblocks), dim3(256), 0, m->stream>>>(
       m->nf, m->f2c, m->cell_tags,
       m->has_exterior_override >= 0 ? (m->has_exterior_override ? 0 : 1) : (m->tag_hist[3] == 0 ? 1 : 0),
-      m->facet_exempt, m->facet_tags, dbad);
+      m->facet_exempt, m->facet_tags, dbad, part, m->sel_counts[0], m->sel_counts[1]);
+  k_hist_fold<<<dim3(64, 7), dim3(256), 0, m->stream>>>(nblocks, part, dbad + 1);
   PHX_HIP(hipGetLastError());
   PHX_CHECK(phx_end_timing_mark(m));
-  unsigned long long bad = 0;
-  PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist, dbad, sizeof(bad), &bad));
+  unsigned long long hb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const phx_rb_item rb[1] = {{dbad, (int)sizeof(hb), hb}};
+  PHX_CHECK(phx_read_back(m->stream, rb, 1));
+  const unsigned long long bad = hb[0];
+  for (int i = 0; i < 7; ++i) m->ftag_hist[i] = (int64_t)hb[1 + i];
+  m->sel_counts_valid = true;
   PHX_CHECK(phx_end_timing_read(m, 1));
   PHX_HIP(phx_free(dbad));
+  PHX_HIP(phx_free(part));
   m->have_facet_tags = true;
   m->have_entities = false;
   PHX_REQUIRE(bad == 0, PHX_ERR_PARTITION,
@@ -573,6 +675,8 @@ extern "C" int phx_overwrite_tags(phx_mesh *m, int entity_is_facet, int64_t n,
   PHX_HIP(phx_free(dv));
   if (entity_is_facet) PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist));
   else PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist));
+  if (entity_is_facet) m->sel_counts_valid = false;
+  else m->sel_cut_valid = false;
   m->have_entities = false;
   return PHX_OK;
 }
@@ -599,9 +703,11 @@ extern "C" int phx_set_tags(phx_mesh *m, int entity_is_facet, const int32_t *val
   if (entity_is_facet) {
     PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist));
     m->have_facet_tags = true;
+    m->sel_counts_valid = false;
   } else {
     PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist));
     m->have_cell_tags = true;
+    m->sel_cut_valid = false;
   }
   m->have_entities = false;
   return PHX_OK;
@@ -628,7 +734,8 @@ int phx_collect_entities(phx_mesh *m) {
   std::vector<void *> later;   // freed behind the synchronisation at the end
   {
     int64_t nsel = 0;
-    PHX_CHECK(phx_select_indices(st, m->nf, SelTag34{m->facet_tags}, &list, &nsel, &later));
+    PHX_CHECK(phx_select_indices(st, m->nf, SelTag34{m->facet_tags}, &list, &nsel, &later,
+                                 m->sel_counts_valid ? m->sel_counts[1] : nullptr));
     PHX_REQUIRE(nsel == nmax, PHX_ERR_VALUE, "facet tag histogram and selection disagree");
   }
   PHX_HIP(phx_malloc(&cnt, sizeof(int32_t) * 2 * (size_t)(nmax + 1)));
@@ -648,9 +755,9 @@ int phx_collect_entities(phx_mesh *m) {
     for (int w = 0; w < 2; ++w) {
       int32_t *ci = w == 0 ? cnt0 : cnt1, *oi = w == 0 ? off0 : off1;
       PHX_HIP(phx_exclusive_sum(tmp, bytes, ci, oi, (size_t)(nmax + 1), st));
-      PHX_HIP(hipMemcpyAsync(&tot[w], oi + nmax, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     }
-    PHX_HIP(hipStreamSynchronize(st));
+    const phx_rb_item rb[2] = {{off0 + nmax, 4, &tot[0]}, {off1 + nmax, 4, &tot[1]}};
+    PHX_CHECK(phx_read_back(st, rb, 2));
     PHX_HIP(phx_free(tmp));
     for (int w = 0; w < 2; ++w) {
       m->ent_count[w] = tot[w];

@@ -18,12 +18,12 @@ PY
 cp /tmp/ks/p_kernel_stats.csv $O/kernel_stats_bench_256_steps2.csv
 python3 $R/tools/gaps.py /tmp/ks/p_kernel_trace.csv 8 > $O/step_gaps.txt 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-include-regex 'k_spmv_sell|k_dst_s|k_tri_z|k_dst_x' -d /tmp/pmc_$c -o c --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-include-regex 'k_spmv_sell|k_dst_yw|k_tri_z|k_dst_xw' -d /tmp/pmc_$c -o c --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_$c.log 2>&1; echo "pmc $c rc=$?"
 done
 ALG=$(python3 -c "import json;d=json.loads([l for l in open('$O/bench_default_n1.json') if l.startswith('{')][-1]);r=d['roofline'] if 'spmv' in d['roofline']['kernel'] else d['roofline_other'];print(r['bytes_per_launch'])")
 ALGD=$(python3 -c "import json;d=json.loads([l for l in open('$O/bench_default_n1.json') if l.startswith('{')][-1]);r=d['roofline'] if 'dst' in d['roofline']['kernel'] else d['roofline_other'];print(r['bytes_per_launch'])")
 python3 $R/tools/pmc_record.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "k_spmv_sell" k_spmv_sell $ALG $O/pmc_spmv_256.json "structured SpMV (stencil blocks + SELL-16 blocks in one launch), 256^3 default workload"
-python3 $R/tools/pmc_record.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "k_dst_s<double, 1" k_dst_s_y $ALGD $O/pmc_dst_256.json "sine transform along y of the 192 x 192 x 182 preconditioner lattice, f64 (rows outside the active interval of a plane skipped)"
+python3 $R/tools/pmc_record.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "k_dst_yw<192>" k_dst_yw $ALGD $O/pmc_dst_256.json "sine transform along y of the 192 x 192 x 182 preconditioner lattice, f64, wave-mode kernel (rows outside the active interval of a plane skipped)"
 python3 $R/tools/pmc_record.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE "k_tri_z" k_tri_z $ALGD $O/pmc_tri_256.json "tridiagonal z pass of the preconditioner lattice, f64"
 timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --kernel-include-regex 'k_dst|k_tri' -d /tmp/sq1 -o s --output-format csv -- python3 $R/tools/dst_bench.py 192 192 182 0 5 > $O/pmc_sq1.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-include-regex 'k_dst|k_tri' -d /tmp/sq2 -o s --output-format csv -- python3 $R/tools/dst_bench.py 192 192 182 0 5 > $O/pmc_sq2.log 2>&1
