@@ -315,7 +315,8 @@ def main(argv=None):
             a2 = res["dst_algorithmic_bytes"] / dst_s / 1e9
             # f64 lattices of a wave-mode length run the shape-specialised kernel (phx_dst_wave.inc.hip)
             wave = res["precond_value_bytes"] == 8 and res["precond_L"][1] in (192, 256, 512)
-            kname = (f"k_dst_yw<{res['precond_L'][1]}>" if wave else
+            long_ = res["precond_value_bytes"] == 8 and res["precond_L"][1] in (384, 768, 1024)   # phx_dst_long.inc.hip
+            kname = (f"k_dst_yw<{res['precond_L'][1]}>" if wave else f"k_dst_yl<{res['precond_L'][1]}>" if long_ else
                      f"k_dst_s<{'float' if res['precond_value_bytes'] == 4 else 'double'},1,false>")
             tr2, src2 = pmc_traffic("k_dst_yw" if wave else "k_dst_s_y", res["dst_algorithmic_bytes"])
             dst_roof = {

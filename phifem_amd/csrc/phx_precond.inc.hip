@@ -681,6 +681,7 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G, const int2 *__restrict__ row_an
 
 constexpr bool dst_wave_f64(int L) { return L / 8 == 32 || L / 8 == 64 || L / 8 == 24; }
 #include "phx_dst_wave.inc.hip"
+#include "phx_dst_long.inc.hip"
 
 // --------------------------------------------------------------------------------------------------
 struct phx_box_precond {
@@ -751,6 +752,9 @@ static int dst_allow_lds() {
 #undef X
 #define X(L_) PHX_CHECK((dst_wave_allow_lds<L_>()));
   PHX_DST_WAVE_LENGTHS(X)
+#undef X
+#define X(L_) PHX_CHECK((dst_long_allow_lds<L_>()));
+  PHX_DST_LONG_LENGTHS(X)
 #undef X
   PHX_CHECK((dst_allow_lds_t<double, true>()));
   PHX_CHECK((dst_allow_lds_t<double, false>()));
@@ -862,6 +866,18 @@ static int box_pass_y_t(phx_box_precond *bp, hipStream_t st, phx_system *prof, i
     }
   }
   if constexpr (sizeof(T) == 8) {
+    if (!done && dst_long_fast(g, py, 0)) {
+      const int ntiles = ncb * g.m[2];
+      const dim3 gl((unsigned)dst_long_grid(py, ntiles));
+      switch (py.L) {
+#define X(L_) case L_: k_dst_yl<L_><<<gl, block, (size_t)py.lds_elems * el, st>>>(g, py, G, ra, dir, ncb, ntiles); done = true; break;
+        PHX_DST_LONG_LENGTHS(X)
+#undef X
+        default: break;
+      }
+    }
+  }
+  if constexpr (sizeof(T) == 8) {
     if (!done && !getenv("PHX_DST_GENERIC")) {
       switch (py.L) {
 #define X(L_) case L_: if ((py.wave != 0) == dst_wave_f64(L_)) { \
@@ -937,6 +953,23 @@ static int box_pass_x_t(phx_box_precond *bp, hipStream_t st, const double *vin, 
           else k_dst_xw<L_, IO, false><<<grid, block, lds, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb); \
           done = true; break;
         PHX_DST_WAVE_LENGTHS(X)
+#undef X
+        default: break;
+      }
+    }
+  }
+  if constexpr (sizeof(T) == 8) {
+    if (!done && dst_long_fast(g, px, bp->nvec)) {
+      const uint32_t vb = (uint32_t)(bp->nvec * 8);
+      double *Gd = static_cast<double *>(bp->G);
+      const int ngroups = (int)phx_div_up(npairs, px.pairs);
+      const dim3 gl((unsigned)dst_long_grid(px, ngroups));
+      switch (px.L) {
+#define X(L_) case L_: \
+          if (sc) k_dst_xl<L_, IO, IO != 0><<<gl, block, lds, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb, ngroups); \
+          else k_dst_xl<L_, IO, false><<<gl, block, lds, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb, ngroups); \
+          done = true; break;
+        PHX_DST_LONG_LENGTHS(X)
 #undef X
         default: break;
       }
