@@ -970,8 +970,9 @@ static int det_finish(phx_mesh *m, Slots &sl, int64_t nslots, int64_t nrows, dou
 
 template <typename Pred>
 static int build_list(phx_mesh *m, int64_t n, Pred pred, int32_t **list, int64_t *count,
-                      std::vector<void *> *later = nullptr, const int32_t *known_counts = nullptr) {
-  return phx_select_indices(m->stream, n, pred, list, count, later, known_counts);
+                      std::vector<void *> *later = nullptr, const int32_t *known_counts = nullptr,
+                      int64_t known_total = -1) {
+  return phx_select_indices(m->stream, n, pred, list, count, later, known_counts, known_total);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1444,9 +1445,11 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   int32_t *l_cut = nullptr, *l_fac = nullptr;
   int64_t n_cut = 0, n_fac = 0;
   PHX_CHECK(build_list(m, m->nc, SelCut{m->cell_tags}, &l_cut, &n_cut, &later,
-                       m->sel_cut_valid ? m->sel_counts_cut : nullptr));       // counted by the cell tagging kernel
+                       m->sel_cut_valid ? m->sel_counts_cut : nullptr,         // counted by the cell tagging kernel:
+                       m->sel_cut_valid ? m->tag_hist[2] : -1));               // the cut cells ARE the cells tagged 2
   PHX_CHECK(build_list(m, m->nf, SelGhostFacet{m->facet_tags, m->f2c}, &l_fac, &n_fac, &later,
-                       m->sel_counts_valid ? m->sel_counts[0] : nullptr));   // counted by the facet tagging kernel
+                       m->sel_counts_valid ? m->sel_counts[0] : nullptr,     // counted by the facet tagging kernel
+                       m->sel_counts_valid ? m->sel_total[0] : -1));
   Slots sl;
   sl.W = W;
   sl.cols = nullptr; sl.vals = nullptr; sl.overflow = nullptr;

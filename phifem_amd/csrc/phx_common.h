@@ -116,6 +116,7 @@ struct phx_mesh {
   // while sel_counts_valid (the facet tags are the ones k_tag_facets wrote).
   int32_t *sel_counts[2] = {nullptr, nullptr};
   bool sel_counts_valid = false;
+  int64_t sel_total[2] = {0, 0};       // the totals of sel_counts[.] (host copies, valid with sel_counts_valid)
   int32_t *sel_counts_cut = nullptr;   // the same for the cut cells (tag 2), left behind by the last cell tagging kernel
   bool sel_cut_valid = false;
   // integration entities of the current tags (device, unordered): (key, cell, lf) triples

@@ -74,8 +74,10 @@ k_select_chunks(int64_t n, Pred pred, int32_t *__restrict__ chunk_counts,
 // known_counts (nullable): the per-chunk counts [nchunks + 1, last entry 0] are already on the device (the kernel that
 // wrote the tags counted) -- the counting pass over the items is skipped.
 template <typename Pred>
+// known_total >= 0 (with known_counts): the kept count is known on the host as well -- no host round trip at all.
 static int phx_select_indices(hipStream_t stream, int64_t n, Pred pred, int32_t **list, int64_t *count,
-                              std::vector<void *> *later = nullptr, const int32_t *known_counts = nullptr) {
+                              std::vector<void *> *later = nullptr, const int32_t *known_counts = nullptr,
+                              int64_t known_total = -1) {
   *list = nullptr;
   *count = 0;
   const int64_t nchunks = phx_div_up(n > 0 ? n : 1, (int64_t)PHX_SEL_CHUNK);
@@ -94,8 +96,12 @@ static int phx_select_indices(hipStream_t stream, int64_t n, Pred pred, int32_t 
   PHX_HIP(phx_malloc(&tmp, bytes ? bytes : 16));
   PHX_HIP(phx_exclusive_sum(tmp, bytes, known_counts, off, (size_t)(nchunks + 1), stream));
   int32_t total = 0;
-  PHX_HIP(hipMemcpyAsync(&total, off + nchunks, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-  PHX_HIP(hipStreamSynchronize(stream));
+  if (known_total >= 0 && later) {
+    total = (int32_t)known_total;
+  } else {
+    PHX_HIP(hipMemcpyAsync(&total, off + nchunks, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    PHX_HIP(hipStreamSynchronize(stream));
+  }
   PHX_HIP(phx_malloc(list, sizeof(int32_t) * (size_t)(total > 0 ? total : 1)));
   if (total > 0) k_select_chunks<Pred, true><<<grid, block, 0, stream>>>(n, pred, nullptr, off, *list);
   PHX_HIP(hipGetLastError());

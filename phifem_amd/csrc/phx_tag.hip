@@ -290,7 +290,7 @@ k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restri
              int no_ext, const uint8_t *__restrict__ exempt, int8_t *__restrict__ ftags,
              unsigned long long *__restrict__ bad, uint32_t *__restrict__ hist_part,
              int32_t *__restrict__ sel0, int32_t *__restrict__ sel1) {
-  __shared__ uint32_t lh[4][8];
+  __shared__ uint32_t lh[4][9];
   const int64_t f0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
   int nbad = 0;
   int8_t tj[4] = {0x7f, 0x7f, 0x7f, 0x7f};   // 0x7f: no facet here
@@ -337,9 +337,11 @@ k_tag_facets(int64_t nf, const int32_t *__restrict__ f2c, const int8_t *__restri
       if (c1) atomicAdd(&sel1[chunk], (int32_t)c1);
     }
     for (int b = 0; b < 7; ++b) lh[wv][b] = cnt[b];
+    lh[wv][7] = c0;   // "bins" 7 / 8: the totals of the two selections
+    lh[wv][8] = c1;
   }
   __syncthreads();
-  if (threadIdx.x < 7)
+  if (threadIdx.x < 9)
     hist_part[(size_t)threadIdx.x * gridDim.x + blockIdx.x] =
         lh[0][threadIdx.x] + lh[1][threadIdx.x] + lh[2][threadIdx.x] + lh[3][threadIdx.x];
 }
@@ -566,13 +568,13 @@ __global__ void k_clear_bcut(int64_t n, int8_t *tags) {
 }
 
 static int run_facet_rule(phx_mesh *m) {
-  unsigned long long *dbad = nullptr;   // [0] bad facets, [1..7] the histogram
+  unsigned long long *dbad = nullptr;   // [0] bad facets, [1..7] the histogram, [8..9] the totals of the two selections
   uint32_t *part = nullptr;
   const int64_t nblocks = phx_div_up(phx_div_up(m->nf, 4), 256);
   const int64_t nchunks = phx_div_up(m->nf > 0 ? m->nf : 1, (int64_t)PHX_SEL_CHUNK);
-  PHX_HIP(phx_malloc(&dbad, sizeof(unsigned long long) * 8));
-  PHX_HIP(phx_malloc(&part, sizeof(uint32_t) * 7 * (size_t)nblocks));
-  PHX_HIP(hipMemsetAsync(dbad, 0, sizeof(unsigned long long) * 8, m->stream));
+  PHX_HIP(phx_malloc(&dbad, sizeof(unsigned long long) * 10));
+  PHX_HIP(phx_malloc(&part, sizeof(uint32_t) * 9 * (size_t)nblocks));
+  PHX_HIP(hipMemsetAsync(dbad, 0, sizeof(unsigned long long) * 10, m->stream));
   for (int w = 0; w < 2; ++w) {
     if (!m->sel_counts[w]) PHX_HIP(phx_malloc(&m->sel_counts[w], sizeof(int32_t) * (size_t)(nchunks + 1)));
     PHX_HIP(hipMemsetAsync(m->sel_counts[w], 0, sizeof(int32_t) * (size_t)(nchunks + 1), m->stream));
@@ -581,14 +583,16 @@ static int run_facet_rule(phx_mesh *m) {
       m->nf, m->f2c, m->cell_tags,
       m->has_exterior_override >= 0 ? (m->has_exterior_override ? 0 : 1) : (m->tag_hist[3] == 0 ? 1 : 0),
       m->facet_exempt, m->facet_tags, dbad, part, m->sel_counts[0], m->sel_counts[1]);
-  k_hist_fold<<<dim3(64, 7), dim3(256), 0, m->stream>>>(nblocks, part, dbad + 1);
+  k_hist_fold<<<dim3(64, 9), dim3(256), 0, m->stream>>>(nblocks, part, dbad + 1);
   PHX_HIP(hipGetLastError());
   PHX_CHECK(phx_end_timing_mark(m));
-  unsigned long long hb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const phx_rb_item rb[1] = {{dbad, (int)sizeof(hb), hb}};
-  PHX_CHECK(phx_read_back(m->stream, rb, 1));
+  unsigned long long hb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ht[2] = {0, 0};
+  const phx_rb_item rb[2] = {{dbad, (int)sizeof(hb), hb}, {dbad + 8, (int)sizeof(ht), ht}};
+  PHX_CHECK(phx_read_back(m->stream, rb, 2));
   const unsigned long long bad = hb[0];
   for (int i = 0; i < 7; ++i) m->ftag_hist[i] = (int64_t)hb[1 + i];
+  m->sel_total[0] = (int64_t)ht[0];
+  m->sel_total[1] = (int64_t)ht[1];
   m->sel_counts_valid = true;
   PHX_CHECK(phx_end_timing_read(m, 1));
   PHX_HIP(phx_free(dbad));
@@ -735,7 +739,8 @@ int phx_collect_entities(phx_mesh *m) {
   {
     int64_t nsel = 0;
     PHX_CHECK(phx_select_indices(st, m->nf, SelTag34{m->facet_tags}, &list, &nsel, &later,
-                                 m->sel_counts_valid ? m->sel_counts[1] : nullptr));
+                                 m->sel_counts_valid ? m->sel_counts[1] : nullptr,
+                                 m->sel_counts_valid ? m->sel_total[1] : -1));
     PHX_REQUIRE(nsel == nmax, PHX_ERR_VALUE, "facet tag histogram and selection disagree");
   }
   PHX_HIP(phx_malloc(&cnt, sizeof(int32_t) * 2 * (size_t)(nmax + 1)));
