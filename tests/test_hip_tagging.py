@@ -429,3 +429,41 @@ def test_meshtags_keep_the_state_they_were_created_in(P):
     assert np.array_equal(f_small.values, f_ref.values) and np.array_equal(f_small.indices, f_ref.indices)
     assert int((c_small.values == 1).sum()) < n_in_big
     assert c_small.find(2).size > 0 and c_small.dim == 2 and f_small.dim == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gdim,n,single_layer", [(3, (19, 23, 17), True), (3, (40, 33, 35), False), (2, (67, 53), True)])
+def test_counts_left_by_the_tagging_kernels_equal_a_recount(P, gdim, n, single_layer):
+    """The kernels that write the tags also count them (histograms, and the per-chunk counts the cut-cell, ghost-facet and
+    tag-3/4 selections of an assembly start from): the histogram equals a recount of the tag arrays, the entity lists
+    built from the kept counts equal the lists derived from the tags, and a solve that starts from them converges."""
+    import ctypes as C
+    import warnings
+    from phifem_amd.mesh_scripts import NodalFunction, _tag_cells, _tag_facets
+    lo, hi = [-1.5] * gdim, [1.5] * gdim
+    m = P.create_box(lo, hi, n)
+    x = m.x
+    phi = (x ** 2).sum(axis=1) - 1.0 + 0.05 * np.sin(5.0 * x[:, 0])
+    staged = _tag_cells(m, NodalFunction(phi), 1, single_layer_cut=single_layer)
+    _tag_facets(m, staged, 1)
+    hc, hf = (C.c_int64 * 4)(), (C.c_int64 * 7)()
+    P._lib.check(P._lib.lib.phx_mesh_tag_histogram(m._h, hc, hf))
+    ct, ft = m.cell_tag_values(), m.facet_tag_values()
+    assert list(hc) == [int((ct == b).sum()) for b in range(4)]
+    assert list(hf) == [int((ft == b).sum()) for b in range(7)]
+    # ds(100) / ds(101) entities come from the selection of the facets tagged 3 / 4
+    f2c = m.f2c
+    from phifem_amd import _lib as L_
+    for which, tag, cells_ok in ((100, 4, (1, 2)), (101, 3, (2, 3))):
+        npairs = C.c_int64(0)
+        L_.check(L_.lib.phx_integration_entities(m._h, which, None, C.byref(npairs)))
+        facets = np.flatnonzero(ft == tag)
+        expect = sum(int(ct[c] in cells_ok) for f in facets for c in f2c[f] if c >= 0)
+        assert npairs.value == expect
+    # and the assembly (cut-cell / ghost-facet selections with the kept counts) yields a system that solves
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s = P.PhiFEMSolver(m)
+        s.assemble(phi, np.ones(m.nv), np.zeros(m.nv))
+        u = s.solve(rtol=1e-9)
+    assert s.stats["converged"] and np.isfinite(u).all()
