@@ -23,6 +23,16 @@ int phx_system_build_sell(phx_system *s);
 // ---------------------------------------------------------------------------------------------
 // active DoF numbering
 // ---------------------------------------------------------------------------------------------
+// fu / fp from the vertex flags the single-layer tagging pass left behind (phx_common.h: act_in, act_cut)
+__global__ void k_flags_from_tagging(int64_t nv, const uint8_t *__restrict__ vin, const uint8_t *__restrict__ vcut,
+                                     uint8_t *__restrict__ fu, uint8_t *__restrict__ fp) {
+  const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (v >= nv) return;
+  const uint8_t c = vcut[v] ? 1 : 0;
+  fu[v] = (vin[v] || c) ? 1 : 0;
+  fp[v] = c;
+}
+
 template <int NVPC>
 __global__ void k_mark_active(int64_t nc, const int32_t *__restrict__ cells,
                               const int8_t *__restrict__ tags, uint8_t *__restrict__ fu,
@@ -61,12 +71,12 @@ __global__ void k_finish_numbering_packed(int64_t nv, const uint8_t *__restrict_
                                    const uint8_t *__restrict__ fp,
                                    const unsigned long long *__restrict__ sup,
                                    int32_t nu, int32_t *__restrict__ du, int32_t *__restrict__ dp,
-                                   int64_t *__restrict__ full_of_active) {
+                                   int64_t *__restrict__ full_of_active, int u_or_p) {
   const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (v >= nv) return;
   int32_t a = -1, b = -1;
   const unsigned long long r = sup[v];
-  if (fu[v]) { a = (int32_t)(r & 0xffffffffull); full_of_active[a] = v; }
+  if (fu[v] || (u_or_p && fp[v])) { a = (int32_t)(r & 0xffffffffull); full_of_active[a] = v; }
   if (fp[v]) { b = nu + (int32_t)(r >> 32); full_of_active[b] = nv + v; }
   du[v] = a;
   dp[v] = b;
@@ -1209,15 +1219,18 @@ static int scan_flags(phx_mesh *m, const uint8_t *flags, int32_t *out, int64_t n
 
 // two flag arrays of the same entities as ONE scan of 64-bit words (low word: a, high word: b; the totals stay below
 // 2^31), both totals with one host round trip
+// a_or_b: the first flag is fa | fb (u DoFs: vertices of inside OR cut cells, from the flag arrays of the tagging pass)
 struct PackFlags2 {
   const uint8_t *fa, *fb;
+  int a_or_b;
   __host__ __device__ unsigned long long operator()(const int64_t &i) const {
-    return (unsigned long long)fa[i] | ((unsigned long long)fb[i] << 32);
+    const unsigned long long b = fb[i] ? 1ull : 0ull, a = (fa[i] || (a_or_b && b)) ? 1ull : 0ull;
+    return a | (b << 32);
   }
 };
 static int scan_flags_packed(phx_mesh *m, const uint8_t *fa, const uint8_t *fb, unsigned long long *out, int32_t *ta,
-                             int32_t *tb, int64_t n) {
-  auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), PackFlags2{fa, fb});
+                             int32_t *tb, int64_t n, int a_or_b = 0) {
+  auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), PackFlags2{fa, fb, a_or_b});
   size_t bytes = 0;
   PHX_HIP(phx_exclusive_sum(nullptr, bytes, it, out, (size_t)(n), m->stream));
   void *tmp = nullptr;
@@ -1228,8 +1241,8 @@ static int scan_flags_packed(phx_mesh *m, const uint8_t *fa, const uint8_t *fb, 
   const phx_rb_item rb[3] = {{out + (n - 1), 8, &last}, {fa + (n - 1), 1, &la}, {fb + (n - 1), 1, &lb}};
   PHX_CHECK(phx_read_back(m->stream, rb, 3));
   PHX_HIP(phx_free(tmp));
-  *ta = (int32_t)(last & 0xffffffffull) + (int32_t)la;
-  *tb = (int32_t)(last >> 32) + (int32_t)lb;
+  *ta = (int32_t)(last & 0xffffffffull) + ((la || (a_or_b && lb)) ? 1 : 0);
+  *tb = (int32_t)(last >> 32) + (lb ? 1 : 0);
   return PHX_OK;
 }
 
@@ -1402,14 +1415,21 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   // ---- active numbering
   uint8_t *fu = nullptr, *fp = nullptr;
   unsigned long long *sup = nullptr;
+  PHX_HIP(phx_malloc(&sup, sizeof(unsigned long long) * (size_t)m->nv));
+  // the single-layer tagging pass left the vertex flags behind (inside cells; cells that stayed cut): no walk over the cells
+  static const bool no_act = getenv("PHX_NO_ACT_FLAGS") != nullptr;   // A/B aid
+  const int from_tags = (m->act_valid && m->act_in && m->act_cut && !no_act) ? 1 : 0;
   PHX_HIP(phx_malloc(&fu, (size_t)m->nv));
   PHX_HIP(phx_malloc(&fp, (size_t)m->nv));
-  PHX_HIP(phx_malloc(&sup, sizeof(unsigned long long) * (size_t)m->nv));
-  PHX_HIP(hipMemsetAsync(fu, 0, (size_t)m->nv, m->stream));
-  PHX_HIP(hipMemsetAsync(fp, 0, (size_t)m->nv, m->stream));
-  const dim3 gcells((unsigned)phx_div_up(phx_div_up(m->nc, 4), 256));
-  if (D == 2) k_mark_active<3><<<gcells, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, fu, fp);
-  else k_mark_active<4><<<gcells, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, fu, fp);
+  if (from_tags) {
+    k_flags_from_tagging<<<dim3((unsigned)phx_div_up(m->nv, 256)), block, 0, m->stream>>>(m->nv, m->act_in, m->act_cut, fu, fp);
+  } else {
+    PHX_HIP(hipMemsetAsync(fu, 0, (size_t)m->nv, m->stream));
+    PHX_HIP(hipMemsetAsync(fp, 0, (size_t)m->nv, m->stream));
+    const dim3 gcells((unsigned)phx_div_up(phx_div_up(m->nc, 4), 256));
+    if (D == 2) k_mark_active<3><<<gcells, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, fu, fp);
+    else k_mark_active<4><<<gcells, block, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, fu, fp);
+  }
   int32_t nu = 0, np = 0;
   PHX_CHECK(scan_flags_packed(m, fu, fp, sup, &nu, &np, m->nv));
   s->nu = nu;
@@ -1438,7 +1458,7 @@ static int assemble_with_capacity(phx_mesh *m, double pen_coef, double stab_coef
   PHX_HIP(phx_malloc(&s->dof_of_vertex_p, sizeof(int32_t) * (size_t)m->nv));
   PHX_HIP(phx_malloc(&s->full_of_active, sizeof(int64_t) * (size_t)s->n));
   k_finish_numbering_packed<<<dim3((unsigned)phx_div_up(m->nv, 256)), block, 0, m->stream>>>(
-      m->nv, fu, fp, sup, nu, s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active);
+      m->nv, fu, fp, sup, nu, s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active, 0);
   // temporaries whose last kernel is only enqueued: freed behind the synchronisation in front of finish_*
   std::vector<void *> later = {fu, fp, sup};
   // ---- element kernels run over compacted work lists
@@ -1672,6 +1692,7 @@ static int assemble_poisson_wd_on_inner(phx_mesh *m, double pen_coef, double sta
   in->have_cell_tags = in->have_facet_tags = true;
   in->sel_counts_valid = false;
   in->sel_cut_valid = false;
+  in->act_valid = false;
   in->have_entities = false;
   for (int i = 0; i < 4; ++i) in->tag_hist[i] = m->tag_hist[i];
   for (int i = 0; i < 8; ++i) in->ftag_hist[i] = m->ftag_hist[i];

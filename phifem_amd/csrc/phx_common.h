@@ -119,6 +119,11 @@ struct phx_mesh {
   int64_t sel_total[2] = {0, 0};       // the totals of sel_counts[.] (host copies, valid with sel_counts_valid)
   int32_t *sel_counts_cut = nullptr;   // the same for the cut cells (tag 2), left behind by the last cell tagging kernel
   bool sel_cut_valid = false;
+  // vertex flags the single-layer tagging pass produces anyway: act_in[v] = v belongs to a cell tagged 1, act_cut[v] =
+  // v belongs to a cell tagged 2 (after the demotion).  The P1 assembly numbers its DoFs from them (u: either, p: cut)
+  // instead of walking the cells again.  Valid while act_valid.
+  uint8_t *act_in = nullptr, *act_cut = nullptr;
+  bool act_valid = false;
   // integration entities of the current tags (device, unordered): (key, cell, lf) triples
   int64_t *ent_buf[2] = {nullptr, nullptr};
   int64_t ent_count[2] = {0, 0};

@@ -1032,6 +1032,7 @@ extern "C" int phx_mesh_destroy(phx_mesh *m) {
   for (auto &pe : m->prof_ev) for (auto &e : pe) (void)hipEventDestroy(e);
   for (int w = 0; w < 2; ++w) (void)phx_free(m->sel_counts[w]);
   (void)phx_free(m->sel_counts_cut);
+  (void)phx_free(m->act_in); (void)phx_free(m->act_cut);
   if (m->ev0) (void)hipEventDestroy(m->ev0);
   if (m->ev1) (void)hipEventDestroy(m->ev1);
   if (m->stream && m->own_stream) (void)hipStreamDestroy(m->stream);

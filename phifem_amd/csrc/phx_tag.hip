@@ -122,7 +122,7 @@ template <int NVPC>
 __global__ void __launch_bounds__(256)
 k_demote_isolated_cut(int64_t nc, const int32_t *__restrict__ cells, int8_t *__restrict__ tags,
                       const uint8_t *__restrict__ touched, uint32_t *__restrict__ hist_part,
-                      int32_t *__restrict__ sel_cut) {
+                      int32_t *__restrict__ sel_cut, uint8_t *__restrict__ vcut) {
   __shared__ uint32_t lh[4][4];
   const int64_t c0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 4;
   int tj[4] = {0x7f, 0x7f, 0x7f, 0x7f};
@@ -134,9 +134,11 @@ k_demote_isolated_cut(int64_t nc, const int32_t *__restrict__ cells, int8_t *__r
       int t = (int)((w >> (8 * j)) & PHX_TAG_MASK);
       if (t == 2 && touched) {
         const int64_t c = c0 + j;
+        int32_t v[NVPC];
         bool keep = false;
-        for (int i = 0; i < NVPC; ++i) keep = keep || touched[cells[c * NVPC + i]];
+        for (int i = 0; i < NVPC; ++i) { v[i] = cells[c * NVPC + i]; keep = keep || touched[v[i]]; }
         if (!keep) { tags[c] = 3; t = 3; }
+        else if (vcut) for (int i = 0; i < NVPC; ++i) vcut[v[i]] = 1;   // vertices of the cells that stay cut
       }
       tj[j] = t;
     }
@@ -501,10 +503,16 @@ extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int l
   if (phi_kind == PHX_PHI_NODAL_P1) PHX_CHECK(launch_tag_cells<PHX_PHI_NODAL_P1>(m, tab, dphi, quad, dwarn));
   else if (phi_kind == PHX_PHI_POINTS) PHX_CHECK(launch_tag_cells<PHX_PHI_POINTS>(m, tab, dphi, quad, dwarn));
   else PHX_CHECK(launch_tag_cells<PHX_PHI_QUADRIC>(m, tab, dphi, quad, dwarn));
-  uint8_t *touched = nullptr;
+  uint8_t *touched = nullptr, *vcut = nullptr;
   const dim3 grid4((unsigned)phx_div_up(phx_div_up(m->nc, 4), 256)), block4(256);   // four cells per thread
+  m->act_valid = false;
   if (single_layer_cut) {
-    PHX_HIP(phx_malloc(&touched, (size_t)m->nv));
+    // the two vertex flag arrays stay with the mesh: the P1 assembly numbers its DoFs from them
+    if (!m->act_in) PHX_HIP(phx_malloc(&m->act_in, (size_t)m->nv));
+    if (!m->act_cut) PHX_HIP(phx_malloc(&m->act_cut, (size_t)m->nv));
+    touched = m->act_in;
+    vcut = m->act_cut;
+    PHX_HIP(hipMemsetAsync(vcut, 0, (size_t)m->nv, m->stream));
     PHX_HIP(hipMemsetAsync(touched, 0, (size_t)m->nv, m->stream));
     if (m->ci.nvpc == 3) k_mark_inside_vertices<3><<<grid4, block4, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
     else k_mark_inside_vertices<4><<<grid4, block4, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched);
@@ -518,8 +526,8 @@ extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int l
   PHX_HIP(hipMemsetAsync(dres, 0, sizeof(unsigned long long) * 4, m->stream));
   if (!m->sel_counts_cut) PHX_HIP(phx_malloc(&m->sel_counts_cut, sizeof(int32_t) * (size_t)(nchunks + 1)));
   PHX_HIP(hipMemsetAsync(m->sel_counts_cut, 0, sizeof(int32_t) * (size_t)(nchunks + 1), m->stream));
-  if (m->ci.nvpc == 3) k_demote_isolated_cut<3><<<grid4, block4, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched, part, m->sel_counts_cut);
-  else k_demote_isolated_cut<4><<<grid4, block4, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched, part, m->sel_counts_cut);
+  if (m->ci.nvpc == 3) k_demote_isolated_cut<3><<<grid4, block4, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched, part, m->sel_counts_cut, vcut);
+  else k_demote_isolated_cut<4><<<grid4, block4, 0, m->stream>>>(m->nc, m->cells, m->cell_tags, touched, part, m->sel_counts_cut, vcut);
   PHX_HIP(hipGetLastError());
   PHX_CHECK(phx_end_timing_mark(m));
   k_hist_fold<<<dim3(64, 4), dim3(256), 0, m->stream>>>((int64_t)grid4.x, part, dres);
@@ -530,8 +538,8 @@ extern "C" int phx_tag_cells(phx_mesh *m, int phi_kind, const double *phi, int l
   PHX_CHECK(phx_read_back(m->stream, rb, 2));
   for (int i = 0; i < 4; ++i) m->tag_hist[i] = (int64_t)hh[i];
   m->sel_cut_valid = true;
+  m->act_valid = single_layer_cut != 0;
   PHX_CHECK(phx_end_timing_read(m, 0));
-  if (touched) PHX_HIP(phx_free(touched));
   PHX_HIP(phx_free(dres));
   PHX_HIP(phx_free(part));
   PHX_HIP(phx_free(dwarn));
@@ -680,7 +688,7 @@ extern "C" int phx_overwrite_tags(phx_mesh *m, int entity_is_facet, int64_t n,
   if (entity_is_facet) PHX_CHECK(read_hist(m, m->facet_tags, m->nf, 7, m->ftag_hist));
   else PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist));
   if (entity_is_facet) m->sel_counts_valid = false;
-  else m->sel_cut_valid = false;
+  else { m->sel_cut_valid = false; m->act_valid = false; }
   m->have_entities = false;
   return PHX_OK;
 }
@@ -712,6 +720,7 @@ extern "C" int phx_set_tags(phx_mesh *m, int entity_is_facet, const int32_t *val
     PHX_CHECK(read_hist(m, m->cell_tags, m->nc, 4, m->tag_hist));
     m->have_cell_tags = true;
     m->sel_cut_valid = false;
+    m->act_valid = false;
   }
   m->have_entities = false;
   return PHX_OK;
