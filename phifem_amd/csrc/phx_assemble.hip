@@ -157,7 +157,10 @@ __device__ __forceinline__ void slot_add(const Slots &s, int32_t row, int32_t co
       if (cur == -1) cur = col;
     }
     if (cur == col) {
-      det_add(s, s.vals, s.emax, s.lo, base + k, v);
+      // the slot is claimed either way (the structural pattern is dolfinx's); an exactly vanishing contribution -- on a
+      // Kuhn box most products of two normal-derivative jumps of the ghost penalty are: the gradients of non-neighbouring
+      // path vertices are orthogonal, the zeros are exact -- needs no f64 atomic
+      if (v != 0.0) det_add(s, s.vals, s.emax, s.lo, base + k, v);
       return;
     }
   }
