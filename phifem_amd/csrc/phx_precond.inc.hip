@@ -682,6 +682,7 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G, const int2 *__restrict__ row_an
 constexpr bool dst_wave_f64(int L) { return L / 8 == 32 || L / 8 == 64 || L / 8 == 24; }
 #include "phx_dst_wave.inc.hip"
 #include "phx_dst_long.inc.hip"
+#include "phx_dst_pair.inc.hip"
 
 // --------------------------------------------------------------------------------------------------
 struct phx_box_precond {
@@ -755,6 +756,9 @@ static int dst_allow_lds() {
 #undef X
 #define X(L_) PHX_CHECK((dst_long_allow_lds<L_>()));
   PHX_DST_LONG_LENGTHS(X)
+#undef X
+#define X(L_) PHX_CHECK((dst_pair_allow_lds<L_>()));
+  PHX_DST_PAIR_LENGTHS(X)
 #undef X
   PHX_CHECK((dst_allow_lds_t<double, true>()));
   PHX_CHECK((dst_allow_lds_t<double, false>()));
@@ -866,6 +870,20 @@ static int box_pass_y_t(phx_box_precond *bp, hipStream_t st, phx_system *prof, i
     }
   }
   if constexpr (sizeof(T) == 8) {
+    if (!done && dst_pair_fast(g, py, 0)) {
+      switch (py.L) {
+#define X(L_) case L_: { \
+          using S = PairShape<L_, 0>; \
+          const int ncbp = (g.m[0] + S::W - 1) / S::W, ntiles = ncbp * g.m[2]; \
+          k_dst_yp<L_, 0><<<dim3((unsigned)dst_pair_grid<L_>(ntiles)), dim3(S::NTHR), (size_t)S::LDS_ELEMS * 16, st>>>(g, py, G, ra, dir, ncbp, ntiles); \
+          done = true; } break;
+        PHX_DST_PAIR_LENGTHS(X)
+#undef X
+        default: break;
+      }
+    }
+  }
+  if constexpr (sizeof(T) == 8) {
     if (!done && dst_long_fast(g, py, 0)) {
       const int ntiles = ncb * g.m[2];
       const dim3 gl((unsigned)dst_long_grid(py, ntiles));
@@ -953,6 +971,25 @@ static int box_pass_x_t(phx_box_precond *bp, hipStream_t st, const double *vin, 
           else k_dst_xw<L_, IO, false><<<grid, block, lds, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb); \
           done = true; break;
         PHX_DST_WAVE_LENGTHS(X)
+#undef X
+        default: break;
+      }
+    }
+  }
+  if constexpr (sizeof(T) == 8) {
+    if (!done && dst_pair_fast(g, px, bp->nvec)) {
+      const uint32_t vb = (uint32_t)(bp->nvec * 8);
+      double *Gd = static_cast<double *>(bp->G);
+      switch (px.L) {
+#define X(L_) case L_: { \
+          using S = PairShape<L_, 0>; \
+          const int ngroups = (int)phx_div_up(npairs, S::PAIRS); \
+          const dim3 gp((unsigned)dst_pair_grid<L_>(ngroups)), bk(S::NTHR); \
+          const size_t ldsp = (size_t)S::LDS_ELEMS * 16; \
+          if (sc) k_dst_xp<L_, 0, IO, IO != 0><<<gp, bk, ldsp, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb, ngroups); \
+          else k_dst_xp<L_, 0, IO, false><<<gp, bk, ldsp, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb, ngroups); \
+          done = true; } break;
+        PHX_DST_PAIR_LENGTHS(X)
 #undef X
         default: break;
       }
