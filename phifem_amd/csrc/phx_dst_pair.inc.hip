@@ -446,11 +446,14 @@ k_dst_xp(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict
 }
 
 #define PHX_DST_PAIR_LENGTHS(X) X(384) X(768) X(1024)
+// alternative y-tile widths (PHX_DST_YALT=1): as many pairs as the LDS holds
+template <int LL> struct PairAlt { static constexpr int NP = LL == 384 ? 24 : (LL == 768 ? 12 : 7); };
 
 template <int LL>
 static int dst_pair_allow_lds() {
   const int bytes = 160 * 1024;
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_yp<LL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_yp<LL, PairAlt<LL>::NP>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_xp<LL, 0, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_xp<LL, 0, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_xp<LL, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -459,9 +462,9 @@ static int dst_pair_allow_lds() {
   return PHX_OK;
 }
 // blocks a CU holds (by LDS and threads) x CUs: the persistent grid
-template <int LL>
+template <int LL, int NP = 0>
 static int dst_pair_grid(int64_t nwork) {
-  using S = PairShape<LL, 0>;
+  using S = PairShape<LL, NP>;
   const size_t lds = (size_t)S::LDS_ELEMS * 16;
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)(160 * 1024) / lds, 2048 / (size_t)S::NTHR));
   return (int)std::min<int64_t>(nwork, (int64_t)per_cu * 256);

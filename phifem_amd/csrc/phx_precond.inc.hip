@@ -871,8 +871,13 @@ static int box_pass_y_t(phx_box_precond *bp, hipStream_t st, phx_system *prof, i
   }
   if constexpr (sizeof(T) == 8) {
     if (!done && dst_pair_fast(g, py, 0)) {
+      static const bool yalt = getenv("PHX_DST_YALT") != nullptr;
       switch (py.L) {
-#define X(L_) case L_: { \
+#define X(L_) case L_: if (yalt) { \
+          using S = PairShape<L_, PairAlt<L_>::NP>; \
+          const int ncbp = (g.m[0] + S::W - 1) / S::W, ntiles = ncbp * g.m[2]; \
+          k_dst_yp<L_, PairAlt<L_>::NP><<<dim3((unsigned)dst_pair_grid<L_, PairAlt<L_>::NP>(ntiles)), dim3(S::NTHR), (size_t)S::LDS_ELEMS * 16, st>>>(g, py, G, ra, dir, ncbp, ntiles); \
+          done = true; } else { \
           using S = PairShape<L_, 0>; \
           const int ncbp = (g.m[0] + S::W - 1) / S::W, ntiles = ncbp * g.m[2]; \
           k_dst_yp<L_, 0><<<dim3((unsigned)dst_pair_grid<L_>(ntiles)), dim3(S::NTHR), (size_t)S::LDS_ELEMS * 16, st>>>(g, py, G, ra, dir, ncbp, ntiles); \

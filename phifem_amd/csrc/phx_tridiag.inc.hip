@@ -42,18 +42,28 @@ struct TriArgs {
   const double *lamx, *lamy;
   const double *w_in, *y_in, *y1;   // MODE 2, one value per column e
   double *wl, *yl;                  // MODE 1
+  int cl;                   // rows per chunk (<= C, the register array of the kernel): ceil(nloc / chunks), so the
+                            // chunks are balanced (194 planes: 8 x 25 rows instead of 6 x 32 + 2 + 0)
 };
 
-template <typename T, int C, int MODE>
-__global__ void __launch_bounds__(1024)
+// NT = threads of the block (64 x chunks): with 512 threads the compiler may keep a chunk of 32 rows in registers
+// (__launch_bounds__(1024) capped it at 128 VGPRs: C = 32 spilled 36 registers, C = 48 145 -- the pass ran at 3.1 TB/s on the
+// 768 x 768 x 194 lattice and at 1.9 TB/s on 384 x 384 x 354 against 4.8 TB/s where C = 8)
+// CW = columns of a block (64, or 32: the two halves of a wavefront then take different chunks of the same 32 columns --
+// twice the chunks for long columns, rows of 256 bytes).
+template <typename T, int C, int MODE, int NT, int CW = 64>
+__global__ void __launch_bounds__(NT)
 k_tri_z(TriArgs a, T *__restrict__ G) {
   extern __shared__ double tri_lds[];
-  const int lane = threadIdx.x & 63, c = threadIdx.x >> 6, P = blockDim.x >> 6;
-  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  constexpr int SUB = 64 / CW;
+  const int lane = (int)(threadIdx.x & 63) % CW, c = (int)(threadIdx.x >> 6) * SUB + (int)(threadIdx.x & 63) / CW;
+  const int P = (int)(blockDim.x >> 6) * SUB;
+  const int64_t e = (int64_t)blockIdx.x * CW + lane;
   const int x = (int)(e % a.pitch), yy = (int)(e / a.pitch);
   const bool colok = x < a.m0 && yy < a.m1;
-  double *sW = tri_lds, *sY = tri_lds + (size_t)P * 64;       // [P][64] each
-  const int r0 = c * C, len = max(0, min(C, a.nloc - r0));     // local rows r0 .. r0 + len - 1
+  double *sW = tri_lds, *sY = tri_lds + (size_t)P * CW;       // [P][CW] each
+  const int CL = a.cl;
+  const int r0 = c * CL, len = max(0, min(CL, a.nloc - r0));   // local rows r0 .. r0 + len - 1
   // ---- column constants
   double rho = 0.0, om = 1.0;  // om = 1 - rho^2
   if (colok) {
@@ -77,12 +87,12 @@ k_tri_z(TriArgs a, T *__restrict__ G) {
   for (int i = 0; i < C; ++i) {
     if (i < len) { acc = __builtin_fma(rho, acc, v[i]); v[i] = acc; }
   }
-  sW[c * 64 + lane] = acc;
-  const double rhoC = dpow(rho, C);
+  sW[c * CW + lane] = acc;
+  const double rhoC = dpow(rho, CL);
   __syncthreads();
-  // true w below this chunk: inflow of the rank, then the chunks before this one (all of full length C)
+  // true w below this chunk: inflow of the rank, then the chunks before this one (all of full length CL)
   double win = MODE == 2 && colok ? a.w_in[e] : 0.0;
-  for (int j = 0; j < c; ++j) win = __builtin_fma(rhoC, win, sW[j * 64 + lane]);
+  for (int j = 0; j < c; ++j) win = __builtin_fma(rhoC, win, sW[j * CW + lane]);
   {
     double pw = win;
 #pragma unroll
@@ -97,23 +107,23 @@ k_tri_z(TriArgs a, T *__restrict__ G) {
   for (int i = C - 1; i >= 0; --i) {
     if (i < len) { acc = rho * (v[i] + acc); v[i] = acc; }
   }
-  sY[c * 64 + lane] = acc;
+  sY[c * CW + lane] = acc;
   __syncthreads();
   // true y above this chunk, and y at the first local plane: chain the chunks from the top (a chunk of length
   // l passes an inflow on as rho^l x inflow; only the last non-empty chunk can be short)
   double yin = MODE == 2 && colok ? a.y_in[e] : 0.0, ynext = 0.0;
   for (int j = P - 1; j >= 0; --j) {
     if (j == c) ynext = yin;
-    const int lj = max(0, min(C, a.nloc - j * C));
-    yin = sY[j * 64 + lane] + (lj == C ? rhoC : dpow(rho, lj)) * yin;
+    const int lj = max(0, min(CL, a.nloc - j * CL));
+    yin = sY[j * CW + lane] + (lj == CL ? rhoC : dpow(rho, lj)) * yin;
   }
   if (MODE == 1) {
     // carries with zero inflow: w at the last local plane = what the chunk scan hands on at the top
     if (c == 0 && colok) {
       double wtop = 0.0;
       for (int j = 0; j < P; ++j) {
-        const int lj = max(0, min(C, a.nloc - j * C));
-        wtop = sW[j * 64 + lane] + (lj == C ? rhoC : dpow(rho, lj)) * wtop;
+        const int lj = max(0, min(CL, a.nloc - j * CL));
+        wtop = sW[j * CW + lane] + (lj == CL ? rhoC : dpow(rho, lj)) * wtop;
       }
       a.wl[e] = wtop;
       a.yl[e] = yin;
@@ -184,36 +194,50 @@ __global__ void k_tri_interface(TriArgs a, TriRanks R, const double *__restrict_
   y1[e] = Y;
 }
 
-// chunk length (registers per lane) and waves per block for `nloc` planes
-static inline void tri_shape(int nloc, int *C, int *P) {
-  *P = nloc > 512 ? 16 : 8;
-  const int need = (nloc + *P - 1) / *P;
+// register rows per lane C, chunks per column P (8 or 16 wavefronts of 64 columns, or 16 wavefronts of 2 x 32 columns) and
+// rows per chunk CL for `nloc` planes
+static inline void tri_shape(int nloc, int *C, int *P, int *CL) {
+  *P = nloc > 384 ? 32 : (nloc > 256 ? 16 : 8);
+  *CL = std::max(1, (nloc + *P - 1) / *P);
   const int cand[] = {8, 16, 24, 32, 48, 64};
   *C = 64;
-  for (int c : cand) if (c >= need) { *C = c; break; }
+  for (int c : cand) if (c >= *CL) { *C = c; break; }
 }
 
 template <typename T, int MODE>
-static int tri_launch(const TriArgs &a, T *G, hipStream_t st) {
+static int tri_launch(const TriArgs &a0, T *G, hipStream_t st) {
+  TriArgs a = a0;
   if (a.cz == 0.0) {
     const int64_t ncol = (int64_t)a.pitch * a.m1;
     if (MODE != 1) k_scale_xy<T><<<dim3((unsigned)phx_div_up(ncol, 256)), dim3(256), 0, st>>>(a, G);
     PHX_HIP(hipGetLastError());
     return PHX_OK;
   }
-  int C, P;
-  tri_shape(a.nloc, &C, &P);
+  int C, P, CL;
+  tri_shape(a.nloc, &C, &P, &CL);
   PHX_REQUIRE(a.nloc <= C * P, PHX_ERR_VALUE, "tridiagonal z pass: %d planes exceed %d x %d", a.nloc, P, C);
+  a.cl = CL;
   const int64_t ncol = (int64_t)a.pitch * a.m1;
-  const dim3 grid((unsigned)phx_div_up(ncol, 64)), block((unsigned)(64 * P));
-  const size_t lds = sizeof(double) * 2 * 64 * (size_t)P;
-  switch (C) {
-    case 8: k_tri_z<T, 8, MODE><<<grid, block, lds, st>>>(a, G); break;
-    case 16: k_tri_z<T, 16, MODE><<<grid, block, lds, st>>>(a, G); break;
-    case 24: k_tri_z<T, 24, MODE><<<grid, block, lds, st>>>(a, G); break;
-    case 32: k_tri_z<T, 32, MODE><<<grid, block, lds, st>>>(a, G); break;
-    case 48: k_tri_z<T, 48, MODE><<<grid, block, lds, st>>>(a, G); break;
-    default: k_tri_z<T, 64, MODE><<<grid, block, lds, st>>>(a, G); break;
+  const int cw = P == 32 ? 32 : 64;
+  const dim3 grid((unsigned)phx_div_up(ncol, cw)), block((unsigned)(P == 8 ? 512 : 1024));
+  const size_t lds = sizeof(double) * 2 * (size_t)cw * (size_t)P;
+  if (P == 8) {
+    switch (C) {
+      // (up to 24 rows the 128-register cap of 1024 threads costs nothing and keeps four waves per SIMD)
+      case 8: k_tri_z<T, 8, MODE, 1024><<<grid, block, lds, st>>>(a, G); break;
+      case 16: k_tri_z<T, 16, MODE, 1024><<<grid, block, lds, st>>>(a, G); break;
+      case 24: k_tri_z<T, 24, MODE, 1024><<<grid, block, lds, st>>>(a, G); break;
+      default: k_tri_z<T, 32, MODE, 512><<<grid, block, lds, st>>>(a, G); break;
+    }
+  } else if (P == 16) {
+    k_tri_z<T, 24, MODE, 1024><<<grid, block, lds, st>>>(a, G);   // 257 .. 384 planes
+  } else {
+    switch (C) {
+      case 8: case 16: case 24: k_tri_z<T, 24, MODE, 1024, 32><<<grid, block, lds, st>>>(a, G); break;   // .. 768 planes
+      case 32: k_tri_z<T, 32, MODE, 1024, 32><<<grid, block, lds, st>>>(a, G); break;
+      case 48: k_tri_z<T, 48, MODE, 1024, 32><<<grid, block, lds, st>>>(a, G); break;
+      default: k_tri_z<T, 64, MODE, 1024, 32><<<grid, block, lds, st>>>(a, G); break;
+    }
   }
   PHX_HIP(hipGetLastError());
   return PHX_OK;

@@ -30,6 +30,8 @@ def scipy_box_solve(f, L, h):
                                (512, 64, 64), (64, 64, 768), (1024, 64, 64), (768, 64, 40), (64, 768, 20), (384, 192, 30),
                                # z is solved as a tridiagonal system: any column length, no transform
                                (64, 64, 180), (128, 64, 38), (64, 128, 2), (64, 64, 3), (64, 64, 1025),
+                               # chunk shapes of the z pass: 8 / 16 wavefronts of 64 columns, 16 wavefronts of 2 x 32 columns
+                               (64, 64, 195), (64, 64, 258), (64, 64, 355), (64, 64, 500), (64, 64, 701),
                                # lengths served by the wave-mode kernels (phx_dst_wave.inc.hip) in x AND in y, odd plane counts
                                (192, 192, 21), (256, 512, 4), (512, 256, 7), (192, 256, 2)])
 @pytest.mark.parametrize("f32", [0, 1])
