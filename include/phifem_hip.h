@@ -178,6 +178,10 @@ enum phx_option {
                                H ~ n / 8 (H = 16 h beyond 128 cubes); 0: off; >= 5: this ratio.  Needs
                                librocsolver for the dense inverse of the coarse matrix (loaded on first use;
                                without it the solve keeps the vertex blocks alone)                              */
+  PHX_OPT_STENCIL_PLANE_ROWS = 11, /* structured P1 systems on 3-D boxes: from this many interior rows per lattice
+                               plane on (default 32768: three planes of the vector no longer fit an XCD's L2 next to the
+                               streams) the stencil blocks of the SpMV walk the k-th eighth of EVERY plane on XCD k
+                               instead of the k-th eighth of all rows; 0: never.  Placement only: same product   */
   PHX_OPT_ALLOW_EMPTY = 6, /* 1: phx_assemble_poisson_wd returns an EMPTY system (n_active = 0) when no cell
                                is tagged 1 / 2 instead of PHX_ERR_VALUE: a slab of a partitioned box that
                                does not touch the domain still joins every collective of the solve          */

@@ -28,7 +28,7 @@ CELL_TYPES = {"triangle": TRIANGLE, "quadrilateral": QUADRILATERAL, "tetrahedron
 CELL_NAMES = {v: k for k, v in CELL_TYPES.items()}
 PHI_NODAL_P1, PHI_POINTS, PHI_QUADRIC = 0, 1, 2
 (OPT_PROFILE_SPMV, OPT_HAS_EXTERIOR, OPT_SPMV_XCD_GROUP, OPT_SPMV_VALUE_INDEX, OPT_PRECOND, OPT_ALLOW_EMPTY,
- OPT_EXPORT_CSR, OPT_STRUCTURED, OPT_DETERMINISTIC, OPT_EL_COARSE) = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10)
+ OPT_EXPORT_CSR, OPT_STRUCTURED, OPT_DETERMINISTIC, OPT_EL_COARSE, OPT_STENCIL_PLANE_ROWS) = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)
 (ARR_COORDS, ARR_CELLS, ARR_C2F, ARR_F2C, ARR_CELL_TAGS, ARR_FACET_TAGS, ARR_BFACETS, ARR_C2E,
  ARR_EDGES) = range(9)
 

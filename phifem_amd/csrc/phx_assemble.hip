@@ -1279,7 +1279,7 @@ extern "C" int phx_system_destroy(phx_system *s) {
   void *ptrs[] = {s->dof_of_vertex_u, s->dof_of_vertex_p, s->full_of_active, s->rowptr, s->col,
                   s->val, s->rhs, s->diag, s->slice_ptr, s->sell_col, s->sell_val,
                   s->sell_val_raw, s->sell_kind, s->perm, s->iperm, s->work, s->scal, s->row_nz,
-                  s->c0, s->stencil, s->seg, s->slice_seg, s->sell_rows, s->cscale, s->pvec, s->bnd, s->bnd_rec, s->dpart};
+                  s->c0, s->stencil, s->seg, s->slice_seg, s->sell_rows, s->cscale, s->pvec, s->bnd, s->bnd_rec, s->dpart, s->st_map};
   for (void *p : ptrs) (void)phx_free(p);
   if (s->p2s) {
     (void)phx_free(s->p2s->coef); (void)phx_free(s->p2s->mask); (void)phx_free(s->p2s->runs);

@@ -140,6 +140,7 @@ struct phx_mesh {
   bool own_stream = true;
   int profile_spmv = 0;
   int spmv_xcd_group = 0;          // PHX_OPT_SPMV_XCD_GROUP
+  int64_t stencil_plane_rows = 32768;  // PHX_OPT_STENCIL_PLANE_ROWS
   int spmv_value_index = 1;        // PHX_OPT_SPMV_VALUE_INDEX
   int precond = 1;                 // PHX_OPT_PRECOND: 0 Jacobi, 1 / 2 box sine transforms in f64 / f32 where applicable
   int has_exterior_override = -1;  // -1: decide from the local tags; 0/1: imposed (multi-GPU)
@@ -271,6 +272,10 @@ struct phx_system {
   int32_t *seg = nullptr;          // [nseg][6] {first row, end row, offset of the +y, -y, +z, -z neighbour rows}
   int32_t nseg = 0;
   int32_t *slice_seg = nullptr;    // [ceil(nu / 64)][16] slice records: {runs in the slice, first run, two runs inline}
+  // stencil blocks of LARGE lattice planes (three planes of x exceed an XCD's L2): block (XCD k, sequence j) -> {first
+  // slice, slices} so that XCD k walks the k-th eighth of EVERY plane, plane after plane (phx_solve.hip, k_stmap_build)
+  int32_t *st_map = nullptr;       // [8][st_chunk][2]
+  int64_t st_chunk = 0;
   int32_t *sell_rows = nullptr;    // [nslices * 64] row held by SELL slot (slice, lane), -1: padding
   int64_t n_sell_rows = 0;
   double *cscale = nullptr;        // [n] x = cscale * y when the iteration ends (1 for unscaled columns, else 1 / diag)

@@ -215,12 +215,12 @@ k_dst_yp(BoxGrid g, DstPlan P, double *__restrict__ G, const int2 *__restrict__ 
       const int2 iv = row_any[outer];
       const int rlo = iv.y >= iv.x ? iv.x : (1 << 30);
       const uint32_t span = iv.y >= iv.x ? (uint32_t)(iv.y - iv.x) : 0u;
-      if (dir == 1) { T.lrlo = rlo; T.lspan = span; } else { T.srlo = rlo; T.sspan = span; }
+      if ((dir & 3) == 1) { T.lrlo = rlo; T.lspan = span; } else { T.srlo = rlo; T.sspan = span; }
     }
     return T;
   };
   auto issue_loads = [&](const Tile &T) {
-    const bool colok = tcol < T.ncols;
+    const bool colok = tcol < T.ncols && !(dir & 0x200);
     const uint32_t offa = colok ? (uint32_t)(tcol * 8 + row0 * pitch8) : PHX_BUF_OOB;
     const uint32_t offb = colok ? (uint32_t)(tcol * 8 + (LL - 2 - row0) * pitch8) : 0xc0000000u;
     const uint32_t da = (uint32_t)(row0 - T.lrlo), db = (uint32_t)(LL - 2 - row0 - T.lrlo);
@@ -254,7 +254,7 @@ k_dst_yp(BoxGrid g, DstPlan P, double *__restrict__ G, const int2 *__restrict__ 
     if (fold_in && row0 == 0) wcol[0] = 0.0;
   };
   auto issue_stores = [&](const Tile &T) {
-    const bool colok = tcol < T.ncols;
+    const bool colok = tcol < T.ncols && !(dir & 0x200);
     const uint32_t offa = colok ? (uint32_t)(tcol * 8 + row0 * pitch8) : PHX_BUF_OOB;
     const uint32_t offb = colok ? (uint32_t)(tcol * 8 + (LL - 2 - row0) * pitch8) : 0xc0000000u;
     const uint32_t da = (uint32_t)(row0 - T.srlo), db = (uint32_t)(LL - 2 - row0 - T.srlo);
@@ -280,7 +280,7 @@ k_dst_yp(BoxGrid g, DstPlan P, double *__restrict__ G, const int2 *__restrict__ 
   __syncthreads();
   for (;;) {
     // a wavefront whose pair(s) lie beyond the tile's columns transforms nothing (wave-uniform)
-    if (2 * (pr - (S::TP == 32 ? (pr & 1) : 0)) < cur.ncols) {
+    if (2 * (pr - (S::TP == 32 ? (pr & 1) : 0)) < cur.ncols && !(dir & 0x100)) {
       int tt = t;
       asm volatile("" : "+v"(tt));
       pair_core<LL, S::TP>(w, tt, tw);

@@ -1134,6 +1134,10 @@ extern "C" int phx_set_option(phx_mesh *m, int option, int64_t value) {
       PHX_REQUIRE(value >= 0 && value < (1 << 24), PHX_ERR_VALUE, "XCD group size out of range");
       m->spmv_xcd_group = (int)value;
       return PHX_OK;
+    case PHX_OPT_STENCIL_PLANE_ROWS:
+      PHX_REQUIRE(value >= 0, PHX_ERR_VALUE, "rows per plane out of range");
+      m->stencil_plane_rows = value;
+      return PHX_OK;
     default: phx_set_error("unknown option %d", option); return PHX_ERR_VALUE;
   }
 }

@@ -872,6 +872,8 @@ static int box_pass_y_t(phx_box_precond *bp, hipStream_t st, phx_system *prof, i
   if constexpr (sizeof(T) == 8) {
     if (!done && dst_pair_fast(g, py, 0)) {
       static const bool yalt = getenv("PHX_DST_YALT") != nullptr;
+      static const int ydbg = getenv("PHX_DST_YDBG") ? atoi(getenv("PHX_DST_YDBG")) : 0;   // experiment: 1 no transform, 2 no memory
+      dir |= ydbg << 8;
       switch (py.L) {
 #define X(L_) case L_: if (yalt) { \
           using S = PairShape<L_, PairAlt<L_>::NP>; \

@@ -603,6 +603,64 @@ __global__ void k_seg_fill(int64_t nq, const int32_t *__restrict__ perm, const i
   if (fe[q]) seg[6 * (int64_t)ie[q] + 1] = (int32_t)(q + 1);
 }
 
+// ---- stencil blocks of large lattice planes.  The C0 rows are numbered in lattice order, so the z neighbours of a row
+// sit one PLANE of rows away.  Where three planes of x (z - 1, z, z + 1) exceed an XCD's 4 MiB L2 -- 1024 x 1024 x 128 slab:
+// 3.7e5 rows = 2.9 MB per plane -- a walk over contiguous eighths of the rows fetched x FOUR times through the fabric
+// (FETCH_SIZE of the stencil blocks alone: 1.5 GB against the 0.38 GB of x; 283 us).  Instead XCD k takes the k-th eighth of
+// EVERY plane, plane after plane: its window is three eighth-planes.  zstart[z] = first position of plane z (zstart[nzp] = nq).
+__global__ void k_plane_starts(int64_t nq, const int32_t *__restrict__ perm, const int64_t *__restrict__ full, int64_t n01,
+                               int nzp, int32_t *__restrict__ zstart) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const int z = (int)(full[perm[q]] / n01);
+  const int zp = q > 0 ? (int)(full[perm[q - 1]] / n01) : -1;
+  for (int zz = zp + 1; zz <= z; ++zz) zstart[zz] = (int32_t)q;
+  if (q == nq - 1) for (int zz = z + 1; zz <= nzp; ++zz) zstart[zz] = (int32_t)nq;
+}
+// slice boundary of part k of plane z
+__device__ __forceinline__ int64_t stmap_bound(const int32_t *zstart, int nzp, int64_t nq, int z, int k) {
+  if (z >= nzp) return (nq + 63) >> 6;
+  const int64_t a = zstart[z], len = zstart[z + 1] - a;
+  return (a + (len * k) / 8) >> 6;
+}
+// block k (one per XCD): entries {first slice, slices <= 16} of its blocks, plane after plane; unused entries {0, 0}
+__global__ void __launch_bounds__(1024)
+k_stmap_build(int nzp, int64_t nq, const int32_t *__restrict__ zstart, int64_t chunk, int32_t *__restrict__ map) {
+  __shared__ int cnt[1024];
+  __shared__ int base;
+  const int k = (int)blockIdx.x, tid = (int)threadIdx.x;
+  int32_t *mk = map + 2 * (int64_t)k * chunk;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int z0 = 0; z0 < nzp; z0 += 1024) {
+    const int z = z0 + tid;
+    int64_t b0 = 0, b1 = 0;
+    if (z < nzp) {
+      b0 = stmap_bound(zstart, nzp, nq, z, k);
+      b1 = k == 7 ? stmap_bound(zstart, nzp, nq, z + 1, 0) : stmap_bound(zstart, nzp, nq, z, k + 1);
+    }
+    const int c = (int)((b1 - b0 + 15) >> 4);
+    cnt[tid] = c;
+    __syncthreads();
+    // exclusive scan of the 1024 counts (Hillis-Steele in shared memory)
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int v = tid >= o ? cnt[tid - o] : 0;
+      __syncthreads();
+      cnt[tid] += v;
+      __syncthreads();
+    }
+    const int off = base + cnt[tid] - c;
+    for (int j = 0; j < c; ++j) {
+      mk[2 * (int64_t)(off + j)] = (int32_t)(b0 + 16 * j);
+      mk[2 * (int64_t)(off + j) + 1] = (int32_t)min((int64_t)16, b1 - b0 - 16 * j);
+    }
+    __syncthreads();
+    if (tid == 1023) base += cnt[1023];
+    __syncthreads();
+  }
+  for (int64_t j = base + tid; j < chunk; j += 1024) { mk[2 * j] = 0; mk[2 * j + 1] = 0; }
+}
+
 // slice record of 64 consecutive positions: {runs intersecting the slice (3 = more than two), index of the first,
 // the first two runs inline}
 __global__ void k_slice_seg(int64_t nw, int nseg, const int32_t *__restrict__ seg, int32_t *__restrict__ srec) {
@@ -815,6 +873,19 @@ int phx_system_build_structured(phx_system *s, const phx_slot_view &sv, int32_t 
     k_slice_seg<<<dim3((unsigned)phx_div_up(nw, 256)), block, 0, st>>>(nw, s->nseg, s->seg, s->slice_seg);
     PHX_HIP(hipGetLastError());
     later.push_back(fs); later.push_back(fe); later.push_back(is); later.push_back(ie);
+    // planes too large for the L2 window of a contiguous walk: per-plane eighths (see k_stmap_build)
+    const int nzp = has_z ? (int)(m->box_n[2] + 1) : 0;
+    if (has_z && m->stencil_plane_rows > 0 && nq / nzp >= m->stencil_plane_rows) {
+      int32_t *zstart = nullptr;
+      PHX_HIP(phx_malloc(&zstart, sizeof(int32_t) * (size_t)(nzp + 1)));
+      k_plane_starts<<<gq, block, 0, st>>>(nq, s->perm, s->full_of_active, n01, nzp, zstart);
+      s->st_chunk = nw / 128 + 2 * (int64_t)nzp + 2;
+      PHX_HIP(phx_malloc(&s->st_map, sizeof(int32_t) * 2 * 8 * (size_t)s->st_chunk));
+      k_stmap_build<<<8, 1024, 0, st>>>(nzp, nq, zstart, s->st_chunk, s->st_map);
+      PHX_HIP(hipGetLastError());
+      later.push_back(zstart);
+      s->sell_stream_bytes += 8 * 8 * s->st_chunk;
+    }
     s->sell_stream_bytes += 24 * (int64_t)s->nseg + 64 * nw;
   }
   PHX_HIP(hipGetLastError());
@@ -878,6 +949,7 @@ struct StencilArgs {
   const int32_t *srec;    // [ceil(nu / 64)][16] slice records
   const double *st;       // {diag, x, y, z entries} of a C0 row
   int64_t chunk;          // stencil blocks per XCD
+  const int32_t *map;     // nullable: [8][chunk][2] {first slice, slices} per block (planes beyond the L2 window)
 };
 
 template <int DOTS>
@@ -926,7 +998,13 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
     const int64_t bl = blockIdx.x - nb_sell;                       // nb_sell is a multiple of 8
     const int64_t sb_ = (bl & 7) * sa.chunk + (bl >> 3);           // XCD (bl % 8) takes the blocks of its eighth
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t w0 = (sb_ * (int64_t)(blockDim.x >> 6) + wave) * U;
+    int64_t w0 = (sb_ * (int64_t)(blockDim.x >> 6) + wave) * U;
+    int wn = U;                                                    // slices of this wave
+    if (sa.map) {
+      const int32_t *e = sa.map + 2 * sb_;                         // block-uniform
+      w0 = (int64_t)e[0] + wave * U;
+      wn = min(U, max(0, e[1] - wave * U));
+    }
     bool live[U];
     int32_t oyp[U], oym[U], ozp[U], ozm[U];
 #pragma unroll
@@ -934,7 +1012,7 @@ k_spmv_sell(int64_t n, int64_t nslices, const int64_t *__restrict__ slice_ptr,
       const int64_t w = w0 + u, r = w * 64 + lane;
       live[u] = false;
       oyp[u] = oym[u] = ozp[u] = ozm[u] = 0;
-      if (w * 64 < sa.nu) {
+      if (u < wn && w * 64 < sa.nu) {
         // {runs in this slice (3: more than two), first run, run A[6], run B[6]}: wave-uniform, scalar loads
         const int32_t *rec = sa.srec + 16 * w;
         const int cnt = rec[0];
@@ -1471,7 +1549,7 @@ static int det_part(phx_system *s, int64_t nb, DotPart *out) {
   out->p0 = out->p1 = nullptr;
   if (!s->mesh->deterministic) return PHX_OK;
   if (!s->dpart) {
-    s->dpart_cap = phx_div_up(s->nslices, 4) + phx_div_up(s->nstencil_pos, 1024) + 16384;
+    s->dpart_cap = phx_div_up(s->nslices, 4) + phx_div_up(s->nstencil_pos, 1024) + 8 * s->st_chunk + 16384;
     PHX_HIP(phx_malloc(&s->dpart, sizeof(double) * 2 * (size_t)s->dpart_cap));
     s->dpart_used = 0;
   }
@@ -1517,7 +1595,7 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   const uint8_t *bnd = part_of == 1 ? s->bnd : nullptr;
   // structured systems: the stencil blocks (rows of C0; u columns are unscaled in both value streams) ride behind
   // the SELL blocks of the same launch
-  StencilArgs sa{0, nullptr, 0, nullptr, nullptr, 0};
+  StencilArgs sa{0, nullptr, 0, nullptr, nullptr, 0, nullptr};
   int64_t nb_sell = phx_div_up(s->nslices, 4);
   static const int part = getenv("PHX_SPMV_PART") ? atoi(getenv("PHX_SPMV_PART")) : 0;  // timing aid: 1 SELL only, 2 stencil only
   if (part == 2) nb_sell = 0;
@@ -1529,7 +1607,8 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
     // (round-robin placement had every L2 fetch the whole vector: 3.5 x the bytes, 44 % hits)
     nb_sell = (nb_sell + 7) & ~(int64_t)7;
     const int64_t nbst = phx_div_up(phx_div_up(s->nstencil_pos, 64), 16);   // four waves per block, four slices per wave
-    sa = StencilArgs{s->nstencil_pos, s->seg, s->nseg, s->slice_seg, s->stencil, (nbst + 7) / 8};
+    sa = StencilArgs{s->nstencil_pos, s->seg, s->nseg, s->slice_seg, s->stencil, (nbst + 7) / 8, nullptr};
+    if (s->st_map) { sa.chunk = s->st_chunk; sa.map = s->st_map; }
     nb = nb_sell + 8 * sa.chunk;
   }
   const int xg2 = (sell_xcd == 1 && s->structured && nb_sell % 8 == 0 && nb_sell > 0) ? -1 : xg;
@@ -1580,11 +1659,11 @@ static int phx_spmv_flag_rows(phx_system *s, int nlists, const int64_t *const *i
     if (counts[l] > 0)
       k_mark_positions<<<dim3((unsigned)phx_div_up(counts[l], 256)), dim3(256), 0, st>>>(counts[l], idx[l], isg);
   const int32_t *rows = s->structured ? s->sell_rows : nullptr;
-  StencilArgs sa{0, nullptr, 0, nullptr, nullptr, 0};
+  StencilArgs sa{0, nullptr, 0, nullptr, nullptr, 0, nullptr};
   const int64_t nb_sell = phx_div_up(s->nslices, 4);
   int64_t nb = nb_sell;
   if (s->structured && s->nseg > 0) {
-    sa = StencilArgs{s->nstencil_pos, s->seg, s->nseg, s->slice_seg, s->stencil, 0};
+    sa = StencilArgs{s->nstencil_pos, s->seg, s->nseg, s->slice_seg, s->stencil, 0, nullptr};
     nb = nb_sell + phx_div_up(phx_div_up(s->nstencil_pos, 64), 4);
   }
   for (int pass = 0; pass < 2 && nb > 0; ++pass) {
