@@ -388,6 +388,11 @@ typedef struct phx_comm phx_comm;
 int phx_comm_unique_id(void *out128);
 int phx_comm_create(int nranks, int rank, const void *uid128, int device, phx_comm **out);
 int phx_comm_destroy(phx_comm *c);
+/* Path of the shared object the ten RCCL entry points were bound from (dladdr of ncclAllReduce), zero-terminated into
+ * out[len].  The library binds RCCL at run time (librccl.so.1 of the process; PHX_RCCL_LIB names another file -- the
+ * one-GPU tests load a host-staged stand-in that way -- and says so on stderr): a driver prints this next to its
+ * result so that what carried the collectives is on record.  No counterpart in the reference (serial). */
+int phx_comm_library(char *out, int64_t len);
 int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, const int *peers,
                           const int64_t *counts, const int64_t *const *idx, double rtol,
                           int64_t max_iter, double *x, int loc, double *stats);

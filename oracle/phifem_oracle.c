@@ -108,10 +108,16 @@ static void mesh_build(Mesh *m, int64_t n) {
 }
 
 /* ---- tagging (detection degree 1, nodal P1 level-set) ------------------------------------- */
-static int detect(const double *ph, int k) {
-  /* sum_q phi_q / sum_q |phi_q| over the k vertices, sequential (oracle/tagging.py:_ratio) */
+static int detect(const double *ph, int k, double scale) {
+  /* sum_q phi_q / sum_q |phi_q| over the k vertices, sequential (oracle/tagging.py:_ratio); samples of both signs: every
+     term times `scale` (|det J| of the cell, the factor FFCx gives the terms of a dx sum) */
   double num = 0.0, den = 0.0;
-  for (int q = 0; q < k; ++q) { num = num + ph[q]; den = den + fabs(ph[q]); }
+  int pos = 0, neg = 0;
+  for (int q = 0; q < k; ++q) { num = num + ph[q]; den = den + fabs(ph[q]); pos |= ph[q] > 0.0; neg |= ph[q] < 0.0; }
+  if (pos && neg) {
+    num = 0.0; den = 0.0;
+    for (int q = 0; q < k; ++q) { const double t = ph[q] * scale; num = num + t; den = den + fabs(t); }
+  }
   const double d = den > 0.0 ? num / den : 0.5;
   if (d == -1.0) return 1;
   if (d == 1.0) return 3;
@@ -121,9 +127,18 @@ static int detect(const double *ph, int k) {
 static void tag_cells(const Mesh *m, const double *phi, int single_layer, int8_t *ct) {
 #pragma omp parallel for
   for (int64_t c = 0; c < m->nc; ++c) {
-    double ph[4];
+    double ph[4], e[3][3];
     for (int i = 0; i < 4; ++i) ph[i] = phi[m->cells[4 * c + i]];
-    ct[c] = (int8_t)detect(ph, 4);
+    /* |det J|: edge vectors from vertex 0, cofactor expansion along the first row (oracle/tagging.py:cell_scale) */
+    const double *x0 = m->x + 3 * (int64_t)m->cells[4 * c];
+    for (int a = 0; a < 3; ++a) {
+      const double *xa = m->x + 3 * (int64_t)m->cells[4 * c + a + 1];
+      for (int d = 0; d < 3; ++d) e[a][d] = xa[d] - x0[d];
+    }
+    const double c0 = e[1][1] * e[2][2] - e[1][2] * e[2][1];
+    const double c1 = e[1][0] * e[2][2] - e[1][2] * e[2][0];
+    const double c2 = e[1][0] * e[2][1] - e[1][1] * e[2][0];
+    ct[c] = (int8_t)detect(ph, 4, fabs((e[0][0] * c0 - e[0][1] * c1) + e[0][2] * c2));
   }
   if (!single_layer) return;
   uint8_t *touched = (uint8_t *)calloc(m->nv, 1);

@@ -11,8 +11,11 @@ numpy restatement of `src/phifem/mesh_scripts.py` (a2-a8 of SURVEY.md section 8)
 
 Deviations that cannot be avoided without dolfinx/FFCx [3P] (all confined to cases where a
 sum of mixed-sign samples is within one ulp of the sum of their magnitudes):
-  * the common |detJ| factor of the `dx` detection sums and the per-facet measure factor of
-    the `ds` detection sums are dropped;
+  * the `dx` detection sums scale every term by |det J| of the cell's corner (round 4: with it the oracle reproduces
+    the 8 `ellipse_in_square` degree-3 goldens, whose level-set passes exactly through mesh vertices; FFCx evaluates J
+    per quadrature point on quadrilaterals); the zero-denominator warning (mesh_scripts.py:129) looks at the UNSCALED
+    sum -- the reference's absolute 1e-8 on the scaled sum fires on every fine mesh; the per-facet measure factor of the
+    `ds` detection sums is dropped;
   * a cell's boundary facets are accumulated in ascending LOCAL facet order.
 """
 import warnings
@@ -67,24 +70,57 @@ def _eval_on(levelset, Nmat, vert_ids, x):
     return np.asarray(vals, dtype=np.float64).reshape(n, npts)
 
 
-def _ratio(phi_q):
-    """mesh_scripts.py:112-134 with sequential sums."""
+def cell_scale(topo, x):
+    """|det J| of the affine map through the first gdim + 1 vertices of a cell (edge vectors e_a = x_a - x_0,
+    cofactor expansion along the first row, left to right).  FFCx scales every quadrature term of a `dx` integral by
+    |det J| x weight [3P]; the weights of the detection rule are 1 (mesh_scripts.py:331).  For a non-affine
+    quadrilateral FFCx evaluates J per point; the corner value stands in for it (only the rounding of the terms
+    depends on it)."""
+    xc = x[topo.cells]
+    e = xc[:, 1:x.shape[1] + 1, :] - xc[:, 0:1, :]
+    if x.shape[1] == 2:
+        return np.abs(e[:, 0, 0] * e[:, 1, 1] - e[:, 0, 1] * e[:, 1, 0])
+    c0 = e[:, 1, 1] * e[:, 2, 2] - e[:, 1, 2] * e[:, 2, 1]
+    c1 = e[:, 1, 0] * e[:, 2, 2] - e[:, 1, 2] * e[:, 2, 0]
+    c2 = e[:, 1, 0] * e[:, 2, 1] - e[:, 1, 1] * e[:, 2, 0]
+    return np.abs((e[:, 0, 0] * c0 - e[:, 0, 1] * c1) + e[:, 0, 2] * c2)
+
+
+def _ratio(phi_q, scale=None):
+    """mesh_scripts.py:112-134 with sequential sums.  `scale` (per cell): the factor FFCx multiplies every term of a
+    `dx` sum with.  A common positive factor cannot change the outcome of a cell whose samples all have one sign
+    (num = +-den term by term), so it is applied where it can matter: to the cells with samples of BOTH signs, where
+    whether a tiny term is absorbed by the rounding of the running sum depends on it.  Returns (d, unscaled den)."""
     num = np.zeros(phi_q.shape[0])
     den = np.zeros(phi_q.shape[0])
     for q in range(phi_q.shape[1]):
         num = num + phi_q[:, q]
         den = den + np.abs(phi_q[:, q])
+    den0 = den
+    if scale is not None:
+        mixed = np.flatnonzero(np.any(phi_q > 0.0, axis=1) & np.any(phi_q < 0.0, axis=1))
+        if mixed.size:
+            num, den = num.copy(), den.copy()
+            pm, sm = phi_q[mixed], scale[mixed]
+            nm = np.zeros(mixed.size)
+            dm = np.zeros(mixed.size)
+            for q in range(pm.shape[1]):
+                t = pm[:, q] * sm
+                nm = nm + t
+                dm = dm + np.abs(t)
+            num[mixed] = nm
+            den[mixed] = dm
     d = np.full_like(num, 0.5)
     ok = den > 0.0
     with np.errstate(all="ignore"):
         d[ok] = num[ok] / den[ok]
-    return d, den
+    return d, den0
 
 
 def cell_detection_vector(topo, x, levelset, degree, warn=True):
     pts = P.cell_detection_points(topo.cell_type, degree)
     Nmat = P.shape_functions(topo.cell_type, pts)
-    d, den = _ratio(_eval_on(levelset, Nmat, topo.cells, x))
+    d, den = _ratio(_eval_on(levelset, Nmat, topo.cells, x), cell_scale(topo, x))
     if warn and np.any(np.isclose(den, 0.0)):
         warnings.warn("The detection function is zero everywhere on a cell. We mark it as "
                       "'cut' but this can be incorrect and should be carefully checked.",

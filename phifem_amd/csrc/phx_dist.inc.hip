@@ -22,6 +22,7 @@ struct NcclApi {
   bool ok = false;
 };
 static NcclApi g_nccl;
+static char g_nccl_path[512] = "";   // file the ten entry points were bound from (phx_comm_library)
 enum { PHX_NCCL_FLOAT64 = 8, PHX_NCCL_SUM = 0 };  // ncclDataType_t / ncclRedOp_t values of nccl.h
 
 static int nccl_bind() {
@@ -46,7 +47,23 @@ static int nccl_bind() {
   BIND(GroupEnd, "ncclGroupEnd");
   BIND(GetErrorString, "ncclGetErrorString");
 #undef BIND
+  {
+    // which file the symbols really come from (a soname says little): the object that holds ncclAllReduce.  Said once on
+    // stderr when PHX_RCCL_LIB substituted the collective library, so that a stand-in is never bound silently.
+    Dl_info di;
+    if (dladdr((void *)g_nccl.AllReduce, &di) && di.dli_fname) snprintf(g_nccl_path, sizeof(g_nccl_path), "%s", di.dli_fname);
+    const char *e = getenv("PHX_RCCL_LIB");
+    if (e && *e) fprintf(stderr, "phifem_hip: collective library taken from PHX_RCCL_LIB: %s\n", g_nccl_path[0] ? g_nccl_path : e);
+  }
   g_nccl.ok = true;
+  return PHX_OK;
+}
+
+// Path of the library the RCCL entry points are bound to (binds them if that has not happened yet).
+extern "C" int phx_comm_library(char *out, int64_t len) {
+  PHX_CHECK(nccl_bind());
+  PHX_REQUIRE(out != nullptr && len > 0, PHX_ERR_VALUE, "phx_comm_library: no buffer");
+  snprintf(out, (size_t)len, "%s", g_nccl_path);
   return PHX_OK;
 }
 

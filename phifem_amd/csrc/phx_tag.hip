@@ -82,10 +82,40 @@ k_tag_cells(int64_t nc, DetTab tab, const int32_t *__restrict__ cells,
     for (int i = 0; i < NVPC; ++i) v[i] = cells[c * NVPC + i];
   }
   double num = 0.0, den = 0.0;
+  bool pos = false, neg = false;
   for (int q = 0; q < tab.npts; ++q) {
     const double p = phi_at<KIND, GDIM>(tab, q, NVPC, v, phi, x, quad, c * (int64_t)tab.npts);
     num = num + p;
     den = den + fabs(p);
+    pos |= p > 0.0;
+    neg |= p < 0.0;
+  }
+  const double den0 = den;
+  if (pos && neg) {
+    // Samples of both signs: FFCx scales every term of a dx sum by |det J| (x weight 1), and whether a tiny term is
+    // absorbed by the rounding of the running sum depends on that factor (oracle/tagging.py:_ratio -- with it the 8
+    // ellipse_in_square degree-3 goldens are reproduced).  One sign only: num = +-den term by term whatever the factor,
+    // so the (few) cells that need the coordinate gathers are the cut ones.  |det J|: edge vectors from vertex 0,
+    // cofactor expansion along the first row, left to right (oracle/tagging.py:cell_scale).
+    double e[GDIM][GDIM];
+    for (int a = 0; a < GDIM; ++a)
+      for (int dd = 0; dd < GDIM; ++dd) e[a][dd] = x[(int64_t)v[a + 1] * GDIM + dd] - x[(int64_t)v[0] * GDIM + dd];
+    double s;
+    if (GDIM == 2) {
+      s = fabs(e[0][0] * e[1][1] - e[0][1] * e[1][0]);
+    } else {
+      const double c0 = e[1][1] * e[GDIM - 1][GDIM - 1] - e[1][GDIM - 1] * e[GDIM - 1][1];
+      const double c1 = e[1][0] * e[GDIM - 1][GDIM - 1] - e[1][GDIM - 1] * e[GDIM - 1][0];
+      const double c2 = e[1][0] * e[GDIM - 1][1] - e[1][1] * e[GDIM - 1][0];
+      s = fabs((e[0][0] * c0 - e[0][1] * c1) + e[0][GDIM - 1] * c2);
+    }
+    num = 0.0;
+    den = 0.0;
+    for (int q = 0; q < tab.npts; ++q) {
+      const double t = phi_at<KIND, GDIM>(tab, q, NVPC, v, phi, x, quad, c * (int64_t)tab.npts) * s;
+      num = num + t;
+      den = den + fabs(t);
+    }
   }
   // mesh_scripts.py:124-128: 0.5 wherever the denominator is not > 0 (zero or NaN)
   const double d = (den > 0.0) ? num / den : 0.5;
@@ -94,7 +124,7 @@ k_tag_cells(int64_t nc, DetTab tab, const int32_t *__restrict__ cells,
   if (d == 1.0) t = 3;              // :346
   if (d == -1.0) t = 1;             // :347
   tags[c] = t;
-  if (fabs(den) <= 1.0e-8) atomicOr(warn, 1);  // numpy.isclose(den, 0.0), :129
+  if (fabs(den0) <= 1.0e-8) atomicOr(warn, 1);  // numpy.isclose(den, 0.0), :129 (on the unscaled sum)
 }
 
 // --- single layer (mesh_scripts.py:349-358) -------------------------------------------------

@@ -346,19 +346,35 @@ class DistributedSolver:
 WATCHDOG_EXIT_CODE = 87
 
 
-class Watchdog:
-    """Bounds a call into RCCL (communicator set-up, halo self-test, the native loop).  A collective whose partner
-    never arrives blocks inside the library where no exception can reach it; after `PHIFEM_DIST_TIMEOUT_S`
-    (default 600 s, 0 = off) the rank says so and EXITS with code 87.  Nothing is re-exec'd: this process has
-    initialised the GPU and its stream is wedged.  A launcher that has not touched the GPU (`bench.py --gpus N`
-    started without one) may start fresh ranks with PHIFEM_NATIVE_LOOP=0; under an external launcher the non-zero
-    exit ends the job instead of hanging it."""
+def dist_timeout_s():
+    """The ONE time limit of the multi-GPU path, seconds (0 = off): PHX_DIST_TIMEOUT_S, default 300 -- the variable the
+    library reads for the host waits of its loop.  PHIFEM_DIST_TIMEOUT_S (the name rounds 2-3 used on the Python side)
+    is accepted and handed on to the library when the new name is not set."""
+    import os
+    if "PHX_DIST_TIMEOUT_S" not in os.environ and "PHIFEM_DIST_TIMEOUT_S" in os.environ:
+        os.environ["PHX_DIST_TIMEOUT_S"] = os.environ["PHIFEM_DIST_TIMEOUT_S"]
+    return float(os.environ.get("PHX_DIST_TIMEOUT_S", "300"))
 
-    def __init__(self, what, rank):
+
+class Watchdog:
+    """Bounds a call into RCCL.  A collective whose partner never arrives blocks inside the library where no exception
+    can reach it; the rank then says so and EXITS with code 87.  Nothing is re-exec'd: this process has initialised
+    the GPU and its stream is wedged.  A launcher that has not touched the GPU (`bench.py --gpus N` started without
+    one) may start fresh ranks with PHIFEM_NATIVE_LOOP=0 (bench.py does, once); under an external launcher the
+    non-zero exit ends the job instead of hanging it.
+
+    Two kinds of call: communicator set-up and the halo self-test have no bound of their own, so a
+    wall-clock limit on the whole call stands around them (`PHX_DIST_TIMEOUT_S`, default 300 s, 0 = off;
+    `PHIFEM_DIST_TIMEOUT_S` is read as an older name of the same variable).  `phx_solve_distributed` bounds EVERY host
+    wait of its loop itself with the same variable (`stream_sync_watchdog`, phx_dist.inc.hip) -- a limit on PROGRESS, so
+    a long but healthy solve is never killed; around it (`bounded_inside=True`) this class runs no timer and only turns
+    the library's PHX_ERR_TIMEOUT into the same exit."""
+
+    def __init__(self, what, rank, bounded_inside=False):
         import os
         import threading
         self.what, self.rank = what, rank
-        self.limit = float(os.environ.get("PHIFEM_DIST_TIMEOUT_S", "600"))
+        self.limit = 0.0 if bounded_inside else float(dist_timeout_s())
         self._done = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True) if self.limit > 0 else None
 
@@ -377,7 +393,7 @@ class Watchdog:
         import sys
         if not self._done.wait(self.limit):
             print(f"phifem_amd: rank {self.rank}: {self.what} did not return within {self.limit:g} s "
-                  f"(PHIFEM_DIST_TIMEOUT_S) -- exiting with code {WATCHDOG_EXIT_CODE}", file=sys.stderr, flush=True)
+                  f"(PHX_DIST_TIMEOUT_S) -- exiting with code {WATCHDOG_EXIT_CODE}", file=sys.stderr, flush=True)
             self._leave()
 
     def __enter__(self):
@@ -413,6 +429,7 @@ class DistributedKrylov:
         self.comm = None
         self.native = None   # None: not tried yet, True/False afterwards
         self.path = "python"
+        self.library = None  # file the library's RCCL entry points are bound to (native loop)
 
     def agree_on_exterior(self):
         """`len(exterior_cells) == 0` (mesh_scripts.py:469) must be decided over ALL slabs."""
@@ -464,6 +481,9 @@ class DistributedKrylov:
         ok = rc == 0
         if ok:
             self.comm = h
+            buf = C.create_string_buffer(512)
+            if L.lib.phx_comm_library(buf, 512) == 0:
+                self.library = buf.value.decode(errors="replace")
         self.native = self._all_ok(ok)
 
     def _halo_arrays(self, ds):
@@ -531,7 +551,7 @@ class DistributedKrylov:
         st = (C.c_double * 8)()
         self.torch.cuda.synchronize(self.dev)
         t0 = time.perf_counter()
-        with Watchdog("phx_solve_distributed", prob.rank):
+        with Watchdog("phx_solve_distributed", prob.rank, bounded_inside=True):
             L.check(L.lib.phx_solve_distributed(backend.sys, self.comm, np_, peers, counts, idx,
                                                 float(prob.rtol), int(prob.max_iter),
                                                 C.c_void_p(out.data_ptr()), L.DEVICE, st))

@@ -61,9 +61,11 @@ def test_gpus_2_without_launcher_starts_ranks_and_fails_without_a_gpu():
 
 
 def test_watchdog_leaves_with_its_exit_code_and_marker(tmp_path):
-    """The RCCL watchdog (phifem_amd.dist_solver.Watchdog): a call that does not return within
-    PHIFEM_DIST_TIMEOUT_S makes the rank exit with code 87 and leave the marker file the launcher looks for; a
-    call that returns in time leaves nothing."""
+    """The RCCL watchdog (phifem_amd.dist_solver.Watchdog): a call WITHOUT a bound of its own (communicator set-up,
+    self-test) that does not return within PHX_DIST_TIMEOUT_S makes the rank exit with code 87 and leave the marker
+    file the launcher looks for; a call that returns in time leaves nothing; a call the library bounds itself
+    (`bounded_inside`: the solve, whose every host wait has the limit) runs without a timer however long it takes,
+    and a TimeoutError out of it takes the same exit.  PHIFEM_DIST_TIMEOUT_S is the older name of the variable."""
     import subprocess
     import sys
     mark = tmp_path / "mark"
@@ -73,12 +75,28 @@ def test_watchdog_leaves_with_its_exit_code_and_marker(tmp_path):
             "with Watchdog('quick call', 0):\n"
             "    pass\n"
             "print('first ok', flush=True)\n"
+            "with Watchdog('long healthy solve', 0, bounded_inside=True):\n"
+            "    time.sleep(1.5)\n"
+            "print('second ok', flush=True)\n"
             "with Watchdog('stuck collective', 3):\n"
             "    time.sleep(30)\n"
             "print('not reached')\n") % ROOT
-    env = dict(os.environ, PHIFEM_DIST_TIMEOUT_S="0.5", PHIFEM_WATCHDOG_FILE=str(mark))
+    env = dict(os.environ, PHX_DIST_TIMEOUT_S="0.5", PHIFEM_WATCHDOG_FILE=str(mark))
+    env.pop("PHIFEM_DIST_TIMEOUT_S", None)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 87, (r.returncode, r.stderr[-500:])
-    assert "first ok" in r.stdout and "not reached" not in r.stdout
+    assert "first ok" in r.stdout and "second ok" in r.stdout and "not reached" not in r.stdout
     assert "stuck collective" in r.stderr and "rank 3" in r.stderr
     assert mark.exists()
+    # the older variable name still sets the limit, and a library timeout inside a bounded call leaves the same way
+    mark.unlink()
+    code2 = ("import sys\n"
+             "sys.path.insert(0, %r)\n"
+             "from phifem_amd.dist_solver import Watchdog, dist_timeout_s\n"
+             "assert dist_timeout_s() == 7.0\n"
+             "with Watchdog('solve', 1, bounded_inside=True):\n"
+             "    raise TimeoutError('the stream did not drain')\n") % ROOT
+    env2 = dict(os.environ, PHIFEM_DIST_TIMEOUT_S="7", PHIFEM_WATCHDOG_FILE=str(mark))
+    env2.pop("PHX_DIST_TIMEOUT_S", None)
+    r2 = subprocess.run([sys.executable, "-c", code2], env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode == 87 and mark.exists(), (r2.returncode, r2.stderr[-500:])

