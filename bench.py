@@ -333,8 +333,9 @@ def main(argv=None):
         # so this is far below the CSR figure of SURVEY 8(d) and it is the one a bus fraction must be taken of.
         required = res["spmv_stream_bytes"] + 16.0 * res["spmv_rows"]
         ach_req = required / spmv_s / 1e9 if spmv_s > 0 else 0.0
-        tr, src = pmc_traffic("k_spmv_sell", res["spmv_algorithmic_bytes"])
-        assert ach_req <= HBM_PEAK_GBS, "SpMV: more required bytes per second than the HBM peak -- the timed kernel is not doing the counted work"
+        tr, src = pmc_traffic("k_spmv_sell+k_spmv_p2s" if args.config3 else "k_spmv_sell", res["spmv_algorithmic_bytes"])
+        # (a small --cubes run whose streams sit in L2 / the Infinity Cache may exceed the HBM peak: flagged, not fatal -- ADVICE r3)
+        cache_resident = ach_req > HBM_PEAK_GBS
         spmv_roof = {
             "bound": "hbm",
             "kernel": ("k_spmv_sell + k_spmv_p2s (f64 SpMV of the structured P2 system: SELL-16 slices with f64 values / i32 "
@@ -348,7 +349,7 @@ def main(argv=None):
             # `achieved` / `frac`: SURVEY 8(d)'s algorithmic bytes of the CSR product, 12 nnz + 20 n -- a THROUGHPUT
             # figure (CSR-equivalent GB/s); `achieved_required` / `frac_required`: bytes this format must move
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "achieved_required": ach_req, "frac_required": ach_req / HBM_PEAK_GBS,
+            "achieved_required": ach_req, "frac_required": ach_req / HBM_PEAK_GBS, "cache_resident": cache_resident,
             "required_bytes_per_launch": required,
             "traffic": tr, "traffic_source": src, "traffic_over_required": (tr / required) if tr else None,
             "bytes_per_launch": res["spmv_algorithmic_bytes"],
@@ -361,10 +362,10 @@ def main(argv=None):
             a2 = res["dst_algorithmic_bytes"] / dst_s / 1e9
             # f64 lattices of a wave-mode length run the shape-specialised kernel (phx_dst_wave.inc.hip)
             wave = res["precond_value_bytes"] == 8 and res["precond_L"][1] in (192, 256, 512)
-            long_ = res["precond_value_bytes"] == 8 and res["precond_L"][1] in (384, 768, 1024)   # phx_dst_long.inc.hip
-            kname = (f"k_dst_yw<{res['precond_L'][1]}>" if wave else f"k_dst_yl<{res['precond_L'][1]}>" if long_ else
+            long_ = res["precond_value_bytes"] == 8 and res["precond_L"][1] in (384, 768, 1024)   # phx_dst_pair.inc.hip
+            kname = (f"k_dst_yw<{res['precond_L'][1]}>" if wave else f"k_dst_yp<{res['precond_L'][1]}>" if long_ else
                      f"k_dst_s<{'float' if res['precond_value_bytes'] == 4 else 'double'},1,false>")
-            tr2, src2 = pmc_traffic("k_dst_yw" if wave else "k_dst_s_y", res["dst_algorithmic_bytes"])
+            tr2, src2 = pmc_traffic("k_dst_yw" if wave else "k_dst_yp" if long_ else "k_dst_s_y", res["dst_algorithmic_bytes"])
             dst_roof = {
                 "bound": "hbm",
                 "kernel": f"{kname} (type-I sine "

@@ -488,6 +488,11 @@ static int coarse_build(phx_system *s, int nblk, phx_coarse **out, const CcReduc
     static bool warned = false;
     if (!warned) fprintf(stderr, "phifem_hip: librocsolver / librocblas not loadable: elasticity solves run without the coarse correction\n");
     warned = true;
+    // asked for by value (PHX_OPT_EL_COARSE >= 5) on one rank: an error, not a silently different preconditioner.  The
+    // automatic choice (-1) degrades to the vertex blocks with the line above; a partitioned box votes (all ranks alike).
+    PHX_REQUIRE(!(req > 0 && !reduce), PHX_ERR_NOT_IMPLEMENTED,
+                "PHX_OPT_EL_COARSE = %d asks for the coarse correction, but librocsolver / librocblas (the dense inverse of the "
+                "coarse matrix) cannot be loaded", req);
     if (!reduce) return PHX_OK;
     veto = true;
   }

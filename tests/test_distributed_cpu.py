@@ -50,9 +50,11 @@ def worker(rank, world, n, port, outdir, sphere=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_slab_solver_matches_single_mesh(world, tmp_path):
-    n = 8
+    """world = 8: the rank count of the driver's scaling run -- eight slabs of four cube layers, so
+    that the ghost layers of a slab reach exactly one neighbour."""
+    n = 8 if world < 8 else 4
     port = free_port()
     mp.spawn(worker, args=(world, n, port, str(tmp_path)), nprocs=world, join=True)
     # single-mesh reference
@@ -95,6 +97,27 @@ def test_empty_end_slabs_join_the_collectives(tmp_path):
         owned.append(int(d["n_owned"]))
         assert d["relres"] <= 1e-11 and d["it"] > 0    # every rank saw the same (all-reduced) residual
     assert owned[0] == 0 and owned[3] == 0 and owned[1] > 0 and owned[2] > 0
+    assert sum(owned) == int(act.sum())
+    assert np.abs(u - wref[:nvg]).max() <= 1e-7 * np.abs(wref).max()
+
+
+def test_eight_slabs_with_empty_ends(tmp_path):
+    """The layout of `bench.py --config5 --gpus 8` in miniature: unit sphere, eight slabs, the end slabs (here ranks 0-1
+    and 6-7) own nothing and still take part in every collective."""  # noqa
+    n, world = 6, 8
+    port = free_port()
+    mp.spawn(worker, args=(world, n, port, str(tmp_path), True), nprocs=world, join=True)
+    x, topo, cv, A, b, act = assemble_local(n, world, 0, n * world, sphere=True)
+    wref = OA.solve_direct(A, b, act)
+    nvg = topo.nv
+    u = np.zeros(nvg)
+    owned = []
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        u[d["gid"]] = d["u"]
+        owned.append(int(d["n_owned"]))
+        assert d["relres"] <= 1e-11 and d["it"] > 0
+    assert owned[0] == 0 and owned[7] == 0 and max(owned) > 0
     assert sum(owned) == int(act.sum())
     assert np.abs(u - wref[:nvg]).max() <= 1e-7 * np.abs(wref).max()
 
