@@ -29,8 +29,13 @@ _mesh_cache = {}
 
 
 def get_mesh(P, name):
+    """The test mesh in the numbering dolfinx's read_mesh gives it (phifem_amd/reorder.py; the identity on the three
+    files dolfinx wrote, a Gibbs-Poole-Stockmeyer reordering of `disk`): tag arrays then compare with the reference's
+    golden files index by index."""
     if name not in _mesh_cache:
+        from phifem_amd.reorder import as_dolfinx_reads_it
         ctype, x, cells = load_mesh(name)
+        x, cells = as_dolfinx_reads_it(ctype, x, cells)[:2]
         m = P.Mesh.from_arrays(ctype, x, cells)
         topo = Topology(ctype, cells, x.shape[0])
         _mesh_cache[name] = (m, topo, x)
@@ -145,6 +150,10 @@ def test_hip_vs_reference_goldens(P, name, deg, box, sl):
         assert ok, (name, deg, box, sl, disc)
         assert np.array_equal(hc.indices, GOLD[f"{name}_{deg}{mid}cells_tags:i"])
         assert np.array_equal(hf.indices, GOLD[f"{name}_{deg}{mid}facets_tags:i"])
+        # ELEMENT-WISE equality with the reference's golden files, as tests/test_compute_meshtags.py:239-243
+        # compares (the mesh is held in dolfinx's numbering, see get_mesh)
+        assert np.array_equal(hc.values, gc), (name, deg, box, sl, disc, np.flatnonzero(hc.values != gc)[:8])
+        assert np.array_equal(hf.values, gf), (name, deg, box, sl, disc, np.flatnonzero(hf.values != gf)[:8])
     if missed:
         pytest.xfail("floating-point-degenerate level-set (SURVEY 4.3), decided by FFCx round-off: " + "; ".join(missed))
 
