@@ -1,8 +1,7 @@
-// Sine-transform passes for the LONG f64 lengths (384, 768, 1024), second version: ONE WAVEFRONT PER PAIR of lines --
-// included by phx_precond.inc.hip behind phx_dst_long.inc.hip, whose block-synchronous kernels stay as the A/B reference
-// (PHX_DST_LONG_OLD=1).
+// Sine-transform passes for the LONG f64 lengths (384, 768, 1024): ONE WAVEFRONT PER PAIR of lines -- included by
+// phx_precond.inc.hip behind phx_dst_wave.inc.hip.  (PHX_DST_OLD=1: the generic kernels k_dst_x / k_dst_s, the A/B reference.)
 //
-// Why: k_dst_xl / k_dst_yl spread a pair over L / 8 threads = 1.5 wavefronts (L = 768), so every Stockham stage and every
+// Why: the kernels of round 3 (k_dst_xl / k_dst_yl, docs/HISTORY.md) spread a pair over L / 8 threads = 1.5 wavefronts (L = 768), so every Stockham stage and every
 // step of the prefix sum met at a BLOCK barrier: eleven barriers over twelve wavefronts per tile, 15 us of transform time per
 // tile against 10 us of memory time and 5 us of LDS pipe time.  Here a pair lives inside one wavefront (64 lanes x 12
 // elements at L = 768, 32 x 12 at 384 -- two pairs per wavefront --, 64 x 16 at 1024), the stages synchronise wave-locally
@@ -13,8 +12,10 @@
 //                                                1024: (8,1) (8,8) (4,64) (4,256)
 // The last stage of the 12-element shapes is one radix-12 butterfly per lane, done in registers as a prime-factor 3 x 4
 // transform (no internal twiddles) and IN PLACE (p = L / 12 = lanes of the pair: input and output positions coincide).
-// Everything else -- persistent blocks, loads of the next tile in flight during the transform, buffer descriptors with
-// out-of-range offsets for masked accesses -- as in phx_dst_long.inc.hip.
+// Blocks are PERSISTENT and software-pipelined over their tiles (one block per CU: the tile takes most of the LDS): while
+// tile n is transformed in LDS the loads of tile n + 1 are in flight into registers and the stores of tile n - 1 drain.
+// Loader / storer idioms as in phx_dst_wave.inc.hip: compile-time shapes, buffer descriptors, out-of-range offsets for
+// masked accesses, gathers through the map without a mask.
 
 // LDS layout of a pair's sequence (16-byte elements).  L = 384 / 768: NO padding, an XOR swizzle of the low four index bits
 //   S(n) = n ^ (14 [n bit 4] | [n bit 3])
@@ -267,7 +268,9 @@ k_dst_yp(BoxGrid g, DstPlan P, double *__restrict__ G, const int2 *__restrict__ 
     }
   };
 
+  // blocks b and b + 8 share an XCD (round-robin placement; speed only): consecutive tiles of a sweep go to one XCD
   int q = (int)blockIdx.x;
+  if ((gridDim.x & 7) == 0) q = (q & 7) * (int)(gridDim.x >> 3) + (q >> 3);
   if (q >= ntiles) return;
   const int stride = (int)gridDim.x;
   Tile cur = tile_of(q);
@@ -447,13 +450,10 @@ k_dst_xp(BoxGrid g, DstPlan P, double *__restrict__ G, const int32_t *__restrict
 
 #define PHX_DST_PAIR_LENGTHS(X) X(384) X(768) X(1024)
 // alternative y-tile widths (PHX_DST_YALT=1): as many pairs as the LDS holds
-template <int LL> struct PairAlt { static constexpr int NP = LL == 384 ? 24 : (LL == 768 ? 12 : 7); };
-
 template <int LL>
 static int dst_pair_allow_lds() {
   const int bytes = 160 * 1024;
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_yp<LL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-  PHX_HIP(hipFuncSetAttribute((const void *)k_dst_yp<LL, PairAlt<LL>::NP>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_xp<LL, 0, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_xp<LL, 0, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   PHX_HIP(hipFuncSetAttribute((const void *)k_dst_xp<LL, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -470,7 +470,7 @@ static int dst_pair_grid(int64_t nwork) {
   return (int)std::min<int64_t>(nwork, (int64_t)per_cu * 256);
 }
 static bool dst_pair_fast(const BoxGrid &g, const DstPlan &p, int64_t nvec) {
-  static const bool off = getenv("PHX_DST_OLD") != nullptr || getenv("PHX_DST_GENERIC") != nullptr || getenv("PHX_DST_LONG_OLD") != nullptr;
+  static const bool off = getenv("PHX_DST_OLD") != nullptr || getenv("PHX_DST_GENERIC") != nullptr;
   if (off) return false;
   const int64_t lat = g.plane * g.m[2];
   if (g.plane != g.pitch * g.m[1] || lat * 8 >= (int64_t)PHX_BUF_OOB || nvec * 8 >= (int64_t)PHX_BUF_OOB) return false;

@@ -681,7 +681,6 @@ k_dst_s(BoxGrid g, DstPlan P, T *__restrict__ G, const int2 *__restrict__ row_an
 
 constexpr bool dst_wave_f64(int L) { return L / 8 == 32 || L / 8 == 64 || L / 8 == 24; }
 #include "phx_dst_wave.inc.hip"
-#include "phx_dst_long.inc.hip"
 #include "phx_dst_pair.inc.hip"
 
 // --------------------------------------------------------------------------------------------------
@@ -753,9 +752,6 @@ static int dst_allow_lds() {
 #undef X
 #define X(L_) PHX_CHECK((dst_wave_allow_lds<L_>()));
   PHX_DST_WAVE_LENGTHS(X)
-#undef X
-#define X(L_) PHX_CHECK((dst_long_allow_lds<L_>()));
-  PHX_DST_LONG_LENGTHS(X)
 #undef X
 #define X(L_) PHX_CHECK((dst_pair_allow_lds<L_>()));
   PHX_DST_PAIR_LENGTHS(X)
@@ -871,32 +867,15 @@ static int box_pass_y_t(phx_box_precond *bp, hipStream_t st, phx_system *prof, i
   }
   if constexpr (sizeof(T) == 8) {
     if (!done && dst_pair_fast(g, py, 0)) {
-      static const bool yalt = getenv("PHX_DST_YALT") != nullptr;
       static const int ydbg = getenv("PHX_DST_YDBG") ? atoi(getenv("PHX_DST_YDBG")) : 0;   // experiment: 1 no transform, 2 no memory
       dir |= ydbg << 8;
       switch (py.L) {
-#define X(L_) case L_: if (yalt) { \
-          using S = PairShape<L_, PairAlt<L_>::NP>; \
-          const int ncbp = (g.m[0] + S::W - 1) / S::W, ntiles = ncbp * g.m[2]; \
-          k_dst_yp<L_, PairAlt<L_>::NP><<<dim3((unsigned)dst_pair_grid<L_, PairAlt<L_>::NP>(ntiles)), dim3(S::NTHR), (size_t)S::LDS_ELEMS * 16, st>>>(g, py, G, ra, dir, ncbp, ntiles); \
-          done = true; } else { \
+#define X(L_) case L_: { \
           using S = PairShape<L_, 0>; \
           const int ncbp = (g.m[0] + S::W - 1) / S::W, ntiles = ncbp * g.m[2]; \
           k_dst_yp<L_, 0><<<dim3((unsigned)dst_pair_grid<L_>(ntiles)), dim3(S::NTHR), (size_t)S::LDS_ELEMS * 16, st>>>(g, py, G, ra, dir, ncbp, ntiles); \
           done = true; } break;
         PHX_DST_PAIR_LENGTHS(X)
-#undef X
-        default: break;
-      }
-    }
-  }
-  if constexpr (sizeof(T) == 8) {
-    if (!done && dst_long_fast(g, py, 0)) {
-      const int ntiles = ncb * g.m[2];
-      const dim3 gl((unsigned)dst_long_grid(py, ntiles));
-      switch (py.L) {
-#define X(L_) case L_: k_dst_yl<L_><<<gl, block, (size_t)py.lds_elems * el, st>>>(g, py, G, ra, dir, ncb, ntiles); done = true; break;
-        PHX_DST_LONG_LENGTHS(X)
 #undef X
         default: break;
       }
@@ -997,23 +976,6 @@ static int box_pass_x_t(phx_box_precond *bp, hipStream_t st, const double *vin, 
           else k_dst_xp<L_, 0, IO, false><<<gp, bk, ldsp, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb, ngroups); \
           done = true; } break;
         PHX_DST_PAIR_LENGTHS(X)
-#undef X
-        default: break;
-      }
-    }
-  }
-  if constexpr (sizeof(T) == 8) {
-    if (!done && dst_long_fast(g, px, bp->nvec)) {
-      const uint32_t vb = (uint32_t)(bp->nvec * 8);
-      double *Gd = static_cast<double *>(bp->G);
-      const int ngroups = (int)phx_div_up(npairs, px.pairs);
-      const dim3 gl((unsigned)dst_long_grid(px, ngroups));
-      switch (px.L) {
-#define X(L_) case L_: \
-          if (sc) k_dst_xl<L_, IO, IO != 0><<<gl, block, lds, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb, ngroups); \
-          else k_dst_xl<L_, IO, false><<<gl, block, lds, st>>>(g, px, Gd, bp->gmap, vin, vout, sc, bp->line_any, vb, ngroups); \
-          done = true; break;
-        PHX_DST_LONG_LENGTHS(X)
 #undef X
         default: break;
       }
