@@ -424,6 +424,7 @@ def main(argv=None):
                 # what actually ran (a retry with PHIFEM_NATIVE_LOOP=0 keeps the vertex blocks WITHOUT the coarse correction)
                 "precond_in_force": res.get("precond"), "precond_slab_exact": bool(res.get("precond_exact", False)),
                 "collective_library": getattr(getattr(prob, "dk", None), "library", None),
+                "halo_overlap": bool(getattr(getattr(prob, "dk", None), "overlap", False)),
                 "system": res.get("system"),
                 "deterministic": bool(getattr(prob.solver, "deterministic", False)),
                 "hbm_in_use_gb": hbm_in_use_gb(),

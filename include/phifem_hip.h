@@ -393,6 +393,10 @@ int phx_comm_destroy(phx_comm *c);
  * one-GPU tests load a host-staged stand-in that way -- and says so on stderr): a driver prints this next to its
  * result so that what carried the collectives is on record.  No counterpart in the reference (serial). */
 int phx_comm_library(char *out, int64_t len);
+/* *out = 1 when phx_solve_distributed overlaps the halo exchanges of this communicator with the SpMV rows that read no
+ * halo entry (second stream, two events): phx_halo_selftest has then seen the overlapped exchange deliver, bit for bit, what
+ * the exchange in series delivers, and PHX_DIST_OVERLAP is not 0.  Otherwise the exchanges stay on the solver stream. */
+int phx_comm_overlap(const phx_comm *c, int *out);
 int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, const int *peers,
                           const int64_t *counts, const int64_t *const *idx, double rtol,
                           int64_t max_iter, double *x, int loc, double *stats);

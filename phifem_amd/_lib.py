@@ -81,6 +81,7 @@ SIGNATURES = {
     "phx_comm_create": ([_i, _i, _vp, _i, C.POINTER(_vp)], _i),
     "phx_comm_destroy": ([_vp], _i),
     "phx_comm_library": ([C.c_char_p, C.c_int64], _i),
+    "phx_comm_overlap": ([_vp, C.POINTER(_i)], _i),
     "phx_solve_distributed": ([_vp, _vp, _i, _vp, _vp, _vp, _d, _i64, _vp, _i, _pd], _i),
     "phx_halo_selftest": ([_vp, _vp, _i, _vp, _vp, _vp, _vp], _i),
     "phx_tag_cells": ([_vp, _i, _vp, _i, _i, _i, _pi], _i),

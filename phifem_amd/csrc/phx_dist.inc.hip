@@ -82,6 +82,9 @@ struct phx_comm {
   // halo exchanges run on their own stream so that the rows of the SpMV that read no halo entry overlap with them
   hipStream_t cs = nullptr;
   hipEvent_t ev_packed = nullptr, ev_recvd = nullptr;
+  // the overlapped exchange (second stream, two events) is used once phx_halo_selftest has seen it deliver, on THIS
+  // communicator, what the exchange in series delivers (never validated on hardware with several GPUs before)
+  bool overlap_ok = false;
 };
 
 extern "C" int phx_comm_unique_id(void *out128) {
@@ -128,6 +131,14 @@ extern "C" int phx_comm_destroy(phx_comm *c) {
   return PHX_OK;
 }
 
+// 1 when the halo exchanges of this communicator run overlapped with the SpMV (self-test passed and PHX_DIST_OVERLAP != 0)
+extern "C" int phx_comm_overlap(const phx_comm *c, int *out) {
+  PHX_REQUIRE(c != nullptr && out != nullptr, PHX_ERR_VALUE, "phx_comm_overlap: null argument");
+  const bool env = !(getenv("PHX_DIST_OVERLAP") && atoi(getenv("PHX_DIST_OVERLAP")) == 0);
+  *out = (env && c->overlap_ok) ? 1 : 0;
+  return PHX_OK;
+}
+
 __global__ void k_halo_pack(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ v,
                             double *__restrict__ buf) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -137,6 +148,13 @@ __global__ void k_halo_unpack(int64_t n, const int64_t *__restrict__ idx, const 
                               double *__restrict__ v) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) v[idx[i]] = buf[i];
+}
+
+// entries that differ bit for bit (NaN-safe) between the vector and a snapshot
+__global__ void k_halo_compare(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ v,
+                               const double *__restrict__ snap, unsigned long long *__restrict__ bad) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n && __double_as_longlong(v[idx[i]]) != __double_as_longlong(snap[i])) atomicAdd(bad, 1ull);
 }
 
 struct HaloSpec {
@@ -210,7 +228,7 @@ static int allreduce_R(phx_system *s, phx_comm *c, int lo, int hi) {
 // Watchdog of the host synchronisations inside the distributed loop: a collective whose partner never arrives would
 // otherwise block in hipStreamSynchronize for ever.  PHX_DIST_TIMEOUT_S (default 300; 0 = wait without limit).
 static double dist_timeout_s() {
-  static const double t = getenv("PHX_DIST_TIMEOUT_S") ? atof(getenv("PHX_DIST_TIMEOUT_S")) : 300.0;
+  static const double t = getenv("PHX_DIST_TIMEOUT_S") ? atof(getenv("PHX_DIST_TIMEOUT_S")) : 300.0;   // (the Python side: dist_solver.dist_timeout_s)
   return t;
 }
 static int stream_sync_watchdog(hipStream_t st, const char *what) {
@@ -241,7 +259,8 @@ static int stream_sync_watchdog(hipStream_t st, const char *what) {
 // halo exchange + SpMV + all-reduce when the recurrences announce convergence, restart from it when it misses rtol);
 // stats[7]: 1 = every rank kept the box preconditioner.
 // PHX_DIST_OVERLAP=0: halo exchanges in series on the solver stream (default: overlapped with the rows of the SpMV
-// that read no halo entry, on the communicator's own stream).
+// that read no halo entry, on the communicator's own stream -- on a communicator whose phx_halo_selftest has seen the
+// overlapped exchange deliver the same entries as the exchange in series; without a self-test: in series).
 extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, const int *peers,
                                      const int64_t *counts, const int64_t *const *idx, double rtol,
                                      int64_t max_iter, double *x_out, int loc, double *stats) {
@@ -261,7 +280,7 @@ extern "C" int phx_solve_distributed(phx_system *s, phx_comm *c, int npeers, con
   }
   static const bool overlap_env = !(getenv("PHX_DIST_OVERLAP") && atoi(getenv("PHX_DIST_OVERLAP")) == 0);
   // a local matter: sends and receives pair up whatever stream each side issues them on
-  const bool overlap = overlap_env && c->nranks > 1 && npeers > 0 && c->cs != nullptr;
+  const bool overlap = overlap_env && c->overlap_ok && c->nranks > 1 && npeers > 0 && c->cs != nullptr;
   double *S = kr_scal(s);
   int rc = PHX_OK;
   auto body = [&]() -> int {
@@ -418,7 +437,50 @@ extern "C" int phx_halo_selftest(phx_system *s, phx_comm *c, int npeers, const i
     PHX_HIP(phx_malloc(&H.sbuf[p], sizeof(double) * (size_t)(H.nsend[p] > 0 ? H.nsend[p] : 1)));
     PHX_HIP(phx_malloc(&H.rbuf[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)));
   }
-  const int rc = halo_exchange(s, c, H, vec);
+  int rc = halo_exchange(s, c, H, vec);
+  if (rc == PHX_OK) rc = stream_sync_watchdog(s->mesh->stream, "halo self-test");
+  // ... and once more through the OVERLAPPED path: the received entries are cleared, exchanged again on the
+  // communicator's stream behind the two events, and must come back bit for bit.  Every rank makes both exchanges (they
+  // pair up), each decides for itself (`overlap_ok`: a local matter, see phx_solve_distributed).
+  if (rc == PHX_OK && c->nranks > 1 && npeers > 0 && c->cs != nullptr) {
+    hipStream_t st = s->mesh->stream;
+    double *snap[2] = {nullptr, nullptr};
+    unsigned long long *bad = nullptr;
+    bool ok = phx_malloc(&bad, sizeof(unsigned long long)) == hipSuccess;
+    for (int p = 0; p < npeers && ok; ++p) ok = phx_malloc(&snap[p], sizeof(double) * (size_t)(H.nrecv[p] > 0 ? H.nrecv[p] : 1)) == hipSuccess;
+    if (ok) {
+      (void)hipMemsetAsync(bad, 0, sizeof(unsigned long long), st);
+      for (int p = 0; p < npeers; ++p)
+        if (H.nrecv[p] > 0) {
+          const dim3 g((unsigned)phx_div_up(H.nrecv[p], 256)), b(256);
+          k_halo_pack<<<g, b, 0, st>>>(H.nrecv[p], H.recv_idx[p], vec, snap[p]);
+          (void)hipMemsetAsync(H.rbuf[p], 0xff, sizeof(double) * (size_t)H.nrecv[p], st);   // NaNs: a stale buffer shows
+          k_halo_unpack<<<g, b, 0, st>>>(H.nrecv[p], H.recv_idx[p], H.rbuf[p], vec);
+        }
+      rc = halo_begin(s, c, H, vec, true);
+      if (rc == PHX_OK) rc = halo_end(s, c, H, vec, true);
+      for (int p = 0; p < npeers && rc == PHX_OK; ++p)
+        if (H.nrecv[p] > 0)
+          k_halo_compare<<<dim3((unsigned)phx_div_up(H.nrecv[p], 256)), dim3(256), 0, st>>>(H.nrecv[p], H.recv_idx[p], vec, snap[p], bad);
+      unsigned long long hbad = 1;
+      if (rc == PHX_OK) rc = hipMemcpyAsync(&hbad, bad, sizeof(hbad), hipMemcpyDeviceToHost, st) == hipSuccess ? PHX_OK : PHX_ERR_HIP;
+      if (rc == PHX_OK) rc = stream_sync_watchdog(st, "halo self-test (overlapped exchange)");
+      if (rc == PHX_OK && c->cs) rc = stream_sync_watchdog(c->cs, "halo self-test (communication stream)");
+      c->overlap_ok = rc == PHX_OK && hbad == 0;
+      if (rc == PHX_OK && hbad != 0) {
+        // the caller checks the entries of the exchange in series: put them back
+        for (int p = 0; p < npeers; ++p)
+          if (H.nrecv[p] > 0)
+            k_halo_unpack<<<dim3((unsigned)phx_div_up(H.nrecv[p], 256)), dim3(256), 0, st>>>(H.nrecv[p], H.recv_idx[p], snap[p], vec);
+        (void)hipStreamSynchronize(st);
+      }
+      if (rc == PHX_OK && hbad != 0)
+        fprintf(stderr, "phifem_hip: rank %d: the overlapped halo exchange delivered %llu entries that differ from the exchange in "
+                        "series -- halo exchanges stay on the solver stream\n", c->rank, hbad);
+    }
+    (void)phx_free(bad);
+    for (int p = 0; p < npeers; ++p) (void)phx_free(snap[p]);
+  }
   (void)hipStreamSynchronize(s->mesh->stream);
   for (int p = 0; p < npeers; ++p) { (void)phx_free(H.sbuf[p]); (void)phx_free(H.rbuf[p]); }
   return rc;

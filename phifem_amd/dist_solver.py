@@ -430,6 +430,7 @@ class DistributedKrylov:
         self.native = None   # None: not tried yet, True/False afterwards
         self.path = "python"
         self.library = None  # file the library's RCCL entry points are bound to (native loop)
+        self.overlap = False  # halo exchanges overlapped with the SpMV (the self-test has seen that path deliver)
 
     def agree_on_exterior(self):
         """`len(exterior_cells) == 0` (mesh_scripts.py:469) must be decided over ALL slabs."""
@@ -543,6 +544,10 @@ class DistributedKrylov:
                 self._init_native()
                 if self.native:
                     self.native = self._all_ok(self._selftest(backend, ds, self._halo_arrays(ds)))
+                if self.native:
+                    ov = C.c_int(0)
+                    if L.lib.phx_comm_overlap(self.comm, C.byref(ov)) == 0:
+                        self.overlap = bool(ov.value)
         if not self.native:
             self.path = "python"
             return ds.solve(out, profile_spmv=profile_spmv)

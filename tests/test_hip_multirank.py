@@ -187,7 +187,7 @@ def _worker_native(rank, world, n, nxy, port, outdir, native, exact=True):
         np.savez(os.path.join(outdir, f"r{rank}.npz"), gid=gid[owned], u=w[:nv][owned],
                  p=w[nv:][owned], it=res["iterations"], relres=res["relres"],
                  n_owned=res["n_active_owned"], path=prob.dk.path, converged=res["converged"],
-                 precond=res["precond"], exact=bool(res.get("precond_exact", False)))
+                 precond=res["precond"], exact=bool(res.get("precond_exact", False)), overlap=bool(prob.dk.overlap))
     finally:
         dist.destroy_process_group()
 
@@ -241,6 +241,9 @@ def test_native_loop_multi_rank_matches_single_mesh(world, native, exact, tmp_pa
     mesh, info, wref, st = _single_mesh(n, world)
     u, p, rows = _collect(tmp_path, world, mesh.nv)
     assert all(str(d["path"]) == ("native" if native else "python") for d in rows), "the wrong loop ran"
+    if native:
+        # the overlapped exchange passed the self-test of every communicator, so the loop ran with the overlap on
+        assert all(bool(d["overlap"]) for d in rows), "the overlapped halo exchange did not pass its self-test"
     assert all(bool(d["converged"]) and d["relres"] <= 1e-11 for d in rows)
     assert len({int(d["it"]) for d in rows}) == 1, "ranks stopped at different iterations"
     assert all(str(d["precond"]) == "box-dst" for d in rows)
