@@ -454,7 +454,23 @@ def main(argv=None):
     # (several), so that the driver's scaling curve compares like with like.
     extra = None
     if default_workload and not args.no_configs4_extra:
+        # The headline must not depend on the extra measurement: if it does not return within its deadline (a collective of
+        # the second problem that never completes), rank 0 prints the line it has -- with the reason under `configs4_slab` --
+        # and every rank leaves; nothing is re-exec'd.
+        import threading
+        deadline = float(os.environ.get("BENCH_CONFIGS4_DEADLINE_S", "300"))
+        done = threading.Event()
+
+        def give_up():
+            if done.wait(deadline):
+                return
+            if rank == 0:
+                out["configs4_slab"] = {"error": f"not finished within {deadline:g} s (BENCH_CONFIGS4_DEADLINE_S); headline unaffected"}
+                print(json.dumps(out), flush=True)
+            os._exit(rc)
+        threading.Thread(target=give_up, daemon=True).start()
         extra = configs4_extra(args, prob, world, rank, local_rank, dev, barrier, dist, torch, D)
+        done.set()
     if rank == 0:
         if extra is not None:
             out["configs4_slab"] = extra

@@ -263,21 +263,21 @@ int phx_system_build_structured_p2(phx_system *s, const phx_slot_view &sv, int32
 }
 
 // y_r = sum_o coef[class(r)][o] x[r + off(o)] over the runs; DOTS as k_spmv_sell.
-// One wavefront per run, 64 rows per trip.  Per trip and dz plane the neighbouring lines (64 + 4 entries each) are
-// staged in LDS with coalesced loads and the lanes read their dx = -2 .. 2 neighbours from there.  Both parity classes
-// of the line are accumulated by every lane with SCALAR coefficient operands (dense 5-entry rows per neighbouring
-// line, lines without a non-zero coefficient skipped) and the lane keeps the sum of its own parity: a per-lane
-// coefficient select turned the coefficient into a dependent vector load per term (measured 1.0 ms per product for
-// 1.9e7 rows at 256^3, 9 ms at 512^3 -- a latency chain of ~80 loads per trip).
+// One wavefront per run, 128 rows per trip: a lane owns TWO consecutive rows, one of each parity class of the line, so
+// every coefficient is a wave-uniform SCALAR operand and each class is computed once (round 3 had every lane accumulate
+// both classes of its row and keep one: twice the multiply-adds; a per-lane coefficient select had turned the
+// coefficient into a dependent vector load per term before that).  Per trip and dz plane the neighbouring lines (128 + 4
+// entries each) are staged in LDS with coalesced loads; the lane's two rows need the SIX entries 2 lane .. 2 lane + 5 of
+// a line: three 16-byte LDS reads for ten terms (round 3: five 8-byte reads for the five terms of one row).
 template <int DOTS>
 __global__ void __launch_bounds__(256)
 k_spmv_p2s(int64_t nrun, const int32_t *__restrict__ runs, const double *__restrict__ tabE,
            const double *__restrict__ tabO, const unsigned *__restrict__ linemask, const double *__restrict__ x,
            double *__restrict__ y, const double *__restrict__ d0, double *__restrict__ out0, double *__restrict__ out1,
            DotPart part) {
-  __shared__ double xs_all[4][5][72];
+  __shared__ double2 xs_all[4][5][68];   // 132 doubles of a line used
   const int lane = threadIdx.x & 63;
-  double (*xs)[72] = xs_all[threadIdx.x >> 6];
+  double2 (*xs)[68] = xs_all[threadIdx.x >> 6];
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double p0 = 0.0, p1 = 0.0;
   for (int64_t w = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6)); w < nrun; w += nwaves) {
@@ -285,57 +285,76 @@ k_spmv_p2s(int64_t nrun, const int32_t *__restrict__ runs, const double *__restr
     const int first = rec[0], len = rec[1], bits = rec[2];
     const int bc = bits & 3, a0 = bits >> 2;
     const unsigned lm = linemask[bc];
-    const double *cE = tabE + (size_t)bc * 125, *cO = tabO + (size_t)bc * 125;
-    for (int base = 0; base < len; base += 64) {
-      const int i = base + lane;
-      const bool on = i < len;
-      const bool odd = ((a0 + i) & 1) != 0;
+    // class of the lane's first / second row: the run starts with class a0 and a trip starts at an even offset
+    const double *cA = (a0 ? tabO : tabE) + (size_t)bc * 125, *cB = (a0 ? tabE : tabO) + (size_t)bc * 125;
+    for (int base = 0; base < len; base += 128) {
+      const int i = base + 2 * lane;
+      const bool onA = i < len, onB = i + 1 < len;
       const int64_t r0 = (int64_t)first + base;
       // entries i - 2 .. i + 2 of every neighbouring line exist for the rows of the run (their whole 5 x 5 x 5
-      // neighbourhood is C0): lane j stages entry base + j - 2, lanes 0..3 also base + 62 + j
-      const bool ok0 = base + lane - 2 < len + 2, ok1 = lane < 4 && base + 62 + lane < len + 2;
-      double ae = 0.0, ao = 0.0;
-#pragma unroll 1
-      for (int dz = 0; dz < 5; ++dz) {
-        const unsigned pm = (lm >> (5 * dz)) & 31u;   // lines of this plane with a coefficient (wave-uniform)
-        if (pm == 0u) continue;
-        double v0[5], v1[5];
+      // neighbourhood is C0)
+      // (entry e of a staged line = position base - 2 + e of the run's coordinates; the lane loads entries lane, 64 + lane
+      // -- contiguous across the wavefront -- and lanes 0..3 entries 128 + lane)
+      const bool ok0 = base - 2 + lane < len + 2, ok1 = base + 62 + lane < len + 2, ok2 = lane < 4 && base + 126 + lane < len + 2;
+      double aA = 0.0, aB = 0.0;
+      double v0[5], vh[5];
+      double v1[5];
+      // the loads of plane dz into v0 / vh / v1 (lines without a coefficient skipped: wave-uniform)
+      auto load_plane = [&](int dz) {
+        const unsigned pm = (lm >> (5 * dz)) & 31u;
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy) {
-          v0[dy] = 0.0; v1[dy] = 0.0;
+          v0[dy] = 0.0; vh[dy] = 0.0; v1[dy] = 0.0;
           if ((pm >> dy) & 1u) {
-            const int64_t rl = r0 + rec[3 + dy + 5 * dz] - 2;
-            if (ok0) v0[dy] = x[rl + lane];
-            if (ok1) v1[dy] = x[rl + 64 + lane];
+            const double *xl = x + (r0 + rec[3 + dy + 5 * dz] - 2);
+            if (ok0) v0[dy] = xl[lane];
+            if (ok1) vh[dy] = xl[64 + lane];
+            if (ok2) v1[dy] = xl[128 + lane];
           }
         }
+      };
+      // planes with a coefficient, in order; the loads of the next one are in flight while this one is multiplied
+      int dz = 0;
+      while (dz < 5 && ((lm >> (5 * dz)) & 31u) == 0u) ++dz;
+      if (dz < 5) load_plane(dz);
+#pragma unroll 1
+      while (dz < 5) {
+        const unsigned pm = (lm >> (5 * dz)) & 31u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();      // the previous plane has been read
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy) {
-          xs[dy][lane] = v0[dy];
-          if (lane < 4) xs[dy][64 + lane] = v1[dy];
+          double *xd = reinterpret_cast<double *>(&xs[dy][0]);
+          xd[lane] = v0[dy];
+          xd[64 + lane] = vh[dy];
+          if (lane < 4) xd[128 + lane] = v1[dy];
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        int nz = dz + 1;
+        while (nz < 5 && ((lm >> (5 * nz)) & 31u) == 0u) ++nz;
+        if (nz < 5) load_plane(nz);
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy) {
           if ((pm >> dy) & 1u) {
-            const double *ce = cE + (5 * dz + dy) * 5, *co = cO + (5 * dz + dy) * 5;
-#pragma unroll
-            for (int dx = 0; dx < 5; ++dx) {
-              const double xv = xs[dy][lane + dx];
-              ae = __builtin_fma(ce[dx], xv, ae);
-              ao = __builtin_fma(co[dx], xv, ao);
-            }
+            const double *ca = cA + (5 * dz + dy) * 5, *cb = cB + (5 * dz + dy) * 5;
+            const double2 q0 = xs[dy][lane], q1 = xs[dy][lane + 1], q2 = xs[dy][lane + 2];
+            aA = __builtin_fma(ca[0], q0.x, aA); aA = __builtin_fma(ca[1], q0.y, aA); aA = __builtin_fma(ca[2], q1.x, aA);
+            aA = __builtin_fma(ca[3], q1.y, aA); aA = __builtin_fma(ca[4], q2.x, aA);
+            aB = __builtin_fma(cb[0], q0.y, aB); aB = __builtin_fma(cb[1], q1.x, aB); aB = __builtin_fma(cb[2], q1.y, aB);
+            aB = __builtin_fma(cb[3], q2.x, aB); aB = __builtin_fma(cb[4], q2.y, aB);
           }
         }
+        dz = nz;
       }
-      if (on) {
-        const double acc = odd ? ao : ae;
-        const int64_t r = r0 + lane;
-        y[r] = acc;
-        if (DOTS > 0) { p0 = __builtin_fma(acc, d0[r], p0); if (DOTS > 1) p1 = __builtin_fma(acc, acc, p1); }
+      const int64_t r = r0 + 2 * lane;
+      if (onA) {
+        y[r] = aA;
+        if (DOTS > 0) { p0 = __builtin_fma(aA, d0[r], p0); if (DOTS > 1) p1 = __builtin_fma(aA, aA, p1); }
+      }
+      if (onB) {
+        y[r + 1] = aB;
+        if (DOTS > 0) { p0 = __builtin_fma(aB, d0[r + 1], p0); if (DOTS > 1) p1 = __builtin_fma(aB, aB, p1); }
       }
     }
   }
