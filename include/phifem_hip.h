@@ -175,9 +175,8 @@ enum phx_option {
                                Galerkin problem on trilinear functions of spacing H = value * h per displacement
                                block, added to the vertex-block Jacobi (the iteration count then follows H / h
                                instead of growing with the box).  -1 (default): on from 80 cubes per axis with
-                               H ~ n / 8 (H = 16 h beyond 128 cubes); 0: off; >= 5: this ratio.  Needs
-                               librocsolver for the dense inverse of the coarse matrix (loaded on first use;
-                               without it the solve keeps the vertex blocks alone)                              */
+                               H ~ n / 8 (H = 16 h beyond 128 cubes); 0: off; >= 5: this ratio.  The dense inverse
+                               of the coarse matrix is the library's own (phx_dense_inverse)                   */
   PHX_OPT_STENCIL_PLANE_ROWS = 11, /* structured P1 systems on 3-D boxes: from this many interior rows per lattice
                                plane on (default 32768: three planes of the vector no longer fit an XCD's L2 next to the
                                streams) the stencil blocks of the SpMV walk the k-th eighth of EVERY plane on XCD k
@@ -199,6 +198,11 @@ int phx_box_poisson_solve(int device, const int *L, const double *h, int f32, do
 /* Timing aid: average microseconds of the x, y and z (forward + divide + inverse) transform passes on an
  * (L0-1) x (L1-1) x (L2-1) lattice (tools/dst_bench.py). */
 int phx_box_dst_bench(int device, const int *L, int f32, int reps, double *out_us3);
+/* a_host (n x n, row-major, n <= 20000) := its inverse: the library's own dense inverse (blocked Gauss-Jordan elimination
+ * with partial pivoting, phx_dense.inc.hip) that the elasticity coarse correction applies to its Galerkin matrix -- exposed
+ * for tests.  *singular = 1: a pivot column vanished (a_host is then undefined).  The reference has no counterpart (MUMPS
+ * factorises the whole system, demo/interface-elasticity/main.py:283-289). */
+int phx_dense_inverse(int device, int64_t n, double *a_host, int *singular);
 /* Mean elapsed time of an empty HIP event pair on the mesh stream: the cost the bracketing of
  * PHX_OPT_PROFILE_SPMV adds to each timed launch (measurement aid of bench.py). */
 int phx_event_pair_overhead(phx_mesh *m, double *seconds);

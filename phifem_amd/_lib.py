@@ -80,6 +80,7 @@ SIGNATURES = {
     "phx_comm_unique_id": ([_vp], _i),
     "phx_comm_create": ([_i, _i, _vp, _i, C.POINTER(_vp)], _i),
     "phx_comm_destroy": ([_vp], _i),
+    "phx_dense_inverse": ([_i, C.c_int64, _vp, C.POINTER(_i)], _i),
     "phx_comm_library": ([C.c_char_p, C.c_int64], _i),
     "phx_comm_overlap": ([_vp, C.POINTER(_i)], _i),
     "phx_solve_distributed": ([_vp, _vp, _i, _vp, _vp, _vp, _d, _i64, _vp, _i, _pd], _i),

@@ -11,15 +11,13 @@
 // n = 48 with H = 8h, 140 with H = 16h: the count follows H / h, not n.
 //   * Ac is found by PROBING: coarse functions of one block whose nodes are 3 apart in every axis have disjoint
 //     images under A, so 27 colours x 2 D blocks SpMVs with the solver's own operator give every column;
-//   * Ac is dense and small (<= ~17 000: the ratio is chosen for that), inverted once per system by rocSOLVER
-//     (getrf + getri, loaded with dlopen: a plain dense LAPACK call, not a kernel of the path) and applied as a
+//   * Ac is dense and small (<= ~17 000: the ratio is chosen for that), inverted once per system by the library's own
+//     blocked Gauss-Jordan elimination (phx_dense.inc.hip; rounds 2-3: rocSOLVER through dlopen) and applied as a
 //     matrix-vector product;
 //   * R^T and R run as three 1-D passes over lattice lines (no atomics: bit-reproducible).
 // Partitioned boxes (native RCCL loop, phx_dist.inc.hip): the coarse lattice is the one of the GLOBAL box; every rank
 // restricts its owned rows, the coarse right-hand side is all-reduced (a few thousand doubles per application), every
 // rank holds Ac^-1 (its own rows' share of Ac summed over the ranks once per system) and prolongs onto its owned rows.
-#include <dlfcn.h>
-
 #include <functional>
 
 struct phx_coarse {
@@ -46,38 +44,6 @@ static void coarse_free(phx_coarse *c) {
   delete c;
 }
 void phx_coarse_destroy(phx_coarse *c) { coarse_free(c); }
-
-// ---- rocSOLVER, loaded on first use ---------------------------------------------------------------------------
-namespace {
-struct RocSolver {
-  void *lib_b = nullptr, *lib_s = nullptr, *handle = nullptr;
-  int (*create)(void **) = nullptr;
-  int (*set_stream)(void *, hipStream_t) = nullptr;
-  int (*getrf)(void *, int, int, double *, int, int *, int *) = nullptr;
-  int (*getri)(void *, int, double *, int, int *, int *) = nullptr;
-  bool tried = false, ok = false;
-};
-RocSolver &rocsolver() {
-  static RocSolver r;
-  if (r.tried) return r;
-  r.tried = true;
-  r.lib_b = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!r.lib_b) r.lib_b = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-  r.lib_s = dlopen("librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
-  if (!r.lib_s) r.lib_s = dlopen("/opt/rocm/lib/librocsolver.so.0", RTLD_NOW | RTLD_GLOBAL);
-  if (!r.lib_b || !r.lib_s) return r;
-  r.create = (int (*)(void **))dlsym(r.lib_b, "rocblas_create_handle");
-  r.set_stream = (int (*)(void *, hipStream_t))dlsym(r.lib_b, "rocblas_set_stream");
-  r.getrf = (int (*)(void *, int, int, double *, int, int *, int *))dlsym(r.lib_s, "rocsolver_dgetrf");
-  r.getri = (int (*)(void *, int, double *, int, int *, int *))dlsym(r.lib_s, "rocsolver_dgetri");
-  if (!r.create || !r.set_stream || !r.getrf || !r.getri) return r;
-  if (r.create(&r.handle) != 0) return r;
-  // no atomics in the library's GEMMs: the inverse, and with it the iteration count, is the same on every run
-  if (auto atomics = (int (*)(void *, int))dlsym(r.lib_b, "rocblas_set_atomics_mode")) (void)atomics(r.handle, 0 /* rocblas_atomics_not_allowed */);
-  r.ok = true;
-  return r;
-}
-}  // namespace
 
 // ---- set-up kernels ---------------------------------------------------------------------------------------------
 // eligible fine DoFs: active rows of the displacement blocks that are not Dirichlet rows (a constrained u_in row is the
@@ -483,19 +449,6 @@ static int coarse_build(phx_system *s, int nblk, phx_coarse **out, const CcReduc
   if (nmax < 2 * ratio) return PHX_OK;   // nothing coarser than the mesh itself
   // from here on a partitioned box must reach the veto reduction on every rank
   bool veto = false;
-  RocSolver &rs = rocsolver();
-  if (!rs.ok) {
-    static bool warned = false;
-    if (!warned) fprintf(stderr, "phifem_hip: librocsolver / librocblas not loadable: elasticity solves run without the coarse correction\n");
-    warned = true;
-    // asked for by value (PHX_OPT_EL_COARSE >= 5) on one rank: an error, not a silently different preconditioner.  The
-    // automatic choice (-1) degrades to the vertex blocks with the line above; a partitioned box votes (all ranks alike).
-    PHX_REQUIRE(!(req > 0 && !reduce), PHX_ERR_NOT_IMPLEMENTED,
-                "PHX_OPT_EL_COARSE = %d asks for the coarse correction, but librocsolver / librocblas (the dense inverse of the "
-                "coarse matrix) cannot be loaded", req);
-    if (!reduce) return PHX_OK;
-    veto = true;
-  }
   phx_coarse *c = new phx_coarse();
   auto fail = [&](int code) { coarse_free(c); return code; };
   c->d = d; c->nblk_u = 2 * d; c->ratio = ratio; c->dist = reduce != nullptr;
@@ -623,19 +576,17 @@ static int coarse_build(phx_system *s, int nblk, phx_coarse **out, const CcReduc
   if (rc == PHX_OK && hipStreamSynchronize(st) != hipSuccess) rc = PHX_ERR_HIP;
   drop_scratch();
   if (rc != PHX_OK) return fail(rc);
-  // ---- dense inverse (every rank inverts the same matrix)
-  int *ipiv = nullptr, *info = nullptr, hinfo[2] = {0, 0};
-  if (phx_malloc(&ipiv, sizeof(int) * (size_t)nc) != hipSuccess || phx_malloc(&info, sizeof(int) * 2) != hipSuccess) {
-    (void)phx_free(ipiv); (void)phx_free(info);
-    return fail(PHX_ERR_HIP);
+  // ---- dense inverse (every rank inverts the same matrix): the library's own blocked Gauss-Jordan, phx_dense.inc.hip
+  int singular = 0;
+  const int rci = dense_inverse_inplace(c->Ainv, nc, st, &singular);
+  if (rci != PHX_OK) return fail(rci);
+  if (singular) {
+    // singular coarse matrix (the same on every rank): the vertex blocks alone -- said, not silent
+    fprintf(stderr, "phifem_hip: the Galerkin coarse matrix of the elasticity correction (%d x %d) is singular to working precision: "
+                    "the solve keeps the vertex blocks alone\n", nc, nc);
+    coarse_free(c);
+    return PHX_OK;
   }
-  bool good = rs.set_stream(rs.handle, st) == 0;
-  good = good && rs.getrf(rs.handle, nc, nc, c->Ainv, nc, ipiv, info) == 0;
-  good = good && rs.getri(rs.handle, nc, c->Ainv, nc, ipiv, info + 1) == 0;
-  good = good && hipMemcpyAsync(hinfo, info, sizeof(hinfo), hipMemcpyDeviceToHost, st) == hipSuccess;
-  good = good && hipStreamSynchronize(st) == hipSuccess;
-  (void)phx_free(ipiv); (void)phx_free(info);
-  if (!good || hinfo[0] != 0 || hinfo[1] != 0) { coarse_free(c); return PHX_OK; }   // singular coarse matrix (the same on every rank): the vertex blocks alone
   *out = c;
   return PHX_OK;
 }

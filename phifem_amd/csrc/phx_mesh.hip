@@ -451,7 +451,13 @@ static bool detect_lattice(int gdim, int nvpc, int64_t nv, const double *coords,
     for (int a = 0; a < gdim; ++a) {
       const double q = (coords[v * gdim + a] - lo[a]) / h[a];
       const int64_t i = (int64_t)llround(q);
-      if (fabs(q - (double)i) > 1e-6 || i < 0 || i > n[a]) return false;
+      if (i < 0 || i > n[a]) return false;
+      // the system is assembled on a GENERATED box (x = lo + (hi - lo) (i / n)): the caller's vertex has to sit there to
+      // within a few ulps of the box size, or the mesh keeps the generic path (1e-6 h let a visibly perturbed
+      // mesh be replaced by the uniform one)
+      const double gen = lo[a] + (hi_out[a] - lo[a]) * ((double)i / (double)n[a]);
+      const double scale = std::max(std::max(fabs(lo[a]), fabs(hi_out[a])), hi_out[a] - lo[a]);
+      if (fabs(coords[v * gdim + a] - gen) > 16.0 * 2.220446049250313e-16 * scale) return false;
       id += i * (a == 0 ? 1 : (a == 1 ? s1 : s2));
     }
     if (lat2v[(size_t)id] != -1) return false;

@@ -1739,6 +1739,7 @@ static int prof_collect(phx_system *s, double *avg_s, int *count, int c = 0) {
 
 #include "phx_precond.inc.hip"
 #include "phx_blockjac.inc.hip"
+#include "phx_dense.inc.hip"
 #include "phx_coarse.inc.hip"
 void phx_blockjac_destroy(phx_blockjac *b) { blockjac_free(b); }
 

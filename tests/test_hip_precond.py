@@ -203,3 +203,12 @@ def test_caller_supplied_lattice_mesh_gets_the_box_preconditioner(P, d, n):
     # vertex perm[i] of the box is vertex i of the shuffled mesh
     assert np.abs(w_arr[:nv] - w_box[:nv][perm]).max() <= 1e-7 * np.abs(w_box).max()
     assert np.abs(w_arr[nv:] - w_box[nv:][perm]).max() <= 1e-7 * np.abs(w_box).max()
+    # a mesh whose vertices are NOT on the lattice (one vertex moved by 1e-7 h: far above round-off, far below
+    # the old 1e-6 h snap) is not replaced by the uniform box -- it keeps the generic path (every row stored) and its own
+    # geometry; the solution moves by about that much
+    xp = xs.copy()
+    xp[xs.shape[0] // 2, 0] += 1e-7 * (3.0 / n)
+    mesh_p = P.Mesh.from_arrays("tetrahedron" if d == 3 else "triangle", xp, cs)
+    w_p, st_p = run(mesh_p, xp)
+    assert st_p["stencil_rows"] == 0
+    assert np.abs(w_p - w_arr).max() <= 1e-5 * np.abs(w_arr).max()
