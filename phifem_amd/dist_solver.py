@@ -529,7 +529,7 @@ class DistributedKrylov:
         backend = HipBackend(prob.solver, self.dev, blocks=getattr(prob, "n_blocks", None))
         backend.use_current_stream()
         L.check(L.lib.phx_set_option(prob.mesh._h, L.OPT_PROFILE_SPMV, int(profile_spmv)))
-        plane = (prob.nxy + 1) * (prob.nxy + 1)
+        plane = getattr(prob, "plane_vertices", None) or (prob.nxy + 1) * (prob.nxy + 1)
         ds = DistributedSolver(backend, self.dist, self.torch, prob.rank, prob.world, plane,
                                lay["k0"], lay["P0"], lay["P1"], lay["k1"] - lay["k0"] + 1,
                                rtol=prob.rtol, max_iter=prob.max_iter)

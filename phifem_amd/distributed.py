@@ -125,6 +125,92 @@ class SlabProblem:
         }
 
 
+def detect_kuhn_lattice(x, rtol=64 * 2.220446049250313e-16):
+    """Tensor lattice behind the vertices of a caller-supplied box mesh (any vertex order): (lo[3], hi[3], n[3], lat) with
+    lat[v] = i + (nx + 1) (j + (ny + 1) k), or a ValueError naming what is not a lattice.  Host side, numpy."""
+    x = np.asarray(x, dtype=np.float64)
+    nv, gdim = x.shape
+    if gdim != 3:
+        raise ValueError("a 3-D box is partitioned into z-slabs")
+    lo, hi, n, idx = [], [], [], []
+    for a in range(3):
+        vals = np.unique(x[:, a])
+        ext = vals[-1] - vals[0]
+        scale = max(abs(vals[0]), abs(vals[-1]), ext)
+        # coordinates equal up to a few ulps of the box size are one lattice plane
+        keep = np.concatenate(([True], np.diff(vals) > rtol * scale))
+        planes = vals[keep]
+        na = planes.size - 1
+        if na < 1:
+            raise ValueError(f"axis {a}: the vertices lie in one plane")
+        q = (x[:, a] - planes[0]) / ext * na
+        i = np.rint(q).astype(np.int64)
+        gen = planes[0] + ext * (i / na)
+        if np.any(np.abs(x[:, a] - gen) > rtol * scale):
+            raise ValueError(f"axis {a}: the vertices are not on a uniform lattice (a graded or perturbed mesh cannot be "
+                             f"served by generated slabs)")
+        lo.append(planes[0]); hi.append(planes[-1]); n.append(na); idx.append(i)
+    lat = idx[0] + (n[0] + 1) * (idx[1] + (n[1] + 1) * idx[2])
+    if nv != (n[0] + 1) * (n[1] + 1) * (n[2] + 1) or np.unique(lat).size != nv:
+        raise ValueError("the vertices do not fill a tensor lattice")
+    return np.array(lo), np.array(hi), np.array(n, dtype=np.int64), lat
+
+
+class ArraySlabProblem(SlabProblem):
+    """A caller-supplied Kuhn box -- vertices `x` in ANY order, what dolfinx's create_box hands over --
+    partitioned into z-slabs over the ranks (missing item 4; the reference is serial,
+    src/phifem/mesh_scripts.py:264 "TODO ... parallel computing").  Every rank is given the WHOLE vertex array and the nodal
+    data in the caller's numbering (as a dolfinx caller that read one mesh file has them), recognises the lattice,
+    generates its slab + ghost layers on the device and runs the slab pipeline (tag, assemble redundantly, solve with halo
+    exchange + slab-exact preconditioner); `solution()` hands the owned part back in the caller's vertex numbering.
+    Only the lattice has to be uniform: a mesh that is not a tensor lattice raises ValueError (no silent fallback)."""
+
+    def __init__(self, x, phi, f, u_D, rank=0, world=1, device=0, rtol=1e-8, max_iter=20000):
+        self.lo_box, self.hi_box, self.n_box, self.lat = detect_kuhn_lattice(x)
+        nz = int(self.n_box[2])
+        if nz % world:
+            raise ValueError(f"{nz} cube layers along z do not split into {world} equal slabs")
+        super().__init__(nz // world, rank=rank, world=world, device=device, rtol=rtol, max_iter=max_iter)
+        self.nxy = int(self.n_box[0])
+        self.plane_vertices = int((self.n_box[0] + 1) * (self.n_box[1] + 1))
+        self._phi, self._f, self._uD = (np.asarray(a, dtype=np.float64) for a in (phi, f, u_D))
+        # caller vertex of a global lattice point
+        self.lat2v = np.empty(self.lat.size, dtype=np.int64)
+        self.lat2v[self.lat] = np.arange(self.lat.size)
+
+    def setup(self):
+        import torch
+        lay, w = self.lay, self.world
+        nx, ny = int(self.n_box[0]), int(self.n_box[1])
+        self.mesh = create_box(self.lo_box, self.hi_box, [nx, ny, lay["k1"] - lay["k0"]], device=self.device,
+                               offset=[0, 0, lay["k0"]], n_global=[nx, ny, lay["nz"]])
+        L.check(L.lib.phx_mesh_set_slab_faces(self.mesh._h, 1 if lay["k0"] > 0 else 0, 1 if lay["k1"] < lay["nz"] else 0))
+        if w > 1:
+            L.check(L.lib.phx_set_option(self.mesh._h, L.OPT_ALLOW_EMPTY, 1))
+        dev = torch.device("cuda", self.device)
+        # the slab's vertices are lattice points k0 .. k1 of the global lattice, in lattice order
+        g0 = lay["k0"] * self.plane_vertices
+        self.caller_vertex = self.lat2v[g0:g0 + self.mesh.nv]
+        take = torch.from_numpy(self.caller_vertex).to(dev)
+        self.phi = torch.from_numpy(self._phi).to(dev)[take].contiguous()
+        self.f = torch.from_numpy(self._f).to(dev)[take].contiguous()
+        self.u_ex = torch.from_numpy(self._uD).to(dev)[take].contiguous()
+        self.out = torch.empty(2 * self.mesh.nv, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        self.solver = PhiFEMSolver(self.mesh)
+        if w > 1:
+            from .dist_solver import DistributedKrylov
+            self.dk = DistributedKrylov(self)
+
+    def solution(self):
+        """(caller vertex ids, u, p) of the vertices this rank OWNS (the planes P0 .. P1 of its slab)."""
+        lay, nv = self.lay, self.mesh.nv
+        w = self.out.cpu().numpy()
+        plane = np.arange(nv) // self.plane_vertices + lay["k0"]
+        own = (plane >= lay["P0"]) & (plane < lay["P1"])
+        return self.caller_vertex[own], w[:nv][own], w[nv:][own]
+
+
 class ElasticitySlabProblem(SlabProblem):
     """BASELINE configs[3]: 3-D interface elasticity (5-field mixed phi-FEM, P1 vector fields,
     E_in = 1, E_out = 1e-3, nu = 0.3, phi = 1 - r^2: demo/interface-elasticity/data.py:14-22,39-40)

@@ -187,7 +187,8 @@ def _worker_native(rank, world, n, nxy, port, outdir, native, exact=True):
         np.savez(os.path.join(outdir, f"r{rank}.npz"), gid=gid[owned], u=w[:nv][owned],
                  p=w[nv:][owned], it=res["iterations"], relres=res["relres"],
                  n_owned=res["n_active_owned"], path=prob.dk.path, converged=res["converged"],
-                 precond=res["precond"], exact=bool(res.get("precond_exact", False)), overlap=bool(prob.dk.overlap))
+                 precond=res["precond"], exact=bool(res.get("precond_exact", False)), overlap=bool(prob.dk.overlap),
+                 library=str(prob.dk.library))
     finally:
         dist.destroy_process_group()
 
@@ -244,6 +245,8 @@ def test_native_loop_multi_rank_matches_single_mesh(world, native, exact, tmp_pa
     if native:
         # the overlapped exchange passed the self-test of every communicator, so the loop ran with the overlap on
         assert all(bool(d["overlap"]) for d in rows), "the overlapped halo exchange did not pass its self-test"
+        # phx_comm_library names the file the collective entry points really come from (here: the stand-in)
+        assert all(str(d["library"]).endswith("libfake_rccl.so") for d in rows), [str(d["library"]) for d in rows]
     assert all(bool(d["converged"]) and d["relres"] <= 1e-11 for d in rows)
     assert len({int(d["it"]) for d in rows}) == 1, "ranks stopped at different iterations"
     assert all(str(d["precond"]) == "box-dst" for d in rows)
@@ -354,3 +357,90 @@ def test_bench_rccl_on_one_device_fails_loudly():
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert "need 2 GPUs" in r.stderr
+
+
+# ---------------------------------------------------------------------------------------------------
+# A CALLER-SUPPLIED Kuhn box, partitioned (ArraySlabProblem): every rank gets the whole vertex array in the caller's
+# (here: shuffled) numbering, recognises the lattice, works on its own slab and hands its owned part back in the caller's
+# numbering.  Cross-section 10 x 14 (not square), box not centred.
+# ---------------------------------------------------------------------------------------------------
+def _caller_box():
+    from oracle import meshgen
+    lo, hi, n = [-1.4, -1.6, -1.5], [1.6, 1.5, 1.7], [10, 14, 12]
+    x, _ = meshgen.create_box(lo, hi, n)
+    perm = np.random.default_rng(11).permutation(x.shape[0])
+    xc = np.ascontiguousarray(x[perm])                      # caller numbering: a shuffle of the lattice order
+    phi = (xc[:, 0] / 1.1) ** 2 + (xc[:, 1] / 0.9) ** 2 + (xc[:, 2] / 1.2) ** 2 - 1.0
+    uD = np.sin(xc[:, 0]) * np.cos(xc[:, 1]) + 0.3 * xc[:, 2]
+    f = 2.0 * np.sin(xc[:, 0]) * np.cos(xc[:, 1])
+    return lo, hi, n, perm, xc, phi, f, uD
+
+
+def _worker_arrays(rank, world, port, outdir, native):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PHIFEM_NATIVE_LOOP"] = "1" if native else "0"
+    os.environ["PHX_RCCL_LIB"] = _FAKE
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from phifem_amd.distributed import ArraySlabProblem
+        _, _, _, _, xc, phi, f, uD = _caller_box()
+        prob = ArraySlabProblem(xc, phi, f, uD, rank=rank, world=world, device=0, rtol=1e-11)
+        prob.setup()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = prob.step()
+        v, u, p = prob.solution()
+        np.savez(os.path.join(outdir, f"a{rank}.npz"), v=v, u=u, p=p, relres=res["relres"],
+                 n_owned=res["n_active_owned"], path=prob.dk.path)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,native", [(2, True), (3, False)])
+def test_caller_supplied_box_partitioned_matches_single_mesh(world, native, tmp_path):
+    import torch.multiprocessing as mp
+    import phifem_amd as P
+    from phifem_amd.mesh_scripts import NodalFunction
+    lo, hi, n, perm, xc, phi, f, uD = _caller_box()
+    mp.spawn(_worker_arrays, args=(world, _free_port(), str(tmp_path), native), nprocs=world, join=True)
+    # the same problem on one generated mesh (lattice order); lattice point g is caller vertex inv[g]
+    mesh = P.create_box(lo, hi, n)
+    inv = np.argsort(perm)                                  # xc[inv] = x: lattice point g is caller vertex inv[g]
+    lat_phi, lat_f, lat_uD = phi[inv], f[inv], uD[inv]
+    assert np.abs(mesh.x - xc[inv]).max() <= 1e-14
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        P.compute_tags_measures(mesh, NodalFunction(lat_phi), 1, box_mode=True, single_layer_cut=True)
+    s = P.PhiFEMSolver(mesh)
+    info = s.assemble(lat_phi, lat_f, lat_uD)
+    wref = s.solve(rtol=1e-11)
+    nv = mesh.nv
+    u = np.full(nv, np.nan)
+    p = np.full(nv, np.nan)
+    n_owned = 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), f"a{r}.npz"))
+        assert np.all(np.isnan(u[d["v"]]))                  # every caller vertex owned by exactly one rank
+        u[d["v"]], p[d["v"]] = d["u"], d["p"]
+        n_owned += int(d["n_owned"])
+        assert d["relres"] <= 1e-11
+        assert str(d["path"]) == ("native" if native else "python")
+    assert not np.any(np.isnan(u)) and n_owned == info["n_active"]
+    scale = np.abs(wref).max()
+    assert np.abs(u[inv] - wref[:nv]).max() <= 1e-7 * scale
+    assert np.abs(p[inv] - wref[nv:]).max() <= 1e-7 * scale
+
+
+def test_caller_supplied_mesh_that_is_no_lattice_is_refused():
+    from phifem_amd.distributed import detect_kuhn_lattice
+    _, _, _, _, xc, _, _, _ = _caller_box()
+    lo, hi, n, lat = detect_kuhn_lattice(xc)
+    assert list(n) == [10, 14, 12] and np.unique(lat).size == xc.shape[0]
+    bad = xc.copy()
+    bad[5, 1] += 1e-9
+    with pytest.raises(ValueError, match="uniform lattice"):
+        detect_kuhn_lattice(bad)
+    with pytest.raises(ValueError, match="fill a tensor lattice"):
+        detect_kuhn_lattice(xc[:-1])
