@@ -150,6 +150,9 @@ struct P2B {
   }
 };
 
+// quadrature points of the cut-cell rule the tables of k_p2_cut are sized for: degree 4 + 2 kphi <= 8 -> 5^D
+#define P2_CUT_NQMAX(D) ((D) == 3 ? 125 : 25)
+
 struct P2Args {
   AsmArgs A;              // du/dp are indexed by ENTITY (vertex, or nv + edge); A.nv holds nv + ne
   const int32_t *c2e;
@@ -194,111 +197,242 @@ __global__ void k_p2_mark_active(int64_t nc, P2Args P, uint8_t *__restrict__ fu,
   for (int r = 0; r < B::NB; ++r) { fu[dof[r]] = 1; if (t == 2) fp[dof[r]] = 1; }
 }
 
-// --- dx((1,2)): main.py:113 stiffness and :143 source; GS lanes per cell, lane = (r, s) ----------
-template <int D, int GS>
+// local edge k of a simplex joins vertices (P2_EA, P2_EB): basix order, as c_tet_edge_a / P2B::edge -- compile-time copies
+// for the kernels that select by lane instead of indexing register arrays
+template <int D> struct P2E {
+  static constexpr int A[6] = {D == 3 ? 2 : 1, D == 3 ? 1 : 0, D == 3 ? 1 : 0, 0, 0, 0};
+  static constexpr int Bv[6] = {D == 3 ? 3 : 2, D == 3 ? 3 : 2, D == 3 ? 2 : 1, 3, 2, 1};
+};
+// coefficient of g_m in grad N_r at the barycentric point lam (lam: memory, any index)
+template <int D>
+__device__ __forceinline__ double p2_gradc_m(int r, int m, const double *lam) {
+  using B = P2B<D>;
+  if (r < B::N) return m == r ? 4.0 * lam[r] - 1.0 : 0.0;
+  int a, b; B::edge(r - B::N, a, b);
+  return m == a ? 4.0 * lam[b] : (m == b ? 4.0 * lam[a] : 0.0);
+}
+
+// --- dx((1,2)): main.py:113 stiffness and :143 source ---------------------------------------------
+// One wavefront per cell, lane = entry (r, s).  On an affine cell  K[r][s] = |K| sum_{m,n} (g_m . g_n) C[r][s][m][n]  with
+// C = sum_q w_q c_r,m(q) c_s,n(q)  (grad N_r = sum_m c_r,m g_m) a property of the RULE: the block tabulates C (and the
+// reference mass matrix for the source term, f being a P2 function) once in LDS and an entry costs (D+1)^2 multiply-adds
+// instead of a pass over the quadrature points.
+template <int D>
 __global__ void __launch_bounds__(256) k_p2_cells(int64_t nlist, const int32_t *__restrict__ list, P2Args P) {
   using B = P2B<D>;
-  const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t e = gid / GS;
-  const int l = (int)(gid % GS);
-  if (e >= nlist || l >= B::NB * B::NB) return;
-  const int r = l / B::NB, s = l % B::NB;
-  const int64_t c = list[e];
-  int32_t v[B::N], dof[B::NB];
-  double X[B::N][D];
-  load_cell<D>(P.A.cells, P.A.x, c, v, X);
-  p2_cell_dofs<D>(P, c, v, dof);
-  if (p2_row_skipped(P, P.A.du[dof[r]])) return;
-  Geo<D> G;
-  simplex_geometry<D>(X, G);
-  double GG[B::N][B::N];
-  gram<D>(G, GG);
-  double acc = 0.0, rhs = 0.0;
-  double fn[B::NB];
-  if (s == 0) for (int b = 0; b < B::NB; ++b) fn[b] = P.A.f[dof[b]];
-  for (int q = 0; q < P.cell.nq; ++q) {
-    const double *lam = P.cell.lam + (int64_t)q * B::N;
-    double cr[B::N], cs[B::N];
-    B::gradc(r, lam, cr);
-    B::gradc(s, lam, cs);
-    double k = 0.0;
-    for (int m = 0; m < B::N; ++m)
-      for (int n = 0; n < B::N; ++n) k += cr[m] * cs[n] * GG[m][n];
-    acc += P.cell.w[q] * k;
-    if (s == 0) rhs += P.cell.w[q] * B::interp(2, lam, fn) * B::val(r, lam);
+  constexpr int NB = B::NB, N = B::N, NN = N * N, NE2 = NB * NB;
+  __shared__ double CT[NN][NE2 | 1], Ms[NB][NB + 1];
+  __shared__ int32_t wdof[4][NB], wrow[4][NB];
+  __shared__ double wfn[4][NB];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int i = threadIdx.x; i < NN * NE2; i += 256) {
+    const int mn = i / NE2, rs = i - mn * NE2;
+    const int m = mn / N, n = mn - m * N, r = rs / NB, t = rs - r * NB;
+    double acc = 0.0;
+    for (int q = 0; q < P.cell.nq; ++q) {
+      const double *lam = P.cell.lam + (int64_t)q * N;
+      acc += P.cell.w[q] * p2_gradc_m<D>(r, m, lam) * p2_gradc_m<D>(t, n, lam);
+    }
+    CT[mn][rs] = acc;
   }
-  const int32_t row = P.A.du[dof[r]];
-  if (p2_row_skipped(P, row)) return;
-  slot_add(P.A.slots, row, dof[s], acc * G.vol);
-  if (s == 0) slot_rhs_add(P.A.slots, P.A.rhs, row, rhs * G.vol);
+  for (int i = threadIdx.x; i < NE2; i += 256) {
+    const int r = i / NB, t = i - r * NB;
+    double acc = 0.0;
+    for (int q = 0; q < P.cell.nq; ++q) {
+      const double *lam = P.cell.lam + (int64_t)q * N;
+      acc += P.cell.w[q] * B::val(r, lam) * B::val(t, lam);
+    }
+    Ms[r][t] = acc;
+  }
+  __syncthreads();
+  for (int64_t e = blockIdx.x * (int64_t)4 + wave; e < nlist; e += gridDim.x * (int64_t)4) {
+    const int64_t c = list[e];
+    int32_t v[N];
+    double X[N][D];
+    load_cell<D>(P.A.cells, P.A.x, c, v, X);
+    Geo<D> G;
+    simplex_geometry<D>(X, G);
+    double GG[N][N];
+    gram<D>(G, GG);
+    if (lane < NB) {
+      const int32_t dl = lane < N ? P.A.cells[c * N + lane] : P.nvert + P.c2e[c * B::NE + (lane - N)];
+      wdof[wave][lane] = dl;
+      wrow[wave][lane] = P.A.du[dl];
+      wfn[wave][lane] = P.A.f[dl];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int rs = lane; rs < NE2; rs += 64) {
+      const int r = rs / NB, t = rs - r * NB;
+      const int32_t row = wrow[wave][r];
+      if (p2_row_skipped(P, row)) continue;
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < N; ++m)
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc = __builtin_fma(GG[m][n], CT[m * N + n][rs], acc);
+      slot_add(P.A.slots, row, wdof[wave][t], acc * G.vol);
+      if (t == 0) {
+        double rhs = 0.0;
+        for (int b = 0; b < NB; ++b) rhs = __builtin_fma(wfn[wave][b], Ms[r][b], rhs);
+        slot_rhs_add(P.A.slots, P.A.rhs, row, rhs * G.vol);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // --- dx(2): penalisation main.py:115-122,144-149 and div(grad) terms :123-128,150 -----------------
-// one 256-thread block per cut cell, thread -> entries of the (2 NB)^2 mixed tensor
+// One WAVEFRONT per cut cell (four per block, a grid-stride loop over the list).  The 2 NB x 2 NB mixed tensor has three
+// distinct NB x NB blocks, each symmetric:  T_e[r][s] = sum_q w_q N_r N_s phi_q^e, e = 0 (u,u), 1 (u,p) = (p,u), 2 (p,p).
+// The basis values at the quadrature points belong to the RULE, not to the cell: the block tabulates them once in LDS
+// (N_r(q) and w_q N_r(q)), T_0 with them; per cell a lane evaluates phi_h at its quadrature points (phi_q -> LDS), then
+// lane = pair (r <= s) runs over q for T_1 and T_2 (two table reads, one broadcast read, three multiply-adds per point),
+// and the 4 NB^2 slot updates read the tables.  The right-hand sides int u_D N_r phi^e and the cell mean of f follow
+// from T_0, T_1 (u_D, f are P2 functions: int u_D N_r phi^e = sum_b u_D[b] T_e[r][b], sum_s N_s = 1) -- no second pass
+// over the points.  Round 3 gave every tensor entry a thread that re-evaluated the ten basis functions and phi_h at
+// each of the 125 points: 396 ms for the 7e5 cut cells of the 256^3 box, a quarter of the P2 step.
 template <int D>
 __global__ void __launch_bounds__(256) k_p2_cut(int64_t nlist, const int32_t *__restrict__ list, P2Args P) {
   using B = P2B<D>;
-  const int64_t e = blockIdx.x;
-  if (e >= nlist) return;
-  const int64_t c = list[e];
-  int32_t v[B::N], dof[B::NB];
-  double X[B::N][D];
-  load_cell<D>(P.A.cells, P.A.x, c, v, X);
-  p2_cell_dofs<D>(P, c, v, dof);
-  Geo<D> G;
-  simplex_geometry<D>(X, G);
-  double GG[B::N][B::N];
-  gram<D>(G, GG);
-  double ph[B::NB];
-  const int nphi = P.kphi == 1 ? B::N : B::NB;
-  for (int b = 0; b < nphi; ++b) ph[b] = P.A.phi[dof[b]];
-  const double h1 = 1.0 / G.h;
-  const double gam = P.A.gamma * G.vol;
-  constexpr int M = 2 * B::NB;
-  for (int idx = threadIdx.x; idx < M * M; idx += blockDim.x) {
-    const int a = idx / M, b = idx % M;
-    const int r = a % B::NB, s = b % B::NB;
-    const bool ap = a >= B::NB, bp = b >= B::NB;
-    const int e_phi = (ap ? 1 : 0) + (bp ? 1 : 0);
-    double acc = 0.0;
-    for (int q = 0; q < P.cut.nq; ++q) {
-      const double *lam = P.cut.lam + (int64_t)q * B::N;
-      double wv = P.cut.w[q] * B::val(r, lam) * B::val(s, lam);
-      if (e_phi) {
-        const double pq = B::interp(P.kphi, lam, ph);
-        wv *= e_phi == 2 ? pq * pq : pq;
-      }
-      acc += wv;
-    }
-    double val;
-    if (e_phi == 0) val = gam * h1 * h1 * acc + P.A.sigma * G.h * G.h * G.vol * B::lapl(r, GG) * B::lapl(s, GG);
-    else if (e_phi == 1) val = -gam * h1 * h1 * h1 * acc;
-    else val = gam * h1 * h1 * h1 * h1 * acc;
-    const int32_t row = ap ? P.A.dp[dof[r]] : P.A.du[dof[r]];
-    if (p2_row_skipped(P, row)) continue;
-    if (P.pneg) slot_add<true>(P.A.slots, row, bp ? -2 - dof[s] : dof[s], val);
-    else slot_add(P.A.slots, row, (bp ? P.A.nv : 0) + dof[s], val);
+  constexpr int NB = B::NB, N = B::N, NP = NB * (NB + 1) / 2, M = 2 * NB;
+  constexpr int NQS = P2_CUT_NQMAX(D);               // odd: rows r of the tables start in distinct banks
+  __shared__ double NqT[NB][NQS], NwT[NB][NQS], lamT[N][NQS];
+  __shared__ double T0s[NP];
+  __shared__ double phq[4][NQS + 1], Tw[4][2][NP + 1];
+  const int nq = P.cut.nq;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int i = threadIdx.x; i < NB * nq; i += 256) {
+    const int r = i / nq, q = i - r * nq;
+    const double v = B::val(r, P.cut.lam + (int64_t)q * N);
+    NqT[r][q] = v;
+    NwT[r][q] = P.cut.w[q] * v;
   }
-  // right-hand side: one thread per row of the mixed tensor
-  if (threadIdx.x < M) {
-    const int a = threadIdx.x, r = a % B::NB;
-    const bool ap = a >= B::NB;
-    double udn[B::NB], fn[B::NB];
-    for (int b = 0; b < B::NB; ++b) { udn[b] = P.A.ud[dof[b]]; fn[b] = P.A.f[dof[b]]; }
-    double acc = 0.0, fbar = 0.0;
-    for (int q = 0; q < P.cut.nq; ++q) {
-      const double *lam = P.cut.lam + (int64_t)q * B::N;
-      const double uq = B::interp(2, lam, udn);
-      double wv = P.cut.w[q] * uq * B::val(r, lam);
-      if (ap) wv *= B::interp(P.kphi, lam, ph);
-      acc += wv;
-      fbar += P.cut.w[q] * B::interp(2, lam, fn);
+  for (int i = threadIdx.x; i < N * nq; i += 256) {
+    const int m = i / nq, q = i - m * nq;
+    lamT[m][q] = P.cut.lam[(int64_t)q * N + m];
+  }
+  __syncthreads();
+  // this lane's pair (r <= s) of the symmetric blocks
+  int pr = 0, ps = 0;
+  {
+    int rem = lane < NP ? lane : 0;
+    while (rem >= NB - pr) { rem -= NB - pr; ++pr; }
+    ps = pr + rem;
+  }
+  if (threadIdx.x < NP) {
+    double acc = 0.0;
+    for (int q = 0; q < nq; ++q) acc = __builtin_fma(NwT[pr][q], NqT[ps][q], acc);
+    T0s[threadIdx.x] = acc;
+  }
+  __syncthreads();
+  auto pair_of = [](int r, int s) { const int a = r < s ? r : s, b = r < s ? s : r; return a * NB - (a * (a - 1)) / 2 + (b - a); };
+  // per-wave cell data: lane b < NB owns DoF b of the cell
+  __shared__ int32_t wdof[4][NB], wru[4][NB], wrp[4][NB];
+  __shared__ double wph[4][NB], wud[4][NB], wfn[4][NB], wlap[4][NB];
+  for (int64_t e = blockIdx.x * (int64_t)4 + wave; e < nlist; e += gridDim.x * (int64_t)4) {
+    const int64_t c = list[e];
+    int32_t v[N];
+    double X[N][D];
+    load_cell<D>(P.A.cells, P.A.x, c, v, X);
+    Geo<D> G;
+    simplex_geometry<D>(X, G);
+    if (lane < NB) {
+      const int32_t dl = lane < N ? P.A.cells[c * N + lane] : P.nvert + P.c2e[c * B::NE + (lane - N)];
+      wdof[wave][lane] = dl;
+      wru[wave][lane] = P.A.du[dl];
+      wrp[wave][lane] = P.A.dp[dl];
+      wph[wave][lane] = (P.kphi == 2 || lane < N) ? P.A.phi[dl] : 0.0;
+      wud[wave][lane] = P.A.ud[dl];
+      wfn[wave][lane] = P.A.f[dl];
+      // Laplacian of N_lane (constant on the cell): 4 g_r.g_r (vertex), 8 g_a.g_b (edge)
+      double lp = 0.0;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int ia = k < N ? k : P2E<D>::A[k - N], ib = k < N ? k : P2E<D>::Bv[k - N];
+        double t = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) t = __builtin_fma(G.g[ia][d], G.g[ib][d], t);
+        lp = lane == k ? (k < N ? 4.0 : 8.0) * t : lp;
+      }
+      wlap[wave][lane] = lp;
     }
-    double rv;
-    if (!ap) rv = gam * h1 * h1 * acc - P.A.sigma * G.h * G.h * G.vol * fbar * B::lapl(r, GG);   // :147 (v), :150
-    else rv = -gam * h1 * h1 * h1 * acc;                                                          // :147 (q)
-    const int32_t rrow = ap ? P.A.dp[dof[r]] : P.A.du[dof[r]];
-    if (!p2_row_skipped(P, rrow)) slot_rhs_add(P.A.slots, P.A.rhs, rrow, rv);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // phi_h at the quadrature points
+    for (int q = lane; q < nq; q += 64) {
+      double t = 0.0;
+      if (P.kphi == 1) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) t = __builtin_fma(lamT[i][q], wph[wave][i], t);
+      } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) t = __builtin_fma(NqT[b][q], wph[wave][b], t);
+      }
+      phq[wave][q] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      double t1 = 0.0, t2 = 0.0;
+      const double *nw = NwT[pr], *nn = NqT[ps], *pq = phq[wave];
+#pragma unroll 5
+      for (int q = 0; q < nq; ++q) {
+        const double a = nw[q] * nn[q], f = pq[q], af = a * f;
+        t1 += af;
+        t2 = __builtin_fma(af, f, t2);
+      }
+      if (lane < NP) { Tw[wave][0][lane] = t1; Tw[wave][1][lane] = t2; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double h1 = 1.0 / G.h;
+    const double gam = P.A.gamma * G.vol;
+    const double shv = P.A.sigma * G.h * G.h * G.vol;
+    for (int idx = lane; idx < M * M; idx += 64) {
+      const int a = idx / M, b = idx - a * M;
+      const bool ap = a >= NB, bp = b >= NB;
+      const int r = ap ? a - NB : a, s = bp ? b - NB : b;
+      const int e_phi = (ap ? 1 : 0) + (bp ? 1 : 0);
+      const int32_t row = ap ? wrp[wave][r] : wru[wave][r];
+      if (p2_row_skipped(P, row)) continue;
+      const int pi = pair_of(r, s);
+      double val;
+      if (e_phi == 0) val = gam * h1 * h1 * T0s[pi] + shv * wlap[wave][r] * wlap[wave][s];
+      else if (e_phi == 1) val = -gam * h1 * h1 * h1 * Tw[wave][0][pi];
+      else val = gam * h1 * h1 * h1 * h1 * Tw[wave][1][pi];
+      const int32_t ds = wdof[wave][s];
+      if (P.pneg) slot_add<true>(P.A.slots, row, bp ? -2 - ds : ds, val);
+      else slot_add(P.A.slots, row, (bp ? P.A.nv : 0) + ds, val);
+    }
+    // right-hand side: one lane per row of the mixed tensor
+    if (lane < M) {
+      const int a = lane;
+      const bool ap = a >= NB;
+      const int r = ap ? a - NB : a;
+      double acc = 0.0, fbar = 0.0;
+      for (int b = 0; b < NB; ++b) {
+        const int pi = pair_of(r, b);
+        acc = __builtin_fma(wud[wave][b], ap ? Tw[wave][0][pi] : T0s[pi], acc);
+      }
+      if (!ap)
+        for (int b = 0; b < NB; ++b) {
+          double mb = 0.0;                                   // int N_b / |K|
+          for (int s2 = 0; s2 < NB; ++s2) mb += T0s[pair_of(b, s2)];
+          fbar = __builtin_fma(wfn[wave][b], mb, fbar);
+        }
+      double rv;
+      if (!ap) rv = gam * h1 * h1 * acc - shv * fbar * wlap[wave][r];   // :147 (v), :150
+      else rv = -gam * h1 * h1 * h1 * acc;                               // :147 (q)
+      const int32_t rrow = ap ? wrp[wave][r] : wru[wave][r];
+      if (!p2_row_skipped(P, rrow)) slot_rhs_add(P.A.slots, P.A.rhs, rrow, rv);
+    }
+    // the next cell overwrites the per-wave tables: every lane is past its reads
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -351,72 +485,115 @@ __global__ void __launch_bounds__(256) k_p2_ds(int64_t nent, const int64_t *__re
 }
 
 // --- dS((2,3)): main.py:129-134  sigma avg(h) int_F [grad u . n][grad v . n] ----------------------
-// one block per facet; the quadrature points are placed through the "+" cell and located in the
-// "-" cell by its barycentric coordinates
+// One wavefront per facet.  The quadrature points are placed through the "+" cell and located in the "-" cell by its
+// barycentric coordinates; lane (id, q) evaluates the normal derivative J[id][q] of basis function id (0 .. NB-1 on "+",
+// NB .. 2 NB - 1 on "-", with the sign of its side's outward normal) ONCE into LDS, then lane = entry (a, b) sums
+// w_q J[a][q] J[b][q].  (Round 3: every entry's thread recomputed both cells' geometry and its two derivatives per point.)
+#define P2_FACET_NQMAX 4
 template <int D>
 __global__ void __launch_bounds__(256) k_p2_facets(int64_t nlist, const int32_t *__restrict__ list, P2Args P) {
   using B = P2B<D>;
-  const int64_t e = blockIdx.x;
-  if (e >= nlist) return;
-  const int64_t f = list[e];
-  int32_t dofs[2 * B::NB];
-  double Xc[2][B::N][D];
-  Geo<D> G[2];
-  int lfs[2];
-  double gdotn[2][B::N], hsum = 0.0, area = 0.0;
-  for (int side = 0; side < 2; ++side) {
-    const int64_t c = P.A.f2c[2 * f + side];
-    int32_t v[B::N];
-    load_cell<D>(P.A.cells, P.A.x, c, v, Xc[side]);
-    p2_cell_dofs<D>(P, c, v, dofs + side * B::NB);
-    simplex_geometry<D>(Xc[side], G[side]);
-    int lf = 0;
-    for (int k = 0; k < B::N; ++k)
-      if (P.A.c2f[c * B::N + k] == (int32_t)f) lf = k;
-    lfs[side] = lf;
-    double gn = 0.0;
-    for (int d = 0; d < D; ++d) gn += G[side].g[lf][d] * G[side].g[lf][d];
-    gn = sqrt(gn);
-    if (side == 0) area = D * G[0].vol * gn;
-    hsum += G[side].h;
-    for (int m = 0; m < B::N; ++m) {
-      double t = 0.0;
-      for (int d = 0; d < D; ++d) t += G[side].g[m][d] * G[side].g[lf][d];
-      gdotn[side][m] = -t / gn;
+  constexpr int NB = B::NB, N = B::N, M = 2 * NB;
+  __shared__ double Jw[4][M][P2_FACET_NQMAX + 1];
+  __shared__ int32_t wdof[4][M], wrow[4][M];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nq = P.facet.nq;
+  for (int64_t e = blockIdx.x * (int64_t)4 + wave; e < nlist; e += gridDim.x * (int64_t)4) {
+    const int64_t f = list[e];
+    double Xc[2][N][D];
+    Geo<D> G[2];
+    int lf0 = 0;
+    int64_t cs[2];
+    double gdotn[2][N], hsum = 0.0, area = 0.0;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      const int64_t c = P.A.f2c[2 * f + side];
+      cs[side] = c;
+      int32_t v[N];
+      load_cell<D>(P.A.cells, P.A.x, c, v, Xc[side]);
+      simplex_geometry<D>(Xc[side], G[side]);
+      int lf = 0;
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+        if (P.A.c2f[c * N + k] == (int32_t)f) lf = k;
+      if (side == 0) lf0 = lf;
+      // g_lf by selection (lf is wave-uniform but not a compile-time index)
+      double gl[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        double t = G[side].g[0][d];
+#pragma unroll
+        for (int k = 1; k < N; ++k) t = lf == k ? G[side].g[k][d] : t;
+        gl[d] = t;
+      }
+      double gn = 0.0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) gn += gl[d] * gl[d];
+      gn = sqrt(gn);
+      if (side == 0) area = D * G[0].vol * gn;
+      hsum += G[side].h;
+#pragma unroll
+      for (int m = 0; m < N; ++m) {
+        double t = 0.0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) t += G[side].g[m][d] * gl[d];
+        gdotn[side][m] = -t / gn;
+      }
     }
-  }
-  const double wgt = P.A.sigma * 0.5 * hsum * area;
-  constexpr int M = 2 * B::NB;
-  for (int idx = threadIdx.x; idx < M * M; idx += blockDim.x) {
-    const int a = idx / M, b = idx % M;
-    double acc = 0.0;
-    for (int q = 0; q < P.facet.nq; ++q) {
+    const double wgt = P.A.sigma * 0.5 * hsum * area;
+    if (lane < M) {
+      const int side = lane >= NB ? 1 : 0, r = lane - side * NB;
+      const int64_t c = cs[side];
+      const int32_t dl = r < N ? P.A.cells[c * N + r] : P.nvert + P.c2e[c * B::NE + (r - N)];
+      wdof[wave][lane] = dl;
+      wrow[wave][lane] = P.A.du[dl];
+    }
+    for (int i = lane; i < M * nq; i += 64) {
+      const int id = i / nq, q = i - id * nq;
+      const int side = id >= NB ? 1 : 0, r = id - side * NB;
       const double *mu = P.facet.lam + (int64_t)q * D;
-      double lamp[B::N], lamm[B::N], xq[D];
-      facet_embed<D>(lfs[0], mu, lamp);
+      // the point in the "+" cell: the facet's vertices are the cell's vertices but lf0, in order
+      double lamp[N], xq[D], lam[N], gd[N];
+#pragma unroll
+      for (int m = 0; m < N; ++m) lamp[m] = m == lf0 ? 0.0 : mu[m < lf0 ? m : m - 1];
+#pragma unroll
       for (int d = 0; d < D; ++d) {
         double t = 0.0;
-        for (int m = 0; m < B::N; ++m) t += lamp[m] * Xc[0][m][d];
+#pragma unroll
+        for (int m = 0; m < N; ++m) t += lamp[m] * Xc[0][m][d];
         xq[d] = t;
       }
-      for (int m = 0; m < B::N; ++m) {
+#pragma unroll
+      for (int m = 0; m < N; ++m) {
         double t = m == 0 ? 1.0 : 0.0;
+#pragma unroll
         for (int d = 0; d < D; ++d) t += G[1].g[m][d] * (xq[d] - Xc[1][0][d]);
-        lamm[m] = t;
+        lam[m] = side ? t : lamp[m];
+        gd[m] = side ? gdotn[1][m] : gdotn[0][m];
       }
-      double J[2];
-      for (int w = 0; w < 2; ++w) {
-        const int id = w == 0 ? a : b;
-        const int side = id / B::NB;
-        double cc[B::N];
-        B::gradc(id % B::NB, side == 0 ? lamp : lamm, cc);
-        double t = 0.0;
-        for (int m = 0; m < B::N; ++m) t += cc[m] * gdotn[side][m];
-        J[w] = t;
+      // grad N_r . n = sum_m c_m (g_m . n)
+      double Jv = 0.0;
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const int ia = k < N ? k : P2E<D>::A[k - N], ib = k < N ? k : P2E<D>::Bv[k - N];
+        const double t = k < N ? (4.0 * lam[k] - 1.0) * gd[k] : 4.0 * (lam[ib] * gd[ia] + lam[ia] * gd[ib]);
+        Jv = r == k ? t : Jv;
       }
-      acc += P.facet.w[q] * J[0] * J[1];
+      Jw[wave][id][q] = Jv;
     }
-    if (!p2_row_skipped(P, P.A.du[dofs[a]])) slot_add(P.A.slots, P.A.du[dofs[a]], dofs[b], wgt * acc);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int idx = lane; idx < M * M; idx += 64) {
+      const int a = idx / M, b = idx - a * M;
+      const int32_t row = wrow[wave][a];
+      if (p2_row_skipped(P, row)) continue;
+      double acc = 0.0;
+      for (int q = 0; q < nq; ++q) acc += P.facet.w[q] * Jw[wave][a][q] * Jw[wave][b][q];
+      slot_add(P.A.slots, row, wdof[wave][b], wgt * acc);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -442,6 +619,8 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
   PHX_CHECK(upload_rule(m, D, 4, &P.cell, keep));
   PHX_CHECK(upload_rule(m, D, 4 + 2 * kphi, &P.cut, keep));
   PHX_CHECK(upload_rule(m, D - 1, 3, &P.facet, keep));
+  PHX_REQUIRE(P.cut.nq <= P2_CUT_NQMAX(D), PHX_ERR_VALUE, "cut-cell rule larger than the tables of k_p2_cut");
+  PHX_REQUIRE(P.facet.nq <= P2_FACET_NQMAX, PHX_ERR_VALUE, "facet rule larger than the tables of k_p2_facets");
   // facet rules carry D barycentric coordinates per point
   uint8_t *fu = nullptr, *fp = nullptr;
   int32_t *su = nullptr, *sp = nullptr;
@@ -505,13 +684,14 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
     sl.pass = pass;
     P.A.slots = sl;
     if (n_om > 0) {
-      PHX_REQUIRE_GRID(n_om * (D == 2 ? 64 : 128), "P2 cell assembly");
-      if (D == 2) k_p2_cells<2, 64><<<dim3((unsigned)phx_div_up(n_om * 64, 256)), block, 0, m->stream>>>(n_om, l_om, P);
-      else k_p2_cells<3, 128><<<dim3((unsigned)phx_div_up(n_om * 128, 256)), block, 0, m->stream>>>(n_om, l_om, P);
+      const dim3 gom((unsigned)std::min<int64_t>(phx_div_up(n_om, 4), 4096));
+      if (D == 2) k_p2_cells<2><<<gom, block, 0, m->stream>>>(n_om, l_om, P);
+      else k_p2_cells<3><<<gom, block, 0, m->stream>>>(n_om, l_om, P);
     }
     if (n_cut > 0) {
-      if (D == 2) k_p2_cut<2><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, P);
-      else k_p2_cut<3><<<dim3((unsigned)n_cut), block, 0, m->stream>>>(n_cut, l_cut, P);
+      const dim3 gcut((unsigned)std::min<int64_t>(phx_div_up(n_cut, 4), 4096));
+      if (D == 2) k_p2_cut<2><<<gcut, block, 0, m->stream>>>(n_cut, l_cut, P);
+      else k_p2_cut<3><<<gcut, block, 0, m->stream>>>(n_cut, l_cut, P);
     }
     PHX_HIP(hipGetLastError());
     if (nds > 0) {
@@ -521,8 +701,9 @@ static int assemble_p2_with_capacity(phx_mesh *m, double pen_coef, double stab_c
       else k_p2_ds<3, 128><<<dim3((unsigned)phx_div_up(nds * 128, 256)), block, 0, m->stream>>>(nds, pk, pr, P);
     }
     if (n_fac > 0) {
-      if (D == 2) k_p2_facets<2><<<dim3((unsigned)n_fac), block, 0, m->stream>>>(n_fac, l_fac, P);
-      else k_p2_facets<3><<<dim3((unsigned)n_fac), block, 0, m->stream>>>(n_fac, l_fac, P);
+      const dim3 gfac((unsigned)std::min<int64_t>(phx_div_up(n_fac, 4), 4096));
+      if (D == 2) k_p2_facets<2><<<gfac, block, 0, m->stream>>>(n_fac, l_fac, P);
+      else k_p2_facets<3><<<gfac, block, 0, m->stream>>>(n_fac, l_fac, P);
     }
     PHX_HIP(hipGetLastError());
   }

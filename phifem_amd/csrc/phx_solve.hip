@@ -1576,7 +1576,11 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   if (s->n == 0) return PHX_OK;  // empty system (a slab outside the domain): the dot-product slots stay zero
   const dim3 block(256);
   const uint8_t *own = s->own;
-  const int xg = s->mesh->spmv_xcd_group;
+  static const int xg_env = getenv("PHX_SPMV_XCD_GROUP") ? atoi(getenv("PHX_SPMV_XCD_GROUP")) : -1;   // tuning aid
+  // 0 (the default): round robin -- except on structured P2 systems, whose stored rows (4e6 rows of ~50 entries at 256^3)
+  // gather from more x lines than one L2 holds: XCD k takes 32 consecutive blocks of every run of 256, its rows' neighbours
+  // then meet in ITS L2 (SpMV pair 1278 -> 1096 us at 256^3; 16 ... 256 measure alike, contiguous eighths 1680; P1: no effect)
+  const int xg = xg_env >= 0 ? xg_env : (s->mesh->spmv_xcd_group ? s->mesh->spmv_xcd_group : (s->p2s ? 32 : 0));
   const uint8_t *kinds = vals == s->sell_val ? s->sell_kind : s->sell_kind_raw;
   const int32_t *rows = s->structured ? s->sell_rows : nullptr;
   DotPart dp{nullptr, nullptr};
@@ -1601,6 +1605,9 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   if (part == 2) nb_sell = 0;
   int64_t nb = nb_sell;
   static const int sell_xcd = getenv("PHX_SELL_XCD") ? atoi(getenv("PHX_SELL_XCD")) : 0;   // experiment: 1 = contiguous eighths
+  // structured systems: a multiple of 8 SELL blocks (the surplus finds no slice), so that blockIdx % 8 is the XCD
+  if (s->structured) nb_sell = (nb_sell + 7) & ~(int64_t)7;
+  nb = nb_sell;
   if (s->structured && s->nseg > 0 && part != 1) {
     // the stencil blocks start at a multiple of 8 so that blockIdx % 8 (the XCD a block lands on) is theirs to
     // use: XCD k walks the k-th contiguous eighth of the rows, whose x entries then stay in ITS 4 MiB L2
