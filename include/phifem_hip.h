@@ -148,8 +148,7 @@ enum phx_option {
                                from this mesh's tags; 0/1: imposed by a multi-GPU driver that
                                reduced it over all slabs                                        */
   PHX_OPT_SPMV_XCD_GROUP = 3, /* G > 0: SpMV blocks are regrouped so that each XCD (blockIdx % 8)
-                               walks runs of G consecutive blocks; 0 (default): plain order, except
-                               structured P2 systems (G = 32, measured)                           */
+                               walks runs of G consecutive blocks; 0: plain order (default)      */
   PHX_OPT_PRECOND = 5, /* 1 (default): P1 Poisson systems on Kuhn boxes (2-D, 3-D) are preconditioned with the
                                lattice Laplacian of a box around the active vertices, inverted by f64 sine
                                transforms (u block; p block: Jacobi); 2: the same with f32 transforms -- 25 %

@@ -1577,10 +1577,7 @@ static int launch_spmv(phx_system *s, const double *vals, const double *x, doubl
   const dim3 block(256);
   const uint8_t *own = s->own;
   static const int xg_env = getenv("PHX_SPMV_XCD_GROUP") ? atoi(getenv("PHX_SPMV_XCD_GROUP")) : -1;   // tuning aid
-  // 0 (the default): round robin -- except on structured P2 systems, whose stored rows (4e6 rows of ~50 entries at 256^3)
-  // gather from more x lines than one L2 holds: XCD k takes 32 consecutive blocks of every run of 256, its rows' neighbours
-  // then meet in ITS L2 (SpMV pair 1278 -> 1096 us at 256^3; 16 ... 256 measure alike, contiguous eighths 1680; P1: no effect)
-  const int xg = xg_env >= 0 ? xg_env : (s->mesh->spmv_xcd_group ? s->mesh->spmv_xcd_group : (s->p2s ? 32 : 0));
+  const int xg = xg_env >= 0 ? xg_env : s->mesh->spmv_xcd_group;
   const uint8_t *kinds = vals == s->sell_val ? s->sell_kind : s->sell_kind_raw;
   const int32_t *rows = s->structured ? s->sell_rows : nullptr;
   DotPart dp{nullptr, nullptr};
