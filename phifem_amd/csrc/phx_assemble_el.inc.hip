@@ -258,11 +258,36 @@ k_el_bulk_box(int64_t nthreads, BoxDims bd, const uint8_t *__restrict__ touched,
 }
 
 // --- cut cells: penalization main.py:188-203, cell stabilisation :211-217, rhs :255-260 ------------
+// block pairs (rb, cb) of the cut-cell tensor that carry a term at all (255 of the 27^2 = 729 in 3-D): the same
+// conditions as in the body of k_el_cut, on the block codes alone
+template <int D>
+__device__ __forceinline__ bool el_cut_pair_present(int rb, int cb) {
+  using B = ElB<D>;
+  int kr, ar, br, kc, ac, bc;
+  B::decode(rb, kr, ar, br);
+  B::decode(cb, kc, ac, bc);
+  if (kr <= 1 && kc <= 1) return kr == kc || ar == ac;
+  if (kr <= 1 && (kc == 2 || kc == 3)) return kr == kc - 2;
+  if ((kr == 2 || kr == 3) && kc <= 1) return kc == kr - 2;
+  if ((kr == 2 || kr == 3) && (kc == 2 || kc == 3)) return ar == ac;
+  return ar == ac;   // u - p, p - u, p - p
+}
+
+// One workgroup per cut cell.  Round 4: the threads walk the entries of the PRESENT block pairs only (listed once per
+// workgroup in LDS) instead of all (27 (D+1))^2 = 11664 entries of the tensor, two thirds of which carry no term.
 template <int D>
 __global__ void __launch_bounds__(256) k_el_cut(int64_t nlist, const int32_t *__restrict__ list, ElArgs A) {
   using B = ElB<D>;
   const int64_t e = blockIdx.x;
   if (e >= nlist) return;
+  __shared__ uint16_t present[B::C * B::C];
+  __shared__ int npresent;
+  if (threadIdx.x == 0) npresent = 0;
+  __syncthreads();
+  for (int pi = threadIdx.x; pi < B::C * B::C; pi += blockDim.x)
+    if (el_cut_pair_present<D>(pi / B::C, pi % B::C)) present[atomicAdd(&npresent, 1)] = (uint16_t)pi;
+  __syncthreads();
+  const int nent = npresent * B::N * B::N;
   const int64_t c = list[e];
   int32_t v[B::N];
   double X[B::N][D];
@@ -281,9 +306,9 @@ __global__ void __launch_bounds__(256) k_el_cut(int64_t nlist, const int32_t *__
   }
   const double h1 = 1.0 / G.h, gam = A.gamma;
   const double sgn[2] = {1.0, -1.0};
-  for (int idx = threadIdx.x; idx < B::R * B::R; idx += blockDim.x) {
-    const int r = idx / B::R, s = idx % B::R;
-    const int rb = r / B::N, i = r % B::N, cb = s / B::N, j = s % B::N;
+  for (int idx = threadIdx.x; idx < nent; idx += blockDim.x) {
+    const int pair = present[idx / (B::N * B::N)], ij = idx % (B::N * B::N);
+    const int rb = pair / B::C, cb = pair % B::C, i = ij / B::N, j = ij % B::N;
     int kr, ar, br, kc, ac, bc;
     B::decode(rb, kr, ar, br);
     B::decode(cb, kc, ac, bc);
