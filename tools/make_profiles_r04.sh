@@ -57,15 +57,20 @@ if has config3; then
   pmc c3 'k_spmv_sell|k_spmv_p2s|k_dst_yp|k_tri_z' --config3 --cubes 256 --steps 1 --warmup 0 --no-cpu-baseline
   rec c3 "k_spmv_sell+k_spmv_p2s" "k_spmv_sell+k_spmv_p2s" $O/bench_config3_p2_256_n1.json spmv pmc_spmv_config3_256.json "SpMV of the structured P2 system (SELL-16 band rows + class stencils), 256^3"
   rec c3 "k_dst_yp<384" k_dst_yp $O/bench_config3_p2_256_n1.json dst pmc_dst_config3_256.json "sine transform along y of the 384 x 384 x 354 fine lattice"
+  # the line again, now quoting the traffic just measured
+  cp $O/pmc_spmv_config3_256.json $O/pmc_dst_config3_256.json $R/profiles/r04/
+  timeout -k 10 600 python bench.py --config3 --cubes 256 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_config3_p2_256_n1.json 2> $O/bench_config3_256.err; echo "c3-256 (final) rc=$?"
 fi
 if has config4; then
   timeout -k 10 600 python bench.py --config4 --cubes 96 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_config4_el_96_n1.json 2> $O/bench_config4.err; echo "c4 rc=$?"
   stats config4_96 --config4 --cubes 96 --steps 2 --warmup 1 --no-cpu-baseline
   pmc c4 'k_spmv_sell|k_bj_apply' --config4 --cubes 96 --steps 1 --warmup 0 --no-cpu-baseline
   rec c4 "k_spmv_sell" k_spmv_sell $O/bench_config4_el_96_n1.json spmv pmc_spmv_config4_96.json "SpMV of the interface-elasticity system (SELL-64, value-indexed slices), 96^3"
+  cp $O/pmc_spmv_config4_96.json $R/profiles/r04/
+  timeout -k 10 600 python bench.py --config4 --cubes 96 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_config4_el_96_n1.json 2> $O/bench_config4.err; echo "c4 (final) rc=$?"
 fi
 if has big; then
-  timeout -k 10 900 python bench.py --config3 --cubes 512 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_config3_p2_512_n1.json 2> $O/bench_config3_512.err; echo "c3-512 rc=$?"
+  timeout -k 10 1000 python bench.py --config3 --cubes 512 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_config3_p2_512_n1.json 2> $O/bench_config3_512.err; echo "c3-512 rc=$?"
   timeout -k 10 600 python bench.py --config4 --cubes 256 --steps 2 --warmup 2 --no-cpu-baseline > $O/bench_config4_el_256_n1.json 2> $O/bench_config4_256.err; echo "c4-256 rc=$?"
 fi
 rm -f $O/*.err
