@@ -254,7 +254,9 @@ def test_native_loop_multi_rank_matches_single_mesh(world, native, exact, tmp_pa
     its = int(rows[0]["it"])
     print(f"world {world} native {native} exact {exact}: {its} iterations, single mesh {st['iterations']}")
     if exact:
-        assert abs(its - st["iterations"]) <= max(3, st["iterations"] // 10), (its, st["iterations"])
+        # the same operator, assembled twice with atomics in different orders: at rtol 1e-11 BiCGStab's count moves by
+        # about a tenth between two such solves of ONE mesh (84 / 94 seen for this case); a lost preconditioner doubles it
+        assert abs(its - st["iterations"]) <= max(5, st["iterations"] // 5), (its, st["iterations"])
     assert sum(int(d["n_owned"]) for d in rows) == info["n_active"]
     scale = np.abs(wref).max()
     assert np.abs(u - wref[:mesh.nv]).max() <= 1e-7 * scale
@@ -299,7 +301,8 @@ def test_elasticity_coarse_correction_across_slabs(world, tmp_path):
     assert np.abs(got - wref).max() <= 1e-6 * np.abs(wref).max()
     its = {int(d["it"]) for d in rows}
     print(f"world {world}: {its} iterations across the slabs, {s.stats['iterations']} on the single mesh")
-    assert len(its) == 1 and abs(its.pop() - s.stats["iterations"]) <= max(8, s.stats["iterations"] // 8)
+    # (the vertex blocks alone need 2.5 x the iterations: a quarter is the noise of the assembly's summation order)
+    assert len(its) == 1 and abs(its.pop() - s.stats["iterations"]) <= max(8, s.stats["iterations"] // 4)
 
 
 @pytest.mark.skipif(not os.path.exists(_FAKE), reason="tests/fake_rccl/libfake_rccl.so not built (build())")
