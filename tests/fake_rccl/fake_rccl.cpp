@@ -172,15 +172,22 @@ static void host_fn(void *arg) {
   delete x;
 }
 
+// which HIP call failed, with the runtime's own words and the operands (a launch error of the CALLER's earlier kernel
+// surfaces in whatever HIP call comes next: the message names it)
+static int fail_hip(const char *what, hipError_t e, const void *p, size_t bytes) {
+  fprintf(stderr, "fake_rccl: %s: %s (pointer %p, %zu bytes)\n", what, hipGetErrorString(e), p, bytes);
+  return 1;
+}
 static int enqueue(Ctx *x, const void *src, void *dst, size_t in_bytes, size_t out_bytes, hipStream_t st) {
   size_t si = 0, so = 0;
+  hipError_t e;
   if (in_bytes) {
     x->in = (char *)stage_get(in_bytes, &si);
-    if (hipMemcpyAsync(x->in, src, in_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return fail("D2H");
+    if ((e = hipMemcpyAsync(x->in, src, in_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail_hip("D2H", e, src, in_bytes);
   }
   if (out_bytes) x->out = (char *)stage_get(out_bytes, &so);
-  if (hipLaunchHostFunc(st, host_fn, x) != hipSuccess) return fail("hipLaunchHostFunc");
-  if (out_bytes && hipMemcpyAsync(dst, x->out, out_bytes, hipMemcpyHostToDevice, st) != hipSuccess) return fail("H2D");
+  if ((e = hipLaunchHostFunc(st, host_fn, x)) != hipSuccess) return fail_hip("hipLaunchHostFunc", e, x, 0);
+  if (out_bytes && (e = hipMemcpyAsync(dst, x->out, out_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return fail_hip("H2D", e, dst, out_bytes);
   if (in_bytes) stage_release_after(si, st);
   if (out_bytes) stage_release_after(so, st);
   if (g_sync && hipStreamSynchronize(st) != hipSuccess) return fail("stream sync");
