@@ -132,3 +132,35 @@ def test_slab_layout_covers_the_box():
             assert lay["k1"] == min(n * world, (r + 1) * n + GHOST_LAYERS)
             planes += list(range(lay["P0"], lay["P1"]))
         assert planes == list(range(n * world + 1))
+
+
+def test_lattice_of_a_caller_supplied_box_is_recognised_in_any_vertex_order():
+    """Host half of ArraySlabProblem (the partitioned solve itself: tests/test_hip_multirank.py): the tensor lattice behind
+    shuffled vertices, the lattice index of every vertex, and what is refused."""
+    from oracle import meshgen
+    from phifem_amd.distributed import detect_kuhn_lattice
+    lo, hi, n = [-1.4, -1.6, -1.5], [1.6, 1.5, 1.7], [5, 7, 6]
+    x, _ = meshgen.create_box(lo, hi, n)
+    perm = np.random.default_rng(3).permutation(x.shape[0])
+    lo2, hi2, n2, lat = detect_kuhn_lattice(x[perm])
+    assert np.allclose(lo2, lo, atol=0, rtol=1e-15) and np.allclose(hi2, hi, atol=0, rtol=1e-15) and list(n2) == n
+    assert np.array_equal(lat, perm)                       # generated order IS lattice order: x[perm][v] is point perm[v]
+    bad = x[perm].copy()
+    bad[4, 2] += 1e-9
+    with pytest.raises(ValueError, match="uniform lattice"):
+        detect_kuhn_lattice(bad)
+    with pytest.raises(ValueError, match="fill a tensor lattice"):
+        detect_kuhn_lattice(x[perm][1:])
+    with pytest.raises(ValueError, match="z-slabs"):
+        detect_kuhn_lattice(x[:, :2])
+    # every slab's lattice points map to distinct caller vertices and the slabs cover the box
+    world, nz = 3, n[2]
+    lat2v = np.empty(lat.size, dtype=np.int64)
+    lat2v[lat] = np.arange(lat.size)
+    plane = (n[0] + 1) * (n[1] + 1)
+    owned = []
+    for r in range(world):
+        lay = slab_layout(nz // world, r, world)
+        owned.append(lat2v[lay["P0"] * plane:lay["P1"] * plane])
+    allv = np.concatenate(owned)
+    assert allv.size == x.shape[0] and np.unique(allv).size == x.shape[0]

@@ -264,3 +264,20 @@ def test_structured_p2_interior_rows_match_the_stored_matrix(P, n, kphi):
     # the true residual of the structured solve through the exported (generic) matrix
     r = M @ w[dof] - rhs
     assert np.linalg.norm(r) <= 1e-8 * np.linalg.norm(rhs)
+
+
+@pytest.mark.parametrize("d,n,kphi", [(2, 10, 2), (3, 5, 1), (3, 5, 2)])
+def test_p2_coupling_blocks_are_bit_symmetric_when_assembled_exactly(P, d, n, kphi):
+    """The (u, p) and (p, u) blocks of the cut-cell penalty are ONE table of integrals int N_r N_s phi_h (k_p2_cut computes
+    each pair (r <= s) once, main.py:115-122): with the exact accumulation (deterministic=True: every slot is an exact sum,
+    whatever the order) A[u_v, p_w] == A[p_w, u_v] to the last bit, and the same inside the (p, p) block.  The (u, u) block
+    carries the one-sided boundary term -int (grad u . n) v and is not symmetric."""
+    work, V, phi, f, uex, A, b, act = setup(P, d, n, kphi)
+    s = P.PhiFEMSolver(work, degree=2, levelset_degree=kphi, deterministic=True)
+    info = s.assemble(phi, f, uex)
+    rowptr, col, val, rhs, dof = s.export_csr()
+    H = sp.csr_matrix((val, col, rowptr), shape=(rowptr.size - 1,) * 2)
+    nu = info["n_active_u"]
+    Hup, Hpu, Hpp = H[:nu, nu:].tocsr(), H[nu:, :nu].T.tocsr(), H[nu:, nu:].tocsr()
+    assert Hup.nnz > 0 and (Hup != Hpu).nnz == 0
+    assert (Hpp != Hpp.T).nnz == 0
