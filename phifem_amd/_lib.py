@@ -147,7 +147,9 @@ def sync_torch_stream(device):
     """The library's kernels run on the mesh's own NON-BLOCKING stream, which does not wait for torch's streams:
     whatever torch still has queued for a tensor must have run before its raw pointer crosses the C ABI."""
     import torch
-    torch.cuda.current_stream(device).synchronize()
+    st = torch.cuda.current_stream(device)
+    if not st.query():        # nothing queued (every pointer after the first of an API call): no host wait (ADVICE r3)
+        st.synchronize()
 
 
 def ptr(a):
