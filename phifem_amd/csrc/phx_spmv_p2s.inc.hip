@@ -297,21 +297,29 @@ int phx_system_build_structured_p2(phx_system *s, const phx_slot_view &sv, int32
 }
 
 // y_r = sum_o coef[class(r)][o] x[r + off(o)] over the runs; DOTS as k_spmv_sell.
-// One wavefront per run, 128 rows per trip: a lane owns TWO consecutive rows, one of each parity class of the line, so
+// One wavefront per run, 124 rows per trip: a lane owns TWO consecutive rows, one of each parity class of the line, so
 // every coefficient is a wave-uniform SCALAR operand and each class is computed once (round 3 had every lane accumulate
 // both classes of its row and keep one: twice the multiply-adds; a per-lane coefficient select had turned the
-// coefficient into a dependent vector load per term before that).  Per trip and dz plane the neighbouring lines (128 + 4
-// entries each) are staged in LDS with coalesced loads; the lane's two rows need the SIX entries 2 lane .. 2 lane + 5 of
-// a line: three 16-byte LDS reads for ten terms (round 3: five 8-byte reads for the five terms of one row).
+// coefficient into a dependent vector load per term before that).  The lane's two rows need the SIX entries
+// 2 lane .. 2 lane + 5 of each neighbouring line.  Round 4, first version: the lines staged in LDS (coalesced 8-byte
+// loads, three 16-byte LDS reads per line) -- 32 LDS bytes per row and line, and the kernel ran at 60 % of the LDS peak
+// with its fetch traffic irrelevant.  Now NO LDS: the lane loads entries 2 lane, 2 lane + 1 as one
+// 16-byte access (the wavefront reads 1 KB contiguously) and takes entries + 2 .. + 5 from lanes + 1 and + 2 with DPP
+// wave shifts.  A trip covers 124 rows: lanes 62 and 63 only supply entries 124 .. 127 to their neighbours.
+__device__ __forceinline__ double2 p2s_shl1(double2 v) {   // lane l <- lane l + 1 (lane 63 <- 0)
+  int w[4] = {__double2loint(v.x), __double2hiint(v.x), __double2loint(v.y), __double2hiint(v.y)};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w[q] = __builtin_amdgcn_update_dpp(0, w[q], 0x130, 0xf, 0xf, true);   // wave_shl:1
+  return make_double2(__hiloint2double(w[1], w[0]), __hiloint2double(w[3], w[2]));
+}
+
 template <int DOTS>
 __global__ void __launch_bounds__(256)
 k_spmv_p2s(int64_t nrun, const int32_t *__restrict__ runs, const double *__restrict__ tabE,
            const double *__restrict__ tabO, const unsigned *__restrict__ linemask, const double *__restrict__ x,
            double *__restrict__ y, const double *__restrict__ d0, double *__restrict__ out0, double *__restrict__ out1,
            DotPart part) {
-  __shared__ double2 xs_all[4][5][68];   // 132 doubles of a line used
   const int lane = threadIdx.x & 63;
-  double2 (*xs)[68] = xs_all[threadIdx.x >> 6];
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double p0 = 0.0, p1 = 0.0;
   for (int64_t w = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6)); w < nrun; w += nwaves) {
@@ -321,64 +329,50 @@ k_spmv_p2s(int64_t nrun, const int32_t *__restrict__ runs, const double *__restr
     const unsigned lm = linemask[bc];
     // class of the lane's first / second row: the run starts with class a0 and a trip starts at an even offset
     const double *cA = (a0 ? tabO : tabE) + (size_t)bc * 125, *cB = (a0 ? tabE : tabO) + (size_t)bc * 125;
-    for (int base = 0; base < len; base += 128) {
+    for (int base = 0; base < len; base += 124) {
       const int i = base + 2 * lane;
-      const bool onA = i < len, onB = i + 1 < len;
+      const bool onA = lane < 62 && i < len, onB = lane < 62 && i + 1 < len;
       const int64_t r0 = (int64_t)first + base;
       // entries i - 2 .. i + 2 of every neighbouring line exist for the rows of the run (their whole 5 x 5 x 5
-      // neighbourhood is C0)
-      // (entry e of a staged line = position base - 2 + e of the run's coordinates; the lane loads entries lane, 64 + lane
-      // -- contiguous across the wavefront -- and lanes 0..3 entries 128 + lane)
-      const bool ok0 = base - 2 + lane < len + 2, ok1 = base + 62 + lane < len + 2, ok2 = lane < 4 && base + 126 + lane < len + 2;
+      // neighbourhood is C0): entry e of a line = position base - 2 + e of the run's coordinates, e < len + 4 - base
+      const bool ok0 = base - 2 + 2 * lane < len + 2, ok1 = base - 1 + 2 * lane < len + 2;
       double aA = 0.0, aB = 0.0;
-      double v0[5], vh[5];
-      double v1[5];
-      // the loads of plane dz into v0 / vh / v1 (lines without a coefficient skipped: wave-uniform)
-      auto load_plane = [&](int dz) {
+      double2 qc[5], qn[5];
+      auto load_plane = [&](int dz, double2 *q) {
         const unsigned pm = (lm >> (5 * dz)) & 31u;
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy) {
-          v0[dy] = 0.0; vh[dy] = 0.0; v1[dy] = 0.0;
+          q[dy] = make_double2(0.0, 0.0);
           if ((pm >> dy) & 1u) {
             const double *xl = x + (r0 + rec[3 + dy + 5 * dz] - 2);
-            if (ok0) v0[dy] = xl[lane];
-            if (ok1) vh[dy] = xl[64 + lane];
-            if (ok2) v1[dy] = xl[128 + lane];
+            if (ok1) __builtin_memcpy(&q[dy], xl + 2 * lane, sizeof(double2));   // 8-byte aligned: one 16-byte access
+            else if (ok0) q[dy].x = xl[2 * lane];
           }
         }
       };
       // planes with a coefficient, in order; the loads of the next one are in flight while this one is multiplied
       int dz = 0;
       while (dz < 5 && ((lm >> (5 * dz)) & 31u) == 0u) ++dz;
-      if (dz < 5) load_plane(dz);
+      if (dz < 5) load_plane(dz, qc);
 #pragma unroll 1
       while (dz < 5) {
         const unsigned pm = (lm >> (5 * dz)) & 31u;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();      // the previous plane has been read
-#pragma unroll
-        for (int dy = 0; dy < 5; ++dy) {
-          double *xd = reinterpret_cast<double *>(&xs[dy][0]);
-          xd[lane] = v0[dy];
-          xd[64 + lane] = vh[dy];
-          if (lane < 4) xd[128 + lane] = v1[dy];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         int nz = dz + 1;
         while (nz < 5 && ((lm >> (5 * nz)) & 31u) == 0u) ++nz;
-        if (nz < 5) load_plane(nz);
+        if (nz < 5) load_plane(nz, qn);
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy) {
           if ((pm >> dy) & 1u) {
             const double *ca = cA + (5 * dz + dy) * 5, *cb = cB + (5 * dz + dy) * 5;
-            const double2 q0 = xs[dy][lane], q1 = xs[dy][lane + 1], q2 = xs[dy][lane + 2];
+            const double2 q0 = qc[dy], q1 = p2s_shl1(q0), q2 = p2s_shl1(q1);
             aA = __builtin_fma(ca[0], q0.x, aA); aA = __builtin_fma(ca[1], q0.y, aA); aA = __builtin_fma(ca[2], q1.x, aA);
             aA = __builtin_fma(ca[3], q1.y, aA); aA = __builtin_fma(ca[4], q2.x, aA);
             aB = __builtin_fma(cb[0], q0.y, aB); aB = __builtin_fma(cb[1], q1.x, aB); aB = __builtin_fma(cb[2], q1.y, aB);
             aB = __builtin_fma(cb[3], q2.x, aB); aB = __builtin_fma(cb[4], q2.y, aB);
           }
         }
+#pragma unroll
+        for (int dy = 0; dy < 5; ++dy) qc[dy] = qn[dy];
         dz = nz;
       }
       const int64_t r = r0 + 2 * lane;
