@@ -322,11 +322,12 @@ k_spmv_p2s(int64_t nrun, const int32_t *__restrict__ runs, const double *__restr
   const int lane = threadIdx.x & 63;
   const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
   double p0 = 0.0, p1 = 0.0;
+  const unsigned lm0 = linemask[0], lm1 = linemask[1], lm2 = linemask[2], lm3 = linemask[3];
   for (int64_t w = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6)); w < nrun; w += nwaves) {
     const int32_t *rec = runs + (int64_t)PHX_P2S_REC * w;
     const int first = rec[0], len = rec[1], bits = rec[2];
     const int bc = bits & 3, a0 = bits >> 2;
-    const unsigned lm = linemask[bc];
+    const unsigned lm = bc == 0 ? lm0 : bc == 1 ? lm1 : bc == 2 ? lm2 : lm3;   // (no load behind the record's)
     // class of the lane's first / second row: the run starts with class a0 and a trip starts at an even offset
     const double *cA = (a0 ? tabO : tabE) + (size_t)bc * 125, *cB = (a0 ? tabE : tabO) + (size_t)bc * 125;
     for (int base = 0; base < len; base += 124) {
