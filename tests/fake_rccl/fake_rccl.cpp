@@ -186,8 +186,11 @@ static int enqueue(Ctx *x, const void *src, void *dst, size_t in_bytes, size_t o
     if ((e = hipMemcpyAsync(x->in, src, in_bytes, hipMemcpyDeviceToHost, st)) != hipSuccess) return fail_hip("D2H", e, src, in_bytes);
   }
   if (out_bytes) x->out = (char *)stage_get(out_bytes, &so);
+  // host_fn deletes its context when it is done, and it may be done before the next line runs: nothing of *x is read
+  // after the launch (reading x->out there was a use-after-free that failed one H2D copy in a few hundred runs)
+  char *const out = x->out;
   if ((e = hipLaunchHostFunc(st, host_fn, x)) != hipSuccess) return fail_hip("hipLaunchHostFunc", e, x, 0);
-  if (out_bytes && (e = hipMemcpyAsync(dst, x->out, out_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return fail_hip("H2D", e, dst, out_bytes);
+  if (out_bytes && (e = hipMemcpyAsync(dst, out, out_bytes, hipMemcpyHostToDevice, st)) != hipSuccess) return fail_hip("H2D", e, dst, out_bytes);
   if (in_bytes) stage_release_after(si, st);
   if (out_bytes) stage_release_after(so, st);
   if (g_sync && hipStreamSynchronize(st) != hipSuccess) return fail("stream sync");
